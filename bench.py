@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- MoFREAK descriptors/sec on dense 1080p frames (BASELINE.json config 3) on N MI355X.
+
+A "step" is one pass of the hot path over the resident batch: --pairs frame pairs of a synthetic
+1920x1080 stack (pair i = frames i+5 and i), the dense 8-px grid of 29 106 size-12 keypoints in each pair,
+inputs already in HBM, through the C ABI (mofreak_extract_pairs, device pointers).  N > 1: one process per
+GPU, every rank its own stack (weak scaling), no data-path collective; the final row gather over RCCL is
+timed separately and reported as gather_ms.
+
+Prints ONE JSON line (rank 0).  See DESIGN.md section "Measurement" for how roofline.achieved is defined.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def make_stack(T, W, H, t0, workers):
+    from mofreak_amd import synth
+    out = np.empty((T, H, W), np.uint8)
+
+    def one(t):
+        out[t] = synth.synth_frame(t0 + t, W, H)
+
+    with ThreadPoolExecutor(workers) as ex:  # numpy releases the GIL in the heavy ufuncs
+        list(ex.map(one, range(T)))
+    return out
+
+
+def cpu_baseline(frames, kps, n_pairs, cores):
+    """The CPU oracle (a port, not the reference binary) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    f = oracle_lib.Freak()
+    f.extract_pair(frames[5], frames[0], kps[:64])  # warm the library
+
+    def one(p):
+        d, v = f.extract_pair(frames[p + 5], frames[p], kps)  # ctypes releases the GIL
+        return int(v.sum())
+
+    t = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        n = sum(ex.map(one, range(n_pairs)))
+    dt = time.perf_counter() - t
+    return {"value": n / dt, "unit": "descriptors/s", "cores": cores, "kind": "port",
+            "sample": f"{n_pairs} of the workload's 1920x1080 pairs x {len(kps)} keypoints, oracle/mofreak_oracle.c "
+                      f"(gcc -O2, strict FP), {cores} threads over pairs, {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=256, help="resident frame pairs per GPU")
+    ap.add_argument("--config", default="C3", help="synthetic config (C3 = the metric's: 1080p, 8-px grid)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=64)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import mofreak_amd as M
+    from mofreak_amd import harness, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = synth.CONFIGS[args.config]
+    W, H = cfg["W"], cfg["H"]
+    kps = synth.config_grid(args.config)
+    n_kp, n_pairs, gap = len(kps), args.pairs, synth.GAP_FOR_FRAME_DIFFERENCE
+    T = n_pairs + gap
+    ncpu = len(os.sched_getaffinity(0))
+    workers = max(1, min(16, ncpu // max(1, world)))
+    frames = make_stack(T, W, H, t0=1000 * rank, workers=workers)
+
+    ctx = M.Context(local_rank)
+    d_frames = torch.from_numpy(frames).cuda()
+    d_kps = torch.from_numpy(kps).cuda()
+    n_desc = n_pairs * n_kp
+    desc = torch.empty((n_desc, 16), dtype=torch.uint8, device="cuda")
+    valid = torch.empty(n_desc, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()  # a real (non-null) stream shared by torch and the library
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
+    ctx.reserve(W, H)
+
+    def step():
+        ctx.extract_pairs(d_frames[gap:], d_frames[:n_pairs], W, H, n_pairs, d_kps, desc, valid)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.set_profiling(True)  # HIP events around every kernel group, on the stream the kernels run on
+    ctx.get_profile(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.get_profile(reset=True)
+    ctx.set_profiling(False)
+    ctx.check_status()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_valid = int(valid.sum().item())
+    assert n_valid == n_desc, f"{n_desc - n_valid} keypoints were erased: the grid is supposed to be border-safe"
+
+    # the path's one exchange step: gather the compacted 32-byte rows to rank 0 (not part of a step)
+    rows = torch.empty(n_desc * 32, dtype=torch.uint8, device="cuda")
+    n_rows = ctx.compact_rows(d_kps, n_pairs, gap - 1, desc, valid, rows)
+    gather_ms = None
+    if world > 1:
+        fence()
+        tg = time.perf_counter()
+        allrows, counts = harness.gather_rows(rows, n_rows, dst=0)
+        fence()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        if rank == 0:
+            assert sum(counts) == world * n_rows and allrows.numel() == sum(counts) * 32
+
+    if rank == 0:
+        total_desc = world * n_desc * args.steps
+        value = total_desc / elapsed
+        b_alg_pair = 2 * W * H + 28 * n_kp  # frames read once + keypoints in + descriptors out
+        launches = max(prof["launches"], 1)
+        describe_ms_avg = prof["describe_ms"] / launches
+        pairs_per_launch = prof["pairs"] / launches
+        achieved = b_alg_pair * pairs_per_launch / (describe_ms_avg * 1e-3) / 1e9
+        pipeline_gbs = b_alg_pair * prof["pairs"] / ((prof["describe_ms"] + prof["integral_ms"]) * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("describe_kernel_hbm_bytes_per_launch")
+        out = {
+            "metric": "MoFREAK descriptors/sec on dense 1080p frames; achieved HBM GB/s vs peak",
+            "value": value, "unit": "descriptors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {n_pairs} resident {W}x{H} frame pairs per GPU, dense {cfg['step']}-px grid, "
+                                   f"{n_kp} keypoints/pair of size {cfg['size']}, 16-byte descriptors",
+                       "descriptors_per_step_per_gpu": n_desc, "bit_mode": "SSE", "parallelism": f"one stack per GPU x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "describe_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_pair": b_alg_pair, "pairs_per_launch": pairs_per_launch,
+                         "avg_launch_ms": describe_ms_avg, "launches_timed": prof["launches"],
+                         "integral_group_avg_ms": prof["integral_ms"] / launches,
+                         "pipeline_achieved_GBs": pipeline_gbs, "pipeline_frac": pipeline_gbs / HBM_PEAK_GBS},
+            "gather_ms": gather_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cp = min(args.cpu_pairs, n_pairs)
+            out["cpu_baseline"] = cpu_baseline(frames, kps, cp, cores=min(ncpu, 16))
+        print(json.dumps(out), flush=True)
+    ctx.set_stream(None)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,207 @@
+/*
+ * mofreak_hip.h -- C ABI of libmofreak_hip.so, the MI355X (gfx950) implementation of the MoFREAK
+ * descriptor-extraction path of ChrisWhiten/MoFREAK.
+ *
+ * The reference exposes this path only as methods of the C++ class MoFREAKUtilities (there is no C ABI
+ * or plugin interface upstream).  Each entry point below names the reference code it replaces
+ * (paths relative to the reference's src/MoFREAK/).  INTEGRATION.md shows the binding a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *  - every function returns an int status (MOFREAK_OK or a negative MOFREAK_ERR_*); nothing throws or
+ *    exits across this boundary; mofreak_last_error() returns the message of the last failure;
+ *  - one context per host thread / HIP stream; contexts are independent;
+ *  - buffers are caller-owned.  `flags` says whether the pointers of a call are device pointers
+ *    (MOFREAK_MEM_DEVICE, the fast path: nothing is copied) or host pointers (MOFREAK_MEM_HOST: the
+ *    library stages them through its own device buffers and synchronises before returning);
+ *  - device-pointer calls are asynchronous on the context's stream unless stated otherwise.
+ */
+#ifndef MOFREAK_HIP_H
+#define MOFREAK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOFREAK_ABI_VERSION 1
+
+/* status codes */
+#define MOFREAK_OK 0
+#define MOFREAK_ERR_BAD_ARG (-1)
+#define MOFREAK_ERR_HIP (-2)
+#define MOFREAK_ERR_OOM (-3)
+#define MOFREAK_ERR_UNSUPPORTED (-4)
+#define MOFREAK_ERR_NO_DEVICE (-5)
+#define MOFREAK_ERR_ROI (-6)       /* a keypoint's MIP ROI left the image (reference: cv::Exception) */
+#define MOFREAK_ERR_CAPACITY (-7)  /* output buffer too small */
+
+/* device_id for mofreak_create that builds the host tables only (no GPU needed): the table accessors
+ * below work on such a context, every compute entry point returns MOFREAK_ERR_NO_DEVICE. */
+#define MOFREAK_TABLES_ONLY (-1)
+
+/* flags */
+#define MOFREAK_MEM_DEVICE 0u
+#define MOFREAK_MEM_HOST 1u
+
+/* FREAK pair-bit layout; OpenCV 2.4.2's binary is not available to pin it */
+#define MOFREAK_BITS_SSE 0        /* v[i] >= v[j], SSE byte order: OpenCV >= 2.4.3, and 2.4.2 built with CV_SSE2 */
+#define MOFREAK_BITS_NATURAL 1    /* v[i] >  v[j], std::bitset order: 2.4.2 built without CV_SSE2 */
+#define MOFREAK_BITS_SSE_SIGNED 2 /* (int8)v[i] > (int8)v[j], SSE byte order */
+
+#define MOFREAK_APPEARANCE_BYTES 8 /* MoFREAKUtilities.h:21 */
+#define MOFREAK_MOTION_BYTES 8     /* MoFREAKUtilities.h:20 */
+#define MOFREAK_DESC_BYTES 16
+
+typedef struct mofreak_ctx mofreak_ctx;
+
+/* Algorithm constants; mofreak_default_params() fills in the reference's values. */
+typedef struct mofreak_params {
+    int32_t struct_size;                  /* sizeof(mofreak_params), set by mofreak_default_params */
+    int32_t gap_for_frame_difference;     /* 5      MoFREAKUtilities.cpp:378 */
+    int32_t mip_theta;                    /* 288    MoFREAKUtilities.cpp:48 */
+    float freak_pattern_scale;            /* 22.0f  cv::FREAK default ctor, MoFREAKUtilities.cpp:427 */
+    int32_t freak_n_octaves;              /* 4 */
+    int32_t freak_orientation_normalized; /* 1 */
+    int32_t freak_scale_normalized;       /* 1 */
+    int32_t freak_bit_mode;               /* MOFREAK_BITS_SSE */
+} mofreak_params;
+
+/* cv::KeyPoint fields the path reads (pt.x, pt.y, size). */
+typedef struct mofreak_keypoint {
+    float x, y, size;
+} mofreak_keypoint;
+
+/* One .mofreak row in binary: the fields of struct MoFREAKFeature (MoFREAKUtilities.h:23-53) that
+ * writeMoFREAKFeaturesToFile (MoFREAKUtilities.cpp:691-719) prints; motion_x/motion_y are always 0. */
+typedef struct mofreak_row {
+    float x, y;
+    int32_t frame_number;
+    float scale;
+    uint8_t appearance[MOFREAK_APPEARANCE_BYTES];
+    uint8_t motion[MOFREAK_MOTION_BYTES];
+} mofreak_row;
+
+/* ------------------------------------------------------------------ context */
+int mofreak_abi_version(void);
+int mofreak_default_params(mofreak_params *p);
+
+/* Replaces MoFREAKUtilities::MoFREAKUtilities (MoFREAKUtilities.cpp:5-8) plus the per-frame
+ * `cv::FREAK extractor;` construction (:427): builds the FREAK pattern LUT, orientation weights, pair
+ * table and the 19x19 resize coefficient tables ON THE HOST once and uploads them to `device_id`. */
+int mofreak_create(int device_id, const mofreak_params *params, mofreak_ctx **out);
+void mofreak_destroy(mofreak_ctx *ctx);
+/* Message of the last failure on ctx (ctx == NULL: of the last failed mofreak_create on this thread). */
+const char *mofreak_last_error(const mofreak_ctx *ctx);
+/* Run the context's work on an existing hipStream_t (e.g. torch's current stream); NULL = own stream. */
+int mofreak_set_stream(mofreak_ctx *ctx, void *hip_stream);
+int mofreak_synchronize(mofreak_ctx *ctx);
+/* Pre-size the internal workspace (integral images of one chunk of pairs) so that later calls do not
+ * allocate.  chunk_pairs <= 0 keeps the default.  Optional. */
+int mofreak_reserve(mofreak_ctx *ctx, int W, int H, int chunk_pairs);
+/* Synchronise and report per-keypoint anomalies seen by the kernels since the last call:
+ * MOFREAK_ERR_ROI / MOFREAK_ERR_UNSUPPORTED, else MOFREAK_OK.  Affected keypoints have out_valid = 0. */
+int mofreak_check_status(mofreak_ctx *ctx);
+
+/* Per-launch device timing, measured with HIP events on the context's stream around (a) the absdiff+integral
+ * kernel group and (b) the describe kernel of every chunk.  Off by default. */
+typedef struct mofreak_profile {
+    double integral_ms;  /* sum over chunks: band_kernel<A> + band_scan + band_kernel<C> */
+    double describe_ms;  /* sum over chunks: describe_kernel */
+    int64_t launches;    /* chunks timed (= describe_kernel launches) */
+    int64_t pairs;       /* frame pairs those launches covered */
+    int64_t descriptors; /* keypoint instances those launches covered */
+} mofreak_profile;
+int mofreak_set_profiling(mofreak_ctx *ctx, int enable);
+/* Synchronises, folds the recorded events into the running totals and returns them (reset != 0 clears them). */
+int mofreak_get_profile(mofreak_ctx *ctx, mofreak_profile *out, int reset);
+
+/* ------------------------------------------------------------------ the hot path */
+/*
+ * Descriptors for n_pairs frame pairs.  Replaces, per frame of computeMoFREAKFromFile's loop:
+ * cv::absdiff (MoFREAKUtilities.cpp:413-414), cv::FREAK::compute on the difference image (:427-428)
+ * with the copy of descriptor bytes 0..7 (:453-456), and extractMotionByMotionInterchangePatterns
+ * (:460 -> :288-325 -> motionInterchangePattern :46-99) on (current, previous).
+ *
+ *   cur, prev    gray u8 frames; pair p at cur + p*pair_stride, prev + p*pair_stride; rows row_stride apart
+ *                (a T-frame stack is the n_pairs = T-gap case with cur = frames + gap*H*W, prev = frames)
+ *   kps          keypoints, in the order the detector produced them
+ *   kp_offsets   NULL: the same n_kp keypoints are described in every pair (dense grid);
+ *                else n_pairs+1 int64 CSR offsets into kps (same memory space as kps), n_kp = total
+ *   out_desc16   n_out x 16 bytes (appearance[8], motion[8]); n_out = n_pairs*n_kp (shared list) or n_kp (CSR)
+ *   out_valid    n_out bytes: 0 where DescriptorExtractor::compute / FREAK::computeImpl would have ERASED the
+ *                keypoint (size < FLT_EPSILON, or within patternSizes[scale] of the border); its
+ *                descriptor bytes are zero.  No compaction here: see mofreak_compact_rows.
+ */
+int mofreak_extract_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, int W, int H,
+                          int64_t row_stride, int64_t pair_stride, int n_pairs,
+                          const mofreak_keypoint *kps, const int64_t *kp_offsets, int64_t n_kp,
+                          uint8_t *out_desc16, uint8_t *out_valid, unsigned flags);
+
+/*
+ * Stable (order-preserving) compaction of the valid keypoints into 32-byte rows: what the keypoint loop
+ * (MoFREAKUtilities.cpp:436-483) pushes into `features`.  Pair p gets frame_number first_frame_number + p
+ * (:401, :448, :488).  rows_out needs room for rows_capacity rows; *n_rows_out (host) receives the count.
+ * Synchronises the stream.
+ */
+int mofreak_compact_rows(mofreak_ctx *ctx, const mofreak_keypoint *kps, const int64_t *kp_offsets,
+                         int64_t n_kp, int n_pairs, int first_frame_number, const uint8_t *desc16,
+                         const uint8_t *valid, mofreak_row *rows_out, int64_t rows_capacity,
+                         int64_t *n_rows_out, unsigned flags);
+
+/*
+ * A whole gray frame stack: the frame loop of MoFREAKUtilities::computeMoFREAKFromFile
+ * (MoFREAKUtilities.cpp:391-489) after decoding -- prev is the frame `gap` earlier, the first processed
+ * frame (index gap) is labelled gap-1.  kp_offsets: NULL (same n_kp keypoints for each of the T-gap
+ * processed frames) or T-gap+1 CSR offsets.  T <= gap yields zero rows.  Synchronises the stream.
+ */
+int mofreak_extract_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W, int H,
+                           const mofreak_keypoint *kps, const int64_t *kp_offsets, int64_t n_kp,
+                           mofreak_row *rows_out, int64_t rows_capacity, int64_t *n_rows_out,
+                           unsigned flags);
+
+/* ------------------------------------------------------------------ .mofreak text (host only) */
+/* MoFREAKUtilities::writeMoFREAKFeaturesToFile (MoFREAKUtilities.cpp:691-719), byte for byte.  Writes at
+ * most cap bytes to buf (may be NULL) and always stores the full length in *needed. */
+int mofreak_format_rows(const mofreak_row *rows, int64_t n_rows, char *buf, size_t cap, size_t *needed);
+/* MoFREAKUtilities::readMoFREAKFeatures' row parser (MoFREAKUtilities.cpp:1146-1190), in FILE order (the
+ * reference then stores them reversed, :1206-1210).  rows may be NULL to count. */
+int mofreak_parse_rows(const char *text, size_t len, mofreak_row *rows, int64_t rows_capacity,
+                       int64_t *n_rows_out);
+
+/* ------------------------------------------------------------------ component entry points (parity tests) */
+/* cv::absdiff + cv::integral of the difference image: out is n_pairs x (H+1) x (W+1) int32. */
+int mofreak_diff_integral(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, int W, int H,
+                          int64_t row_stride, int64_t pair_stride, int n_pairs, int32_t *out,
+                          unsigned flags);
+/* motionInterchangePattern at the 8 patch centres on n given 19x19 buffer pairs (361 bytes each). */
+int mofreak_mip19(mofreak_ctx *ctx, const uint8_t *cur19, const uint8_t *prev19, int64_t n,
+                  uint8_t *out_motion8, unsigned flags);
+/* The two cv::resize(ROI -> 19x19) of extractMotionByMotionInterchangePatterns for one pair:
+ * out is n_kp x 2 x 361 bytes (current ROI, previous ROI); keypoints whose ROI leaves the image get zeros. */
+int mofreak_roi19(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, int W, int H,
+                  const mofreak_keypoint *kps, int64_t n_kp, uint8_t *out, unsigned flags);
+/* FREAK internals per keypoint of one pair: out_info[k] = {scaleIdx, thetaIdx, direction0, direction1}
+ * (thetaIdx = -1 for erased keypoints). */
+int mofreak_freak_info(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, int W, int H,
+                       const mofreak_keypoint *kps, int64_t n_kp, int32_t *out_info, unsigned flags);
+/* thetaIdx for n (direction0, direction1) int32 pairs. */
+int mofreak_theta_index(mofreak_ctx *ctx, const int32_t *dirs, int64_t n, int32_t *out, unsigned flags);
+/* Host-side tables the context was built with: patternSizes[64]; scale index of a keypoint size. */
+int mofreak_pattern_sizes(const mofreak_ctx *ctx, int32_t out[64]);
+int mofreak_scale_index(const mofreak_ctx *ctx, float size, int32_t *out);
+/* patternLookup[scale][rot][0..42] as (x, y, sigma) triples. */
+int mofreak_table_pattern(const mofreak_ctx *ctx, int scale, int rot, float out[43 * 3]);
+/* orientationPairs as (i, j, weight_dx, weight_dy). */
+int mofreak_table_orientation(const mofreak_ctx *ctx, int32_t out[45 * 4]);
+/* The point pair (i, j) behind each of the 64 bits of descriptor bytes 0..7 (bit b of byte B at index 8B+b). */
+int mofreak_table_bit_pairs(const mofreak_ctx *ctx, uint8_t out[128]);
+/* cv::resize(L -> 19) taps, x axis then y axis: (ofs, ofs1, c0, c1) per output index. */
+int mofreak_table_resize(const mofreak_ctx *ctx, int L, int16_t out[2 * 19 * 4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOFREAK_HIP_H */

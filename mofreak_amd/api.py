@@ -1,0 +1,378 @@
+"""ctypes binding of libmofreak_hip.so -- the C ABI declared in include/mofreak_hip.h.
+
+This module is plumbing: it hands pointers to the C ABI and nothing else.  Device memory comes from
+torch tensors (``tensor.data_ptr()``); there is NO CPU implementation behind it -- if the shared library
+is missing or no GPU is visible the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libmofreak_hip.so")
+
+OK = 0
+ERR_BAD_ARG, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_ROI, ERR_CAPACITY = -1, -2, -3, -4, -5, -6, -7
+MEM_DEVICE, MEM_HOST = 0, 1
+BITS_SSE, BITS_NATURAL, BITS_SSE_SIGNED = 0, 1, 2
+TABLES_ONLY = -1
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4")])
+ROW_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("frame_number", "<i4"), ("scale", "<f4"),
+                      ("appearance", "u1", (8,)), ("motion", "u1", (8,))])
+assert ROW_DTYPE.itemsize == 32
+
+# every symbol include/mofreak_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "mofreak_abi_version", "mofreak_default_params", "mofreak_create", "mofreak_destroy", "mofreak_last_error",
+    "mofreak_set_stream", "mofreak_synchronize", "mofreak_reserve", "mofreak_check_status",
+    "mofreak_set_profiling", "mofreak_get_profile",
+    "mofreak_extract_pairs", "mofreak_compact_rows", "mofreak_extract_stream", "mofreak_format_rows",
+    "mofreak_parse_rows", "mofreak_diff_integral", "mofreak_mip19", "mofreak_roi19", "mofreak_freak_info",
+    "mofreak_theta_index", "mofreak_pattern_sizes", "mofreak_scale_index", "mofreak_table_pattern",
+    "mofreak_table_orientation", "mofreak_table_bit_pairs", "mofreak_table_resize",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("gap_for_frame_difference", C.c_int32), ("mip_theta", C.c_int32),
+                ("freak_pattern_scale", C.c_float), ("freak_n_octaves", C.c_int32),
+                ("freak_orientation_normalized", C.c_int32), ("freak_scale_normalized", C.c_int32),
+                ("freak_bit_mode", C.c_int32)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("integral_ms", C.c_double), ("describe_ms", C.c_double), ("launches", C.c_int64),
+                ("pairs", C.c_int64), ("descriptors", C.c_int64)]
+
+
+class MoFREAKError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libmofreak_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libmofreak_hip.so (built in-tree by mofreak_amd.build / __graft_entry__.build()).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MoFREAKError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: run `python -m mofreak_amd.build` "
+                           "(hipcc, gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    L.mofreak_abi_version.restype = i32
+    L.mofreak_default_params.argtypes = [C.POINTER(Params)]
+    L.mofreak_create.argtypes = [i32, C.POINTER(Params), C.POINTER(vp)]
+    L.mofreak_destroy.argtypes = [vp]
+    L.mofreak_destroy.restype = None
+    L.mofreak_last_error.argtypes = [vp]
+    L.mofreak_last_error.restype = C.c_char_p
+    L.mofreak_set_stream.argtypes = [vp, vp]
+    L.mofreak_synchronize.argtypes = [vp]
+    L.mofreak_reserve.argtypes = [vp, i32, i32, i32]
+    L.mofreak_check_status.argtypes = [vp]
+    L.mofreak_set_profiling.argtypes = [vp, i32]
+    L.mofreak_get_profile.argtypes = [vp, C.POINTER(Profile), i32]
+    L.mofreak_extract_pairs.argtypes = [vp, vp, vp, i32, i32, i64, i64, i32, vp, vp, i64, vp, vp, C.c_uint]
+    L.mofreak_compact_rows.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, i64, C.POINTER(i64), C.c_uint]
+    L.mofreak_extract_stream.argtypes = [vp, vp, i32, i32, i32, vp, vp, i64, vp, i64, C.POINTER(i64), C.c_uint]
+    L.mofreak_format_rows.argtypes = [vp, i64, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mofreak_parse_rows.argtypes = [C.c_char_p, C.c_size_t, vp, i64, C.POINTER(i64)]
+    L.mofreak_diff_integral.argtypes = [vp, vp, vp, i32, i32, i64, i64, i32, vp, C.c_uint]
+    L.mofreak_mip19.argtypes = [vp, vp, vp, i64, vp, C.c_uint]
+    L.mofreak_roi19.argtypes = [vp, vp, vp, i32, i32, vp, i64, vp, C.c_uint]
+    L.mofreak_freak_info.argtypes = [vp, vp, vp, i32, i32, vp, i64, vp, C.c_uint]
+    L.mofreak_theta_index.argtypes = [vp, vp, i64, vp, C.c_uint]
+    L.mofreak_pattern_sizes.argtypes = [vp, vp]
+    L.mofreak_scale_index.argtypes = [vp, C.c_float, C.POINTER(C.c_int32)]
+    L.mofreak_table_pattern.argtypes = [vp, i32, i32, vp]
+    L.mofreak_table_orientation.argtypes = [vp, vp]
+    L.mofreak_table_bit_pairs.argtypes = [vp, vp]
+    L.mofreak_table_resize.argtypes = [vp, i32, vp]
+    _lib = L
+    return L
+
+
+def default_params(**overrides) -> Params:
+    p = Params()
+    load().mofreak_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _ptr(a) -> int:
+    """Address of a numpy array, a torch tensor, or None."""
+    if a is None:
+        return 0
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()  # torch.Tensor
+
+
+def _count_keypoints(kps) -> int:
+    """(n, 3) float32 array/tensor, a flat one of 3n floats, or a KEYPOINT_DTYPE array."""
+    if isinstance(kps, np.ndarray) and kps.dtype == KEYPOINT_DTYPE:
+        return int(kps.shape[0])
+    n = int(kps.shape[0])
+    return n if len(kps.shape) == 2 else n // 3
+
+
+def _row_capacity(rows) -> int:
+    """Rows a buffer can hold: a ROW_DTYPE array, or any byte buffer / tensor (32 bytes per row)."""
+    if isinstance(rows, np.ndarray):
+        return int(rows.shape[0]) if rows.dtype == ROW_DTYPE else int(rows.nbytes // 32)
+    return int(rows.numel() * rows.element_size() // 32)
+
+
+def _is_host(*arrays) -> bool:
+    kinds = set()
+    for a in arrays:
+        if a is None:
+            continue
+        kinds.add(isinstance(a, np.ndarray) or (hasattr(a, "is_cuda") and not a.is_cuda))
+    if len(kinds) > 1:
+        raise ValueError("mixing host and device buffers in one call")
+    return kinds.pop() if kinds else True
+
+
+class Context:
+    """One mofreak_ctx.  ``device=TABLES_ONLY`` builds the host tables without touching a GPU."""
+
+    def __init__(self, device: int = 0, **param_overrides):
+        self._lib = load()
+        self.params = default_params(**param_overrides)
+        h = C.c_void_p()
+        rc = self._lib.mofreak_create(device, C.byref(self.params), C.byref(h))
+        if rc != OK:
+            raise MoFREAKError(rc, (self._lib.mofreak_last_error(None) or b"").decode())
+        self._h = h
+        self.device = device
+
+    # ---- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mofreak_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != OK:
+            raise MoFREAKError(rc, (self._lib.mofreak_last_error(self._h) or b"").decode())
+
+    # ---- stream / workspace
+    def set_stream(self, stream_ptr: int | None):
+        self._check(self._lib.mofreak_set_stream(self._h, stream_ptr or None))
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def synchronize(self):
+        self._check(self._lib.mofreak_synchronize(self._h))
+
+    def reserve(self, W: int, H: int, chunk_pairs: int = 0):
+        self._check(self._lib.mofreak_reserve(self._h, W, H, chunk_pairs))
+
+    def check_status(self):
+        self._check(self._lib.mofreak_check_status(self._h))
+
+    def set_profiling(self, enable: bool):
+        self._check(self._lib.mofreak_set_profiling(self._h, int(enable)))
+
+    def get_profile(self, reset: bool = True) -> dict:
+        p = Profile()
+        self._check(self._lib.mofreak_get_profile(self._h, C.byref(p), int(reset)))
+        return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+    # ---- hot path
+    def extract_pairs(self, cur, prev, W, H, n_pairs, kps, out_desc, out_valid, kp_offsets=None, n_kp=None,
+                      row_stride=None, pair_stride=None):
+        """Raw call: buffers are numpy arrays (host) or torch cuda tensors (device), all of one kind."""
+        host = _is_host(cur, prev, kps, out_desc, out_valid, kp_offsets)
+        row_stride = W if row_stride is None else row_stride
+        pair_stride = W * H if pair_stride is None else pair_stride
+        if n_kp is None:
+            n_kp = _count_keypoints(kps)
+        self._check(self._lib.mofreak_extract_pairs(self._h, _ptr(cur), _ptr(prev), W, H, row_stride, pair_stride,
+                                                    n_pairs, _ptr(kps), _ptr(kp_offsets), n_kp, _ptr(out_desc),
+                                                    _ptr(out_valid), MEM_HOST if host else MEM_DEVICE))
+
+    def extract_pairs_host(self, cur: np.ndarray, prev: np.ndarray, kps: np.ndarray, kp_offsets=None):
+        """cur, prev: (n_pairs, H, W) u8; kps: (n, 3) f32 -> (desc16 (n_out,16), valid (n_out,))."""
+        cur = np.ascontiguousarray(cur, np.uint8)
+        prev = np.ascontiguousarray(prev, np.uint8)
+        if cur.ndim == 2:
+            cur, prev = cur[None], prev[None]
+        n_pairs, H, W = cur.shape
+        kps = np.ascontiguousarray(kps, np.float32).reshape(-1, 3)
+        n_kp = kps.shape[0]
+        if kp_offsets is not None:
+            kp_offsets = np.ascontiguousarray(kp_offsets, np.int64)
+            n_out = n_kp
+        else:
+            n_out = n_pairs * n_kp
+        desc = np.zeros((n_out, 16), np.uint8)
+        valid = np.zeros(n_out, np.uint8)
+        self.extract_pairs(cur, prev, W, H, n_pairs, kps, desc, valid, kp_offsets=kp_offsets, n_kp=n_kp)
+        return desc, valid
+
+    def compact_rows(self, kps, n_pairs, first_frame_number, desc, valid, rows_out, kp_offsets=None, n_kp=None) -> int:
+        host = _is_host(kps, desc, valid, rows_out, kp_offsets)
+        if n_kp is None:
+            n_kp = _count_keypoints(kps)
+        cap = _row_capacity(rows_out)
+        n = C.c_int64(0)
+        self._check(self._lib.mofreak_compact_rows(self._h, _ptr(kps), _ptr(kp_offsets), n_kp, n_pairs,
+                                                   first_frame_number, _ptr(desc), _ptr(valid), _ptr(rows_out), cap,
+                                                   C.byref(n), MEM_HOST if host else MEM_DEVICE))
+        return n.value
+
+    def extract_stream(self, frames, T, W, H, kps, rows_out, kp_offsets=None, n_kp=None) -> int:
+        host = _is_host(frames, kps, rows_out, kp_offsets)
+        if n_kp is None:
+            n_kp = _count_keypoints(kps)
+        cap = _row_capacity(rows_out)
+        n = C.c_int64(0)
+        self._check(self._lib.mofreak_extract_stream(self._h, _ptr(frames), T, W, H, _ptr(kps), _ptr(kp_offsets), n_kp,
+                                                     _ptr(rows_out), cap, C.byref(n), MEM_HOST if host else MEM_DEVICE))
+        return n.value
+
+    def extract_stream_host(self, frames: np.ndarray, kps: np.ndarray, kp_offsets=None) -> np.ndarray:
+        """frames (T,H,W) u8, keypoints shared by all processed frames or CSR -> structured rows."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        T, H, W = frames.shape
+        kps = np.ascontiguousarray(kps, np.float32).reshape(-1, 3)
+        gap = self.params.gap_for_frame_difference
+        n_pairs = max(T - gap, 0)
+        if kp_offsets is not None:
+            kp_offsets = np.ascontiguousarray(kp_offsets, np.int64)
+            cap = kps.shape[0]
+        else:
+            cap = n_pairs * kps.shape[0]
+        rows = np.zeros(max(cap, 1), ROW_DTYPE)
+        n = self.extract_stream(frames, T, W, H, kps, rows, kp_offsets=kp_offsets, n_kp=kps.shape[0])
+        return rows[:n].copy()
+
+    # ---- component entry points
+    def diff_integral_host(self, cur: np.ndarray, prev: np.ndarray) -> np.ndarray:
+        cur = np.ascontiguousarray(cur, np.uint8)
+        prev = np.ascontiguousarray(prev, np.uint8)
+        if cur.ndim == 2:
+            cur, prev = cur[None], prev[None]
+        n, H, W = cur.shape
+        out = np.zeros((n, H + 1, W + 1), np.int32)
+        self._check(self._lib.mofreak_diff_integral(self._h, _ptr(cur), _ptr(prev), W, H, W, W * H, n, _ptr(out), MEM_HOST))
+        return out
+
+    def mip19_host(self, cur19: np.ndarray, prev19: np.ndarray) -> np.ndarray:
+        cur19 = np.ascontiguousarray(cur19, np.uint8).reshape(-1, 361)
+        prev19 = np.ascontiguousarray(prev19, np.uint8).reshape(-1, 361)
+        out = np.zeros((cur19.shape[0], 8), np.uint8)
+        self._check(self._lib.mofreak_mip19(self._h, _ptr(cur19), _ptr(prev19), cur19.shape[0], _ptr(out), MEM_HOST))
+        return out
+
+    def roi19_host(self, cur: np.ndarray, prev: np.ndarray, kps: np.ndarray) -> np.ndarray:
+        cur = np.ascontiguousarray(cur, np.uint8)
+        prev = np.ascontiguousarray(prev, np.uint8)
+        kps = np.ascontiguousarray(kps, np.float32).reshape(-1, 3)
+        H, W = cur.shape
+        out = np.zeros((kps.shape[0], 2, 19, 19), np.uint8)
+        self._check(self._lib.mofreak_roi19(self._h, _ptr(cur), _ptr(prev), W, H, _ptr(kps), kps.shape[0], _ptr(out), MEM_HOST))
+        return out
+
+    def freak_info_host(self, cur: np.ndarray, prev: np.ndarray, kps: np.ndarray) -> np.ndarray:
+        cur = np.ascontiguousarray(cur, np.uint8)
+        prev = np.ascontiguousarray(prev, np.uint8)
+        kps = np.ascontiguousarray(kps, np.float32).reshape(-1, 3)
+        H, W = cur.shape
+        out = np.zeros((kps.shape[0], 4), np.int32)
+        self._check(self._lib.mofreak_freak_info(self._h, _ptr(cur), _ptr(prev), W, H, _ptr(kps), kps.shape[0], _ptr(out), MEM_HOST))
+        return out
+
+    def theta_index_host(self, dirs: np.ndarray) -> np.ndarray:
+        dirs = np.ascontiguousarray(dirs, np.int32).reshape(-1, 2)
+        out = np.zeros(dirs.shape[0], np.int32)
+        self._check(self._lib.mofreak_theta_index(self._h, _ptr(dirs), dirs.shape[0], _ptr(out), MEM_HOST))
+        return out
+
+    # ---- host tables
+    def pattern_sizes(self) -> np.ndarray:
+        out = np.zeros(64, np.int32)
+        self._check(self._lib.mofreak_pattern_sizes(self._h, _ptr(out)))
+        return out
+
+    def scale_index(self, size: float) -> int:
+        v = C.c_int32(0)
+        self._check(self._lib.mofreak_scale_index(self._h, float(np.float32(size)), C.byref(v)))
+        return v.value
+
+    def table_pattern(self, scale: int, rot: int) -> np.ndarray:
+        out = np.zeros((43, 3), np.float32)
+        self._check(self._lib.mofreak_table_pattern(self._h, scale, rot, _ptr(out)))
+        return out
+
+    def table_orientation(self) -> np.ndarray:
+        out = np.zeros((45, 4), np.int32)
+        self._check(self._lib.mofreak_table_orientation(self._h, _ptr(out)))
+        return out
+
+    def table_bit_pairs(self) -> np.ndarray:
+        out = np.zeros((64, 2), np.uint8)
+        self._check(self._lib.mofreak_table_bit_pairs(self._h, _ptr(out)))
+        return out
+
+    def table_resize(self, L: int) -> np.ndarray:
+        out = np.zeros((2, 19, 4), np.int16)
+        self._check(self._lib.mofreak_table_resize(self._h, L, _ptr(out)))
+        return out
+
+
+def format_rows(rows: np.ndarray) -> bytes:
+    """writeMoFREAKFeaturesToFile's text for structured rows (host only, no GPU needed)."""
+    rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+    L = load()
+    need = C.c_size_t(0)
+    rc = L.mofreak_format_rows(_ptr(rows), rows.shape[0], None, 0, C.byref(need))
+    if rc != OK:
+        raise MoFREAKError(rc, "format_rows")
+    buf = C.create_string_buffer(need.value + 1)
+    rc = L.mofreak_format_rows(_ptr(rows), rows.shape[0], buf, need.value, C.byref(need))
+    if rc != OK:
+        raise MoFREAKError(rc, "format_rows")
+    return buf.raw[:need.value]
+
+
+def parse_rows(text: bytes) -> np.ndarray:
+    """The row parser of readMoFREAKFeatures, in file order."""
+    L = load()
+    n = C.c_int64(0)
+    rc = L.mofreak_parse_rows(text, len(text), None, 0, C.byref(n))
+    if rc != OK:
+        raise MoFREAKError(rc, "parse_rows: malformed .mofreak text")
+    rows = np.zeros(max(n.value, 1), ROW_DTYPE)
+    rc = L.mofreak_parse_rows(text, len(text), _ptr(rows), n.value, C.byref(n))
+    if rc != OK:
+        raise MoFREAKError(rc, "parse_rows")
+    return rows[:n.value].copy()

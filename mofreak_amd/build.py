@@ -1,0 +1,45 @@
+"""In-tree build of libmofreak_hip.so (gfx950 kernels + C ABI) with hipcc.  No torch involved."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libmofreak_hip.so")
+SOURCES = ["kernels.hip", "capi.cpp", "tables.cpp", "format.cpp"]
+HEADERS = ["tables.h", "device_types.h", os.path.join("..", "..", "include", "mofreak_hip.h")]
+# -ffp-contract=off / -fno-fast-math: a handful of float/double expressions restate reference
+# expressions whose rounding is part of the result.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+         "-Wall", "-Wno-unused-result"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libmofreak_hip.so cannot be built (there is no CPU fallback)")
+    return exe
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    """Compile the shared library if it is missing or older than its sources; returns its path."""
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [hipcc(), *FLAGS, "-o", LIB_PATH, *[os.path.join(CSRC, s) for s in SOURCES]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_native(force=True, verbose=True))

@@ -1,0 +1,874 @@
+// C ABI of libmofreak_hip.so (include/mofreak_hip.h): context, workspace and launch sequencing.
+// No exception leaves this file; every entry point returns a status code.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "device_types.h"
+
+using namespace mofreak;
+
+namespace {
+thread_local std::string g_create_error;
+
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+}  // namespace
+
+struct mofreak_ctx {
+    int device = 0;
+    mofreak_params params{};
+    Tables tables;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cus = 256;
+    // device-resident tables
+    PatternPoint *d_lut = nullptr;
+    ResizeTap *d_resize = nullptr;
+    SmallTables *d_small = nullptr;
+    int32_t *d_status = nullptr;
+    // workspace (grown on demand, never shrunk)
+    DeviceBuffer integral, band_totals, scratch_desc, scratch_valid, compact_offsets, stage[6], offsets_dev;
+    int chunk_pairs_hint = 0;
+    // optional per-launch timing (mofreak_set_profiling): events around the integral group and the describe launch
+    bool profiling = false;
+    struct Span {
+        hipEvent_t e0, e1, e2;
+        int64_t pairs, items;
+    };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> event_pool;
+    mofreak_profile prof{};
+    mutable std::string err;
+};
+
+namespace {
+
+int fail(const mofreak_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx)
+        ctx->err = msg;
+    else
+        g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                              \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? MOFREAK_ERR_OOM : MOFREAK_ERR_HIP,             \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                             \
+    } while (0)
+
+#define NEED_DEVICE(ctx)                                                                                  \
+    do {                                                                                                  \
+        if ((ctx)->device < 0)                                                                            \
+            return fail(ctx, MOFREAK_ERR_NO_DEVICE, "tables-only context: no device work possible (there is no CPU fallback)"); \
+        HIP_TRY(ctx, hipSetDevice((ctx)->device));                                                        \
+    } while (0)
+
+int ensure(mofreak_ctx *ctx, DeviceBuffer &b, size_t bytes)
+{
+    if (b.bytes >= bytes && b.ptr) return MOFREAK_OK;
+    if (b.ptr) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(b.ptr));
+        b.ptr = nullptr;
+        b.bytes = 0;
+    }
+    bytes = std::max<size_t>(bytes, 256);
+    HIP_TRY(ctx, hipMalloc(&b.ptr, bytes));
+    b.bytes = bytes;
+    return MOFREAK_OK;
+}
+
+void release(DeviceBuffer &b)
+{
+    if (b.ptr) (void)hipFree(b.ptr);
+    b.ptr = nullptr;
+    b.bytes = 0;
+}
+
+inline int integral_pitch(int W) { return ((W + 3) / 4) * 4 + 4; }
+
+// Pairs per chunk: keep the chunk's integral images around 64 MiB so that they are still in the 256 MiB
+// Infinity Cache when the describe kernel reads them back.
+int choose_chunk(const mofreak_ctx *ctx, int W, int H, int n_pairs)
+{
+    const size_t per_pair = (size_t)(H + 1) * integral_pitch(W) * sizeof(int32_t);
+    int chunk = ctx->chunk_pairs_hint > 0 ? ctx->chunk_pairs_hint : (int)std::max<size_t>(1, ((size_t)64 << 20) / per_pair);
+    return std::max(1, std::min(chunk, n_pairs));
+}
+
+struct Geometry {
+    int W, H;
+    int64_t row_stride, pair_stride;
+};
+
+int validate_frames(const mofreak_ctx *ctx, const void *cur, const void *prev, int W, int H, int64_t row_stride,
+                    int64_t pair_stride, int n_pairs)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    if (n_pairs < 0 || W <= 0 || H <= 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "W, H must be positive and n_pairs >= 0");
+    if (n_pairs > 0 && (!cur || !prev)) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null frame pointer");
+    if (row_stride < W) return fail(ctx, MOFREAK_ERR_BAD_ARG, "row_stride < W");
+    if (n_pairs > 1 && pair_stride == 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "pair_stride is 0");
+    if ((size_t)kBandRows * integral_pitch(W) * sizeof(int32_t) > 160 * 1024)
+        return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "frame wider than the banded integral kernel supports (W <= 5112)");
+    if ((int64_t)(H + 1) * integral_pitch(W) >= ((int64_t)1 << 31))
+        return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "frame too large for 32-bit integral indexing");
+    return MOFREAK_OK;
+}
+
+// integral images of pairs [p0, p0+np) into ctx->integral
+int run_integral(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, const Geometry &g, int p0, int np)
+{
+    const int pitch = integral_pitch(g.W);
+    const int n_bands = (g.H + kBandRows - 1) / kBandRows;
+    int rc = ensure(ctx, ctx->integral, (size_t)np * (g.H + 1) * pitch * sizeof(int32_t));
+    if (rc) return rc;
+    rc = ensure(ctx, ctx->band_totals, (size_t)np * n_bands * pitch * sizeof(int32_t));
+    if (rc) return rc;
+    IntegralArgs a;
+    a.f.cur = cur + (int64_t)p0 * g.pair_stride;
+    a.f.prev = prev + (int64_t)p0 * g.pair_stride;
+    a.f.W = g.W;
+    a.f.H = g.H;
+    a.f.row_stride = g.row_stride;
+    a.f.pair_stride = g.pair_stride;
+    a.integral = static_cast<int32_t *>(ctx->integral.ptr);
+    a.band_totals = static_cast<int32_t *>(ctx->band_totals.ptr);
+    a.pitch = pitch;
+    a.n_bands = n_bands;
+    a.n_pairs = np;
+    const int e = launch_integral(a, ctx->stream);
+    if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("integral launch: ") + hipGetErrorString((hipError_t)e));
+    return MOFREAK_OK;
+}
+
+// The device-pointer implementation behind mofreak_extract_pairs and the component entry points.
+int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, const Geometry &g, int n_pairs,
+                   const mofreak_keypoint *kps, const int64_t *d_offsets, const int64_t *h_offsets, int64_t n_kp,
+                   uint8_t *out_desc, uint8_t *out_valid, int32_t *out_info, uint8_t *out_roi19)
+{
+    if (n_pairs == 0 || n_kp == 0) return MOFREAK_OK;
+    const int chunk = choose_chunk(ctx, g.W, g.H, n_pairs);
+    for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
+        const int np = std::min(chunk, n_pairs - p0);
+        int64_t item_base, n_items;
+        if (h_offsets) {
+            item_base = h_offsets[p0];
+            n_items = h_offsets[p0 + np] - h_offsets[p0];
+        } else {
+            item_base = (int64_t)p0 * n_kp;
+            n_items = (int64_t)np * n_kp;
+        }
+        if (n_items == 0) continue;
+        mofreak_ctx::Span span{};
+        if (ctx->profiling) {
+            hipEvent_t *ev[3] = {&span.e0, &span.e1, &span.e2};
+            for (auto *e : ev) {
+                if (!ctx->event_pool.empty()) {
+                    *e = ctx->event_pool.back();
+                    ctx->event_pool.pop_back();
+                } else {
+                    HIP_TRY(ctx, hipEventCreate(e));
+                }
+            }
+            span.pairs = np;
+            span.items = n_items;
+            HIP_TRY(ctx, hipEventRecord(span.e0, ctx->stream));
+        }
+        int rc = run_integral(ctx, cur, prev, g, p0, np);
+        if (rc) return rc;
+        if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(span.e1, ctx->stream));
+        DescribeArgs a;
+        a.f.cur = cur + (int64_t)p0 * g.pair_stride;
+        a.f.prev = prev + (int64_t)p0 * g.pair_stride;
+        a.f.W = g.W;
+        a.f.H = g.H;
+        a.f.row_stride = g.row_stride;
+        a.f.pair_stride = g.pair_stride;
+        a.integral = static_cast<const int32_t *>(ctx->integral.ptr);
+        a.pitch = integral_pitch(g.W);
+        a.n_pairs = np;
+        a.lut = ctx->d_lut;
+        a.resize = ctx->d_resize;
+        a.small = ctx->d_small;
+        a.kps = kps;
+        a.kp_offsets = d_offsets;
+        a.n_kp = n_kp;
+        a.first_pair = p0;
+        a.item_base = item_base;
+        a.n_items = n_items;
+        a.out_desc = out_desc;
+        a.out_valid = out_valid;
+        a.out_info = out_info;
+        a.out_roi19 = out_roi19;
+        a.status = ctx->d_status;
+        const int64_t want = (n_items + 3) / 4;
+        const int n_blocks = (int)std::min<int64_t>(want, (int64_t)ctx->n_cus * 8);
+        const int e = launch_describe(a, n_blocks, ctx->stream);
+        if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("describe launch: ") + hipGetErrorString((hipError_t)e));
+        if (ctx->profiling) {
+            HIP_TRY(ctx, hipEventRecord(span.e2, ctx->stream));
+            ctx->spans.push_back(span);
+        }
+    }
+    return MOFREAK_OK;
+}
+
+// Host copy of CSR offsets (needed to cut the call into chunks); validates monotonicity.
+int fetch_offsets(mofreak_ctx *ctx, const int64_t *offsets, int n_pairs, bool host_ptr, std::vector<int64_t> &h)
+{
+    h.resize((size_t)n_pairs + 1);
+    if (host_ptr) {
+        std::memcpy(h.data(), offsets, h.size() * sizeof(int64_t));
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(h.data(), offsets, h.size() * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (h[0] != 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "kp_offsets[0] must be 0");
+    for (int p = 0; p < n_pairs; ++p)
+        if (h[p + 1] < h[p]) return fail(ctx, MOFREAK_ERR_BAD_ARG, "kp_offsets must be non-decreasing");
+    return MOFREAK_OK;
+}
+
+int upload(mofreak_ctx *ctx, DeviceBuffer &b, const void *src, size_t bytes)
+{
+    int rc = ensure(ctx, b, bytes);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(b.ptr, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return MOFREAK_OK;
+}
+
+// Bytes spanned by n_pairs frames with the given strides.
+size_t frame_span(const Geometry &g, int n_pairs)
+{
+    if (n_pairs <= 0) return 0;
+    return (size_t)((int64_t)(n_pairs - 1) * g.pair_stride + (int64_t)(g.H - 1) * g.row_stride + g.W);
+}
+
+int compact_device(mofreak_ctx *ctx, const mofreak_keypoint *kps, const int64_t *d_offsets, int64_t n_kp, int n_pairs,
+                   int64_t n_items, int first_frame, const uint8_t *desc, const uint8_t *valid, mofreak_row *rows,
+                   int64_t capacity, int64_t *n_rows_out)
+{
+    const int64_t nb64 = (n_items + kCompactItemsPerBlock - 1) / kCompactItemsPerBlock;
+    if (nb64 > 0x7fffffff) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "too many items for one compaction");
+    const int n_blocks = (int)nb64;
+    int rc = ensure(ctx, ctx->compact_offsets, ((size_t)n_blocks + 1) * sizeof(int64_t));
+    if (rc) return rc;
+    CompactArgs a;
+    a.kps = kps;
+    a.kp_offsets = d_offsets;
+    a.n_kp = n_kp;
+    a.n_items = n_items;
+    a.n_pairs = n_pairs;
+    a.first_frame_number = first_frame;
+    a.desc = desc;
+    a.valid = valid;
+    a.rows = rows;
+    a.capacity = capacity;
+    a.block_offsets = static_cast<int64_t *>(ctx->compact_offsets.ptr);
+    a.n_blocks = n_blocks;
+    const int e = launch_compact(a, ctx->stream);
+    if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("compact launch: ") + hipGetErrorString((hipError_t)e));
+    int64_t total = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&total, a.block_offsets + n_blocks, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_rows_out) *n_rows_out = total;
+    if (total > capacity) return fail(ctx, MOFREAK_ERR_CAPACITY, "rows_out too small: need " + std::to_string(total));
+    return MOFREAK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mofreak_abi_version(void) { return MOFREAK_ABI_VERSION; }
+
+int mofreak_default_params(mofreak_params *p)
+{
+    if (!p) return MOFREAK_ERR_BAD_ARG;
+    p->struct_size = (int32_t)sizeof(mofreak_params);
+    p->gap_for_frame_difference = 5;
+    p->mip_theta = 288;
+    p->freak_pattern_scale = 22.0f;
+    p->freak_n_octaves = 4;
+    p->freak_orientation_normalized = 1;
+    p->freak_scale_normalized = 1;
+    p->freak_bit_mode = MOFREAK_BITS_SSE;
+    return MOFREAK_OK;
+}
+
+int mofreak_create(int device_id, const mofreak_params *params, mofreak_ctx **out)
+{
+    if (!out) return fail(nullptr, MOFREAK_ERR_BAD_ARG, "out is null");
+    *out = nullptr;
+    mofreak_params p;
+    mofreak_default_params(&p);
+    if (params) {
+        if (params->struct_size != (int32_t)sizeof(mofreak_params))
+            return fail(nullptr, MOFREAK_ERR_BAD_ARG, "params->struct_size mismatch (use mofreak_default_params)");
+        p = *params;
+    }
+    if (p.gap_for_frame_difference < 1 || p.freak_n_octaves < 1 || !(p.freak_pattern_scale > 0) ||
+        p.freak_bit_mode < 0 || p.freak_bit_mode > 2 || p.mip_theta < 0)
+        return fail(nullptr, MOFREAK_ERR_BAD_ARG, "parameter out of range");
+
+    int n_dev = 0;
+    if (device_id != MOFREAK_TABLES_ONLY) {
+        if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+            return fail(nullptr, MOFREAK_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+        if (device_id < 0 || device_id >= n_dev) return fail(nullptr, MOFREAK_ERR_BAD_ARG, "device_id out of range");
+    }
+
+    mofreak_ctx *ctx = new (std::nothrow) mofreak_ctx;
+    if (!ctx) return fail(nullptr, MOFREAK_ERR_OOM, "host allocation failed");
+    ctx->device = device_id;
+    ctx->params = p;
+    try {
+        FreakParams fp;
+        fp.pattern_scale = p.freak_pattern_scale;
+        fp.n_octaves = p.freak_n_octaves;
+        fp.orientation_normalized = p.freak_orientation_normalized != 0;
+        fp.scale_normalized = p.freak_scale_normalized != 0;
+        fp.bit_mode = p.freak_bit_mode;
+        build_tables(fp, ctx->tables);
+    } catch (const std::exception &e) {
+        const std::string m = std::string("table construction failed: ") + e.what();
+        delete ctx;
+        return fail(nullptr, MOFREAK_ERR_OOM, m);
+    }
+    if (ctx->tables.min_sigma < 0.5f) {
+        delete ctx;
+        return fail(nullptr, MOFREAK_ERR_UNSUPPORTED,
+                    "freak_pattern_scale gives a pattern sigma < 0.5: the bilinear branch of FREAK::meanIntensity is not implemented");
+    }
+
+    if (device_id == MOFREAK_TABLES_ONLY) {  // host tables only: every compute entry point refuses this context
+        *out = ctx;
+        return MOFREAK_OK;
+    }
+
+#define CREATE_TRY(expr)                                                              \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            const std::string m_ = std::string(#expr) + ": " + hipGetErrorString(e_); \
+            mofreak_destroy(ctx);                                                     \
+            return fail(nullptr, MOFREAK_ERR_HIP, m_);                                \
+        }                                                                             \
+    } while (0)
+
+    CREATE_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    CREATE_TRY(hipGetDeviceProperties(&prop, device_id));
+    ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+
+    const Tables &t = ctx->tables;
+    CREATE_TRY(hipMalloc((void **)&ctx->d_lut, t.lut.size() * sizeof(PatternPoint)));
+    CREATE_TRY(hipMalloc((void **)&ctx->d_resize, t.resize.size() * sizeof(ResizeTap)));
+    CREATE_TRY(hipMalloc((void **)&ctx->d_small, sizeof(SmallTables)));
+    CREATE_TRY(hipMalloc((void **)&ctx->d_status, sizeof(int32_t)));
+    SmallTables st;
+    std::memset(&st, 0, sizeof(st));
+    std::memcpy(st.pattern_sizes, t.pattern_sizes, sizeof(st.pattern_sizes));
+    std::memcpy(st.scale_thresholds, t.scale_thresholds, sizeof(st.scale_thresholds));
+    std::memcpy(st.orient, t.orient, sizeof(st.orient));
+    std::memcpy(st.bit_pair_i, t.bit_pair_i, 64);
+    std::memcpy(st.bit_pair_j, t.bit_pair_j, 64);
+    st.fixed_scale_index = t.fixed_scale_index;
+    st.orientation_normalized = p.freak_orientation_normalized != 0;
+    st.scale_normalized = p.freak_scale_normalized != 0;
+    st.bit_mode = p.freak_bit_mode;
+    st.mip_theta = p.mip_theta;
+    CREATE_TRY(hipMemcpy(ctx->d_lut, t.lut.data(), t.lut.size() * sizeof(PatternPoint), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(ctx->d_resize, t.resize.data(), t.resize.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(ctx->d_small, &st, sizeof(st), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemset(ctx->d_status, 0, sizeof(int32_t)));
+#undef CREATE_TRY
+    *out = ctx;
+    return MOFREAK_OK;
+}
+
+void mofreak_destroy(mofreak_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->device < 0) {
+        delete ctx;
+        return;
+    }
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_lut) (void)hipFree(ctx->d_lut);
+    if (ctx->d_resize) (void)hipFree(ctx->d_resize);
+    if (ctx->d_small) (void)hipFree(ctx->d_small);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
+    release(ctx->integral);
+    release(ctx->band_totals);
+    release(ctx->scratch_desc);
+    release(ctx->scratch_valid);
+    release(ctx->compact_offsets);
+    release(ctx->offsets_dev);
+    for (auto &s : ctx->stage) release(s);
+    for (auto &sp : ctx->spans) {
+        (void)hipEventDestroy(sp.e0);
+        (void)hipEventDestroy(sp.e1);
+        (void)hipEventDestroy(sp.e2);
+    }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *mofreak_last_error(const mofreak_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int mofreak_set_stream(mofreak_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    NEED_DEVICE(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->own_stream = false;
+    if (hip_stream == nullptr) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    } else {
+        ctx->stream = static_cast<hipStream_t>(hip_stream);
+    }
+    return MOFREAK_OK;
+}
+
+int mofreak_synchronize(mofreak_ctx *ctx)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    NEED_DEVICE(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MOFREAK_OK;
+}
+
+int mofreak_reserve(mofreak_ctx *ctx, int W, int H, int chunk_pairs)
+{
+    if (!ctx || W <= 0 || H <= 0) return MOFREAK_ERR_BAD_ARG;
+    NEED_DEVICE(ctx);
+    ctx->chunk_pairs_hint = chunk_pairs > 0 ? chunk_pairs : 0;
+    const int chunk = choose_chunk(ctx, W, H, 1 << 30);
+    const int pitch = integral_pitch(W);
+    const int n_bands = (H + kBandRows - 1) / kBandRows;
+    int rc = ensure(ctx, ctx->integral, (size_t)chunk * (H + 1) * pitch * sizeof(int32_t));
+    if (rc) return rc;
+    return ensure(ctx, ctx->band_totals, (size_t)chunk * n_bands * pitch * sizeof(int32_t));
+}
+
+int mofreak_set_profiling(mofreak_ctx *ctx, int enable)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    NEED_DEVICE(ctx);
+    ctx->profiling = enable != 0;
+    return MOFREAK_OK;
+}
+
+int mofreak_get_profile(mofreak_ctx *ctx, mofreak_profile *out, int reset)
+{
+    if (!ctx || !out) return MOFREAK_ERR_BAD_ARG;
+    NEED_DEVICE(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &sp : ctx->spans) {
+        float a = 0, b = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&a, sp.e0, sp.e1));
+        HIP_TRY(ctx, hipEventElapsedTime(&b, sp.e1, sp.e2));
+        ctx->prof.integral_ms += a;
+        ctx->prof.describe_ms += b;
+        ctx->prof.launches += 1;
+        ctx->prof.pairs += sp.pairs;
+        ctx->prof.descriptors += sp.items;
+        ctx->event_pool.push_back(sp.e0);
+        ctx->event_pool.push_back(sp.e1);
+        ctx->event_pool.push_back(sp.e2);
+    }
+    ctx->spans.clear();
+    *out = ctx->prof;
+    if (reset) ctx->prof = mofreak_profile{};
+    return MOFREAK_OK;
+}
+
+int mofreak_check_status(mofreak_ctx *ctx)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    NEED_DEVICE(ctx);
+    int32_t s = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&s, ctx->d_status, sizeof(s), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(s), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (s & 1) return fail(ctx, MOFREAK_ERR_ROI, "a keypoint's MIP ROI left the image (the reference throws there); it was marked invalid");
+    if (s & 2) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "a keypoint's ROI side exceeds the resize tables; it was marked invalid");
+    return MOFREAK_OK;
+}
+
+int mofreak_extract_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, int W, int H, int64_t row_stride,
+                          int64_t pair_stride, int n_pairs, const mofreak_keypoint *kps, const int64_t *kp_offsets,
+                          int64_t n_kp, uint8_t *out_desc16, uint8_t *out_valid, unsigned flags)
+{
+    int rc = validate_frames(ctx, cur, prev, W, H, row_stride, pair_stride, n_pairs);
+    if (rc) return rc;
+    if (n_kp < 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "n_kp < 0");
+    if (n_kp > 0 && (!kps || !out_desc16 || !out_valid)) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null keypoint/output pointer");
+    NEED_DEVICE(ctx);
+    const bool host = (flags & MOFREAK_MEM_HOST) != 0;
+    const Geometry g{W, H, row_stride, pair_stride};
+    std::vector<int64_t> h_off;
+    const int64_t *d_off = nullptr;
+    int64_t n_out = (int64_t)n_pairs * n_kp;
+    if (kp_offsets) {
+        rc = fetch_offsets(ctx, kp_offsets, n_pairs, host, h_off);
+        if (rc) return rc;
+        if (h_off[n_pairs] != n_kp) return fail(ctx, MOFREAK_ERR_BAD_ARG, "kp_offsets[n_pairs] != n_kp");
+        n_out = n_kp;
+        d_off = kp_offsets;
+    }
+    if (!host)
+        return extract_device(ctx, cur, prev, g, n_pairs, kps, d_off, kp_offsets ? h_off.data() : nullptr, n_kp,
+                              out_desc16, out_valid, nullptr, nullptr);
+
+    // host pointers: stage through device buffers
+    const size_t span = frame_span(g, n_pairs);
+    if ((rc = upload(ctx, ctx->stage[0], cur, span))) return rc;
+    if ((rc = upload(ctx, ctx->stage[1], prev, span))) return rc;
+    if ((rc = upload(ctx, ctx->stage[2], kps, (size_t)n_kp * sizeof(mofreak_keypoint)))) return rc;
+    if (kp_offsets) {
+        if ((rc = upload(ctx, ctx->offsets_dev, h_off.data(), h_off.size() * sizeof(int64_t)))) return rc;
+        d_off = static_cast<const int64_t *>(ctx->offsets_dev.ptr);
+    }
+    if ((rc = ensure(ctx, ctx->stage[3], (size_t)n_out * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->stage[4], (size_t)n_out))) return rc;
+    rc = extract_device(ctx, static_cast<const uint8_t *>(ctx->stage[0].ptr), static_cast<const uint8_t *>(ctx->stage[1].ptr),
+                        g, n_pairs, static_cast<const mofreak_keypoint *>(ctx->stage[2].ptr), d_off,
+                        kp_offsets ? h_off.data() : nullptr, n_kp, static_cast<uint8_t *>(ctx->stage[3].ptr),
+                        static_cast<uint8_t *>(ctx->stage[4].ptr), nullptr, nullptr);
+    if (rc) return rc;
+    if (n_out) {
+        HIP_TRY(ctx, hipMemcpyAsync(out_desc16, ctx->stage[3].ptr, (size_t)n_out * 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(out_valid, ctx->stage[4].ptr, (size_t)n_out, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MOFREAK_OK;
+}
+
+int mofreak_compact_rows(mofreak_ctx *ctx, const mofreak_keypoint *kps, const int64_t *kp_offsets, int64_t n_kp,
+                         int n_pairs, int first_frame_number, const uint8_t *desc16, const uint8_t *valid,
+                         mofreak_row *rows_out, int64_t rows_capacity, int64_t *n_rows_out, unsigned flags)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    if (n_pairs < 0 || n_kp < 0 || rows_capacity < 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "negative count");
+    NEED_DEVICE(ctx);
+    const bool host = (flags & MOFREAK_MEM_HOST) != 0;
+    const int64_t n_items = kp_offsets ? n_kp : (int64_t)n_pairs * n_kp;
+    if (n_rows_out) *n_rows_out = 0;
+    if (n_items == 0) return MOFREAK_OK;
+    if (!kps || !desc16 || !valid || (!rows_out && rows_capacity > 0)) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null pointer");
+    if (!host)
+        return compact_device(ctx, kps, kp_offsets, n_kp, n_pairs, n_items, first_frame_number, desc16, valid, rows_out,
+                              rows_capacity, n_rows_out);
+    int rc;
+    if ((rc = upload(ctx, ctx->stage[2], kps, (size_t)n_kp * sizeof(mofreak_keypoint)))) return rc;
+    if ((rc = upload(ctx, ctx->stage[3], desc16, (size_t)n_items * 16))) return rc;
+    if ((rc = upload(ctx, ctx->stage[4], valid, (size_t)n_items))) return rc;
+    const int64_t *d_off = nullptr;
+    if (kp_offsets) {
+        if ((rc = upload(ctx, ctx->offsets_dev, kp_offsets, ((size_t)n_pairs + 1) * sizeof(int64_t)))) return rc;
+        d_off = static_cast<const int64_t *>(ctx->offsets_dev.ptr);
+    }
+    if ((rc = ensure(ctx, ctx->stage[5], (size_t)std::max<int64_t>(rows_capacity, 1) * sizeof(mofreak_row)))) return rc;
+    int64_t total = 0;
+    rc = compact_device(ctx, static_cast<const mofreak_keypoint *>(ctx->stage[2].ptr), d_off, n_kp, n_pairs, n_items,
+                        first_frame_number, static_cast<const uint8_t *>(ctx->stage[3].ptr),
+                        static_cast<const uint8_t *>(ctx->stage[4].ptr), static_cast<mofreak_row *>(ctx->stage[5].ptr),
+                        rows_capacity, &total);
+    if (n_rows_out) *n_rows_out = total;
+    if (rc) return rc;
+    if (total) HIP_TRY(ctx, hipMemcpy(rows_out, ctx->stage[5].ptr, (size_t)total * sizeof(mofreak_row), hipMemcpyDeviceToHost));
+    return MOFREAK_OK;
+}
+
+int mofreak_extract_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W, int H, const mofreak_keypoint *kps,
+                           const int64_t *kp_offsets, int64_t n_kp, mofreak_row *rows_out, int64_t rows_capacity,
+                           int64_t *n_rows_out, unsigned flags)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    if (n_rows_out) *n_rows_out = 0;
+    if (T < 0 || n_kp < 0 || rows_capacity < 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "negative count");
+    const int gap = ctx->params.gap_for_frame_difference;
+    const int n_pairs = T - gap;  // the first `gap` frames only prime the queue (MoFREAKUtilities.cpp:391-399)
+    if (n_pairs <= 0 || n_kp == 0) return MOFREAK_OK;
+    const int64_t fsz = (int64_t)W * H;
+    int rc = validate_frames(ctx, frames, frames, W, H, W, fsz, n_pairs);
+    if (rc) return rc;
+    if (!kps) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null keypoint pointer");
+    NEED_DEVICE(ctx);
+    const bool host = (flags & MOFREAK_MEM_HOST) != 0;
+    const Geometry g{W, H, W, fsz};
+
+    std::vector<int64_t> h_off;
+    const int64_t *d_off = nullptr;
+    int64_t n_items = (int64_t)n_pairs * n_kp;
+    if (kp_offsets) {
+        if ((rc = fetch_offsets(ctx, kp_offsets, n_pairs, host, h_off))) return rc;
+        if (h_off[n_pairs] != n_kp) return fail(ctx, MOFREAK_ERR_BAD_ARG, "kp_offsets[T-gap] != n_kp");
+        n_items = n_kp;
+        d_off = kp_offsets;
+    }
+    const uint8_t *d_frames = frames;
+    const mofreak_keypoint *d_kps = kps;
+    mofreak_row *d_rows = rows_out;
+    if (host) {
+        if ((rc = upload(ctx, ctx->stage[0], frames, (size_t)T * fsz))) return rc;
+        if ((rc = upload(ctx, ctx->stage[2], kps, (size_t)n_kp * sizeof(mofreak_keypoint)))) return rc;
+        if (kp_offsets) {
+            if ((rc = upload(ctx, ctx->offsets_dev, h_off.data(), h_off.size() * sizeof(int64_t)))) return rc;
+            d_off = static_cast<const int64_t *>(ctx->offsets_dev.ptr);
+        }
+        if ((rc = ensure(ctx, ctx->stage[5], (size_t)std::max<int64_t>(rows_capacity, 1) * sizeof(mofreak_row)))) return rc;
+        d_frames = static_cast<const uint8_t *>(ctx->stage[0].ptr);
+        d_kps = static_cast<const mofreak_keypoint *>(ctx->stage[2].ptr);
+        d_rows = static_cast<mofreak_row *>(ctx->stage[5].ptr);
+    }
+    if ((rc = ensure(ctx, ctx->scratch_desc, (size_t)n_items * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->scratch_valid, (size_t)n_items))) return rc;
+    uint8_t *desc = static_cast<uint8_t *>(ctx->scratch_desc.ptr);
+    uint8_t *valid = static_cast<uint8_t *>(ctx->scratch_valid.ptr);
+    // pair p: current = frame p+gap, previous = frame p (:398-399, :485-487)
+    rc = extract_device(ctx, d_frames + (int64_t)gap * fsz, d_frames, g, n_pairs, d_kps, d_off,
+                        kp_offsets ? h_off.data() : nullptr, n_kp, desc, valid, nullptr, nullptr);
+    if (rc) return rc;
+    int64_t total = 0;
+    // the first processed frame is labelled gap-1 (:401) and the label is incremented per frame (:488)
+    rc = compact_device(ctx, d_kps, d_off, n_kp, n_pairs, n_items, gap - 1, desc, valid, d_rows, rows_capacity, &total);
+    if (n_rows_out) *n_rows_out = total;
+    if (rc) return rc;
+    if (host && total)
+        HIP_TRY(ctx, hipMemcpy(rows_out, d_rows, (size_t)total * sizeof(mofreak_row), hipMemcpyDeviceToHost));
+    return MOFREAK_OK;
+}
+
+// ------------------------------------------------------------------ component entry points
+int mofreak_diff_integral(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, int W, int H, int64_t row_stride,
+                          int64_t pair_stride, int n_pairs, int32_t *out, unsigned flags)
+{
+    int rc = validate_frames(ctx, cur, prev, W, H, row_stride, pair_stride, n_pairs);
+    if (rc) return rc;
+    if (n_pairs == 0) return MOFREAK_OK;
+    if (!out) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null output");
+    NEED_DEVICE(ctx);
+    const bool host = (flags & MOFREAK_MEM_HOST) != 0;
+    const Geometry g{W, H, row_stride, pair_stride};
+    const uint8_t *d_cur = cur, *d_prev = prev;
+    if (host) {
+        const size_t span = frame_span(g, n_pairs);
+        if ((rc = upload(ctx, ctx->stage[0], cur, span))) return rc;
+        if ((rc = upload(ctx, ctx->stage[1], prev, span))) return rc;
+        d_cur = static_cast<const uint8_t *>(ctx->stage[0].ptr);
+        d_prev = static_cast<const uint8_t *>(ctx->stage[1].ptr);
+    }
+    const size_t per_pair = (size_t)(W + 1) * (H + 1);
+    int32_t *d_out = out;
+    if (host) {
+        if ((rc = ensure(ctx, ctx->stage[3], per_pair * sizeof(int32_t)))) return rc;
+        d_out = static_cast<int32_t *>(ctx->stage[3].ptr);
+    }
+    for (int p = 0; p < n_pairs; ++p) {
+        if ((rc = run_integral(ctx, d_cur, d_prev, g, p, 1))) return rc;
+        int32_t *dst = host ? d_out : out + (size_t)p * per_pair;
+        const int e = launch_unpack_integral(static_cast<const int32_t *>(ctx->integral.ptr), integral_pitch(W), W, H, 1, dst, ctx->stream);
+        if (e) return fail(ctx, MOFREAK_ERR_HIP, "unpack launch failed");
+        if (host) {
+            HIP_TRY(ctx, hipMemcpyAsync(out + (size_t)p * per_pair, d_out, per_pair * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    return MOFREAK_OK;
+}
+
+int mofreak_mip19(mofreak_ctx *ctx, const uint8_t *cur19, const uint8_t *prev19, int64_t n, uint8_t *out_motion8,
+                  unsigned flags)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    if (n < 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "n < 0");
+    if (n == 0) return MOFREAK_OK;
+    if (!cur19 || !prev19 || !out_motion8) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null pointer");
+    NEED_DEVICE(ctx);
+    const bool host = (flags & MOFREAK_MEM_HOST) != 0;
+    int rc;
+    const uint8_t *dc = cur19, *dp = prev19;
+    uint8_t *dout = out_motion8;
+    if (host) {
+        if ((rc = upload(ctx, ctx->stage[0], cur19, (size_t)n * 361))) return rc;
+        if ((rc = upload(ctx, ctx->stage[1], prev19, (size_t)n * 361))) return rc;
+        if ((rc = ensure(ctx, ctx->stage[3], (size_t)n * 8))) return rc;
+        dc = static_cast<const uint8_t *>(ctx->stage[0].ptr);
+        dp = static_cast<const uint8_t *>(ctx->stage[1].ptr);
+        dout = static_cast<uint8_t *>(ctx->stage[3].ptr);
+    }
+    const int e = launch_mip19(dc, dp, n, ctx->params.mip_theta, dout, ctx->stream);
+    if (e) return fail(ctx, MOFREAK_ERR_HIP, "mip19 launch failed");
+    if (host) {
+        HIP_TRY(ctx, hipMemcpyAsync(out_motion8, dout, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MOFREAK_OK;
+}
+
+static int one_pair_debug(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, int W, int H,
+                          const mofreak_keypoint *kps, int64_t n_kp, int32_t *out_info, uint8_t *out_roi, unsigned flags)
+{
+    int rc = validate_frames(ctx, cur, prev, W, H, W, (int64_t)W * H, 1);
+    if (rc) return rc;
+    if (n_kp < 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "n_kp < 0");
+    if (n_kp == 0) return MOFREAK_OK;
+    if (!kps || (!out_info && !out_roi)) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null pointer");
+    NEED_DEVICE(ctx);
+    const bool host = (flags & MOFREAK_MEM_HOST) != 0;
+    const Geometry g{W, H, W, (int64_t)W * H};
+    const uint8_t *dc = cur, *dp = prev;
+    const mofreak_keypoint *dk = kps;
+    const size_t out_bytes = out_info ? (size_t)n_kp * 16 : (size_t)n_kp * 722;
+    void *dout = out_info ? (void *)out_info : (void *)out_roi;
+    if (host) {
+        if ((rc = upload(ctx, ctx->stage[0], cur, (size_t)W * H))) return rc;
+        if ((rc = upload(ctx, ctx->stage[1], prev, (size_t)W * H))) return rc;
+        if ((rc = upload(ctx, ctx->stage[2], kps, (size_t)n_kp * sizeof(mofreak_keypoint)))) return rc;
+        if ((rc = ensure(ctx, ctx->stage[5], out_bytes))) return rc;
+        dc = static_cast<const uint8_t *>(ctx->stage[0].ptr);
+        dp = static_cast<const uint8_t *>(ctx->stage[1].ptr);
+        dk = static_cast<const mofreak_keypoint *>(ctx->stage[2].ptr);
+        dout = ctx->stage[5].ptr;
+    }
+    if ((rc = ensure(ctx, ctx->scratch_desc, (size_t)n_kp * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->scratch_valid, (size_t)n_kp))) return rc;
+    rc = extract_device(ctx, dc, dp, g, 1, dk, nullptr, nullptr, n_kp, static_cast<uint8_t *>(ctx->scratch_desc.ptr),
+                        static_cast<uint8_t *>(ctx->scratch_valid.ptr), out_info ? static_cast<int32_t *>(dout) : nullptr,
+                        out_info ? nullptr : static_cast<uint8_t *>(dout));
+    if (rc) return rc;
+    if (host) {
+        HIP_TRY(ctx, hipMemcpyAsync(out_info ? (void *)out_info : (void *)out_roi, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MOFREAK_OK;
+}
+
+int mofreak_roi19(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, int W, int H, const mofreak_keypoint *kps,
+                  int64_t n_kp, uint8_t *out, unsigned flags)
+{
+    return one_pair_debug(ctx, cur, prev, W, H, kps, n_kp, nullptr, out, flags);
+}
+
+int mofreak_freak_info(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, int W, int H, const mofreak_keypoint *kps,
+                       int64_t n_kp, int32_t *out_info, unsigned flags)
+{
+    return one_pair_debug(ctx, cur, prev, W, H, kps, n_kp, out_info, nullptr, flags);
+}
+
+int mofreak_theta_index(mofreak_ctx *ctx, const int32_t *dirs, int64_t n, int32_t *out, unsigned flags)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    if (n < 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "n < 0");
+    if (n == 0) return MOFREAK_OK;
+    if (!dirs || !out) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null pointer");
+    NEED_DEVICE(ctx);
+    const bool host = (flags & MOFREAK_MEM_HOST) != 0;
+    int rc;
+    const int32_t *dd = dirs;
+    int32_t *dout = out;
+    if (host) {
+        if ((rc = upload(ctx, ctx->stage[0], dirs, (size_t)n * 8))) return rc;
+        if ((rc = ensure(ctx, ctx->stage[3], (size_t)n * 4))) return rc;
+        dd = static_cast<const int32_t *>(ctx->stage[0].ptr);
+        dout = static_cast<int32_t *>(ctx->stage[3].ptr);
+    }
+    const int e = launch_theta(dd, n, dout, ctx->stream);
+    if (e) return fail(ctx, MOFREAK_ERR_HIP, "theta launch failed");
+    if (host) {
+        HIP_TRY(ctx, hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MOFREAK_OK;
+}
+
+int mofreak_pattern_sizes(const mofreak_ctx *ctx, int32_t out[64])
+{
+    if (!ctx || !out) return MOFREAK_ERR_BAD_ARG;
+    std::memcpy(out, ctx->tables.pattern_sizes, sizeof(int32_t) * 64);
+    return MOFREAK_OK;
+}
+
+int mofreak_scale_index(const mofreak_ctx *ctx, float size, int32_t *out)
+{
+    if (!ctx || !out) return MOFREAK_ERR_BAD_ARG;
+    if (!ctx->params.freak_scale_normalized) {
+        *out = ctx->tables.fixed_scale_index;
+        return MOFREAK_OK;
+    }
+    int idx = 0;  // the device's rule: number of thresholds <= size
+    for (int k = 0; k < kNbScales - 1; ++k) idx += size >= ctx->tables.scale_thresholds[k];
+    *out = idx;
+    return MOFREAK_OK;
+}
+
+int mofreak_table_pattern(const mofreak_ctx *ctx, int scale, int rot, float out[43 * 3])
+{
+    if (!ctx || !out || scale < 0 || scale >= kNbScales || rot < 0 || rot >= kNbOrientation) return MOFREAK_ERR_BAD_ARG;
+    const PatternPoint *row = &ctx->tables.lut[((size_t)scale * kNbOrientation + rot) * kNbPoints];
+    for (int i = 0; i < kNbPoints; ++i) {
+        out[3 * i] = row[i].x;
+        out[3 * i + 1] = row[i].y;
+        out[3 * i + 2] = row[i].sigma;
+    }
+    return MOFREAK_OK;
+}
+
+int mofreak_table_orientation(const mofreak_ctx *ctx, int32_t out[45 * 4])
+{
+    if (!ctx || !out) return MOFREAK_ERR_BAD_ARG;
+    for (int m = 0; m < kNbOrientPairs; ++m) {
+        out[4 * m] = ctx->tables.orient[m].i;
+        out[4 * m + 1] = ctx->tables.orient[m].j;
+        out[4 * m + 2] = ctx->tables.orient[m].weight_dx;
+        out[4 * m + 3] = ctx->tables.orient[m].weight_dy;
+    }
+    return MOFREAK_OK;
+}
+
+int mofreak_table_bit_pairs(const mofreak_ctx *ctx, uint8_t out[128])
+{
+    if (!ctx || !out) return MOFREAK_ERR_BAD_ARG;
+    for (int b = 0; b < 64; ++b) {
+        out[2 * b] = ctx->tables.bit_pair_i[b];
+        out[2 * b + 1] = ctx->tables.bit_pair_j[b];
+    }
+    return MOFREAK_OK;
+}
+
+int mofreak_table_resize(const mofreak_ctx *ctx, int L, int16_t out[2 * 19 * 4])
+{
+    if (!ctx || !out || L < 1 || L > kMaxRoiSide) return MOFREAK_ERR_BAD_ARG;
+    const ResizeTap *t = &ctx->tables.resize[(size_t)L * 2 * kPatch];
+    for (int i = 0; i < 2 * kPatch; ++i) {
+        out[4 * i] = t[i].ofs;
+        out[4 * i + 1] = t[i].ofs1;
+        out[4 * i + 2] = t[i].c0;
+        out[4 * i + 3] = t[i].c1;
+    }
+    return MOFREAK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// Argument blocks shared by the host launcher (capi.cpp) and the gfx950 kernels (kernels.hip).
+#pragma once
+
+#include <cstdint>
+
+#include "../../include/mofreak_hip.h"
+#include "tables.h"
+
+namespace mofreak {
+
+// Small per-context tables; every workgroup copies them from global memory into LDS once.
+struct SmallTables {
+    int32_t pattern_sizes[kNbScales];
+    float scale_thresholds[kNbScales];
+    OrientPair orient[kNbOrientPairs];
+    uint8_t bit_pair_i[64];
+    uint8_t bit_pair_j[64];
+    int32_t fixed_scale_index;
+    int32_t orientation_normalized;
+    int32_t scale_normalized;
+    int32_t bit_mode;
+    int32_t mip_theta;
+    int32_t pad[3];
+};
+
+// Integral image of one chunk of pairs, as the kernels lay it out in HBM:
+// (H+1) rows of `pitch` int32 per pair; logical column c (0..W) lives at physical column c+3, so the
+// 4-pixel group starting at pixel x = 4g (logical columns x+1..x+4) is one aligned 16-byte store.
+constexpr int kIntegralColOffset = 3;
+constexpr int kBandRows = 8;  // rows per band of the banded integral kernels
+
+struct FrameArgs {
+    const uint8_t *cur;
+    const uint8_t *prev;
+    int32_t W, H;
+    int64_t row_stride;
+    int64_t pair_stride;
+};
+
+struct IntegralArgs {
+    FrameArgs f;          // cur/prev already point at the first pair of the chunk
+    int32_t *integral;    // [n_pairs][H+1][pitch]
+    int32_t *band_totals; // [n_pairs][n_bands][pitch]
+    int32_t pitch;        // int32 per integral row, multiple of 4
+    int32_t n_bands;
+    int32_t n_pairs;
+};
+
+struct DescribeArgs {
+    FrameArgs f;               // cur/prev point at the first pair of the chunk
+    const int32_t *integral;   // chunk-local
+    int32_t pitch;
+    int32_t n_pairs;           // pairs in this chunk
+    const PatternPoint *lut;
+    const ResizeTap *resize;
+    const SmallTables *small;
+    const mofreak_keypoint *kps;
+    const int64_t *kp_offsets; // device CSR offsets of the WHOLE call (nullptr: shared list)
+    int64_t n_kp;              // shared list length (kp_offsets == nullptr)
+    int64_t first_pair;        // index of the chunk's first pair within the call
+    int64_t item_base;         // CSR: kp_offsets[first_pair]; shared: first_pair * n_kp
+    int64_t n_items;           // keypoint instances in this chunk
+    uint8_t *out_desc;         // whole-call output arrays
+    uint8_t *out_valid;
+    int32_t *out_info;         // optional: 4 x int32 per instance
+    uint8_t *out_roi19;        // optional: 722 bytes per instance
+    int32_t *status;           // device status word (bit 0: ROI left the image, bit 1: ROI side too large)
+};
+
+struct CompactArgs {
+    const mofreak_keypoint *kps;
+    const int64_t *kp_offsets;
+    int64_t n_kp;
+    int64_t n_items;
+    int32_t n_pairs;
+    int32_t first_frame_number;
+    const uint8_t *desc;
+    const uint8_t *valid;
+    mofreak_row *rows;
+    int64_t capacity;
+    int64_t *block_offsets;  // [n_blocks + 1]; last = total
+    int32_t n_blocks;
+};
+
+constexpr int kCompactItemsPerBlock = 1024;
+
+// launchers (kernels.hip); all asynchronous on `stream`, return a hipError_t value as int
+int launch_integral(const IntegralArgs &a, void *stream);
+int launch_describe(const DescribeArgs &a, int n_blocks, void *stream);
+int launch_mip19(const uint8_t *cur19, const uint8_t *prev19, int64_t n, int mip_theta, uint8_t *out, void *stream);
+int launch_theta(const int32_t *dirs, int64_t n, int32_t *out, void *stream);
+int launch_compact(const CompactArgs &a, void *stream);
+int launch_unpack_integral(const int32_t *src, int pitch, int W, int H, int n_pairs, int32_t *dst, void *stream);
+
+}  // namespace mofreak

@@ -1,0 +1,605 @@
+// gfx950 (CDNA4, wave64) kernels of the MoFREAK descriptor path.
+//
+// Integer / byte work, bandwidth- and gather-bound; no MFMA.  Compile with -ffp-contract=off: the few
+// float/double expressions below restate reference expressions whose rounding is part of the result.
+//
+//   band_kernel<false|true> + band_scan_kernel   cv::absdiff + cv::integral (MoFREAKUtilities.cpp:413-414,
+//                                                 and the integral cv::FREAK::computeImpl builds)
+//   describe_kernel                               one wavefront per keypoint: cv::FREAK bytes 0..7 on the
+//                                                 difference image (:427-428, :453-456) and the Motion
+//                                                 Interchange Pattern bytes (:460 -> :288-325 -> :46-99)
+//   compact_*                                     the stable "erase + push_back" of :436-483
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#include "device_types.h"
+
+namespace mofreak {
+namespace {
+
+constexpr double kCvPi = 3.1415926535897932384626433832795;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// LDS written by some lanes of a wave and read by others of the SAME wave: DS operations of one wave execute
+// in order, so only the compiler has to be told not to move them across this point.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ int wave_inclusive_scan(int v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int absdiff_u8(uint32_t a, uint32_t b, int k)
+{
+    const int x = (a >> (8 * k)) & 0xff, y = (b >> (8 * k)) & 0xff;
+    return x > y ? x - y : y - x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Integral image of |cur - prev|, banded: a workgroup owns kBandRows rows of one pair.
+//   pass A (FINAL=false): band_totals[band] = column sums of the band's row-prefix sums
+//   pass B: exclusive scan of band_totals over bands (band_scan_kernel)
+//   pass C (FINAL=true):  integral rows = band carry + running column sums, 16-byte stores
+// The u8 frames are read twice (1 B/px each time); the int32 integral is written once.
+// ------------------------------------------------------------------------------------------------
+template <bool FINAL>
+__global__ __launch_bounds__(256) void band_kernel(IntegralArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t rp[];  // [kBandRows][pitch] row-prefix sums
+    const int band = blockIdx.x, pair = blockIdx.y;
+    const int W = a.f.W, pitch = a.pitch;
+    const int y0 = band * kBandRows;
+    const int rows = min(kBandRows, a.f.H - y0);
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const uint8_t *cur = a.f.cur + (int64_t)pair * a.f.pair_stride;
+    const uint8_t *prev = a.f.prev + (int64_t)pair * a.f.pair_stride;
+
+    for (int r = wave; r < rows; r += 4) {
+        const uint8_t *c = cur + (int64_t)(y0 + r) * a.f.row_stride;
+        const uint8_t *p = prev + (int64_t)(y0 + r) * a.f.row_stride;
+        int32_t *out = rp + r * pitch;
+        if (lane < 4) out[lane] = 0;  // physical columns 0..3; column 3 is logical column 0
+        const bool aligned = (((uintptr_t)c | (uintptr_t)p) & 3) == 0;
+        int carry = 0;
+        for (int x0 = 0; x0 < W; x0 += 256) {
+            const int x = x0 + lane * 4;
+            uint32_t cv = 0, pv = 0;
+            if (aligned && x + 3 < W) {
+                cv = *reinterpret_cast<const uint32_t *>(c + x);
+                pv = *reinterpret_cast<const uint32_t *>(p + x);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (x + k < W) {
+                        cv |= (uint32_t)c[x + k] << (8 * k);
+                        pv |= (uint32_t)p[x + k] << (8 * k);
+                    }
+            }
+            const int p0 = absdiff_u8(cv, pv, 0);
+            const int p1 = p0 + absdiff_u8(cv, pv, 1);
+            const int p2 = p1 + absdiff_u8(cv, pv, 2);
+            const int p3 = p2 + absdiff_u8(cv, pv, 3);
+            const int incl = wave_inclusive_scan(p3);
+            const int base = carry + incl - p3;
+            if (x < W) *reinterpret_cast<int4 *>(out + x + 4) = make_int4(base + p0, base + p1, base + p2, base + p3);
+            carry += __shfl(incl, 63);
+        }
+    }
+    __syncthreads();
+
+    const int64_t bt = ((int64_t)pair * a.n_bands + band) * pitch;
+    int32_t *integ = a.integral + (int64_t)pair * (a.f.H + 1) * pitch;
+    for (int c4 = threadIdx.x * 4; c4 < pitch; c4 += 1024) {
+        int4 acc = make_int4(0, 0, 0, 0);
+        if (FINAL) {
+            acc = *reinterpret_cast<const int4 *>(a.band_totals + bt + c4);
+            if (band == 0) *reinterpret_cast<int4 *>(integ + c4) = make_int4(0, 0, 0, 0);  // integral row 0
+        }
+        for (int r = 0; r < rows; ++r) {
+            const int4 v = *reinterpret_cast<const int4 *>(rp + r * pitch + c4);
+            acc.x += v.x;
+            acc.y += v.y;
+            acc.z += v.z;
+            acc.w += v.w;
+            if (FINAL) *reinterpret_cast<int4 *>(integ + (int64_t)(y0 + r + 1) * pitch + c4) = acc;
+        }
+        if (!FINAL) *reinterpret_cast<int4 *>(a.band_totals + bt + c4) = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void band_scan_kernel(int32_t *band_totals, int pitch, int n_bands)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= pitch) return;
+    int32_t *t = band_totals + (int64_t)blockIdx.y * n_bands * pitch + c;
+    int acc = 0;
+    for (int b = 0; b < n_bands; ++b) {
+        const int v = t[(int64_t)b * pitch];
+        t[(int64_t)b * pitch] = acc;
+        acc += v;
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_integral_kernel(const int32_t *src, int pitch, int W, int H,
+                                                              int32_t *dst)
+{
+    const int64_t n = (int64_t)(W + 1) * (H + 1);
+    const int pair = blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int y = (int)(i / (W + 1)), x = (int)(i - (int64_t)y * (W + 1));
+        dst[(int64_t)pair * n + i] = src[((int64_t)pair * (H + 1) + y) * pitch + x + kIntegralColOffset];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FREAK pieces
+// ------------------------------------------------------------------------------------------------
+
+// floor(v / a) for 0 <= v, 0 < a, v / a <= 255 (a box SUM over its pixel count): one reciprocal, one fix-up.
+__device__ __forceinline__ int div_box(int v, int a)
+{
+    int q = (int)((float)v * __builtin_amdgcn_rcpf((float)a));
+    int r = v - q * a;
+    if (r < 0) {
+        --q;
+        r += a;
+    }
+    if (r >= a) ++q;
+    return q;
+}
+
+// FREAK::meanIntensity, box branch (radius >= 0.5; the context refuses tables with a smaller sigma).
+__device__ __forceinline__ int mean_intensity(const int32_t *__restrict__ integ, int pitch, float kx, float ky,
+                                              const PatternPoint P)
+{
+    const float xf = P.x + kx;
+    const float yf = P.y + ky;
+    const float radius = P.sigma;
+    const int x_left = (int)((double)(xf - radius) + 0.5);
+    const int y_top = (int)((double)(yf - radius) + 0.5);
+    const int x_right = (int)((double)(xf + radius) + 1.5);
+    const int y_bottom = (int)((double)(yf + radius) + 1.5);
+    const int32_t *top = integ + (int64_t)y_top * pitch + kIntegralColOffset;
+    const int32_t *bot = integ + (int64_t)y_bottom * pitch + kIntegralColOffset;
+    int ret_val = bot[x_right];
+    ret_val -= bot[x_left];
+    ret_val += top[x_left];
+    ret_val -= top[x_right];
+    return div_box(ret_val, (x_right - x_left) * (y_bottom - y_top)) & 0xff;
+}
+
+// thetaIdx from the integer direction sums (freak.cpp computeImpl):
+//   angle = (float)(atan2((float)direction1,(float)direction0)*(180.0/CV_PI));  atan2(float,float) -> float
+//   thetaIdx = int(FREAK_NB_ORIENTATION*angle*(1/360.0)+0.5); wrap into [0,256)
+// The float atan2 is taken as the double result rounded once (the reference's x86 MSVC CRT does exactly that).
+__device__ __forceinline__ int theta_index(int direction0, int direction1)
+{
+    const float a = (float)atan2((double)(float)direction1, (double)(float)direction0);
+    const float angle = (float)((double)a * (180.0 / kCvPi));
+    int t = (int)((double)(256.0f * angle) * (1 / 360.0) + 0.5);
+    if (t < 0) t += kNbOrientation;
+    if (t >= kNbOrientation) t -= kNbOrientation;
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MIP pieces
+// ------------------------------------------------------------------------------------------------
+
+// motionInterchangePattern (MoFREAKUtilities.cpp:46-99) for all 8 patch centres (:308-316) at once:
+// lane = 8*centre + offset computes one 9-byte strip SSD; the ballot IS the 8 motion bytes.
+// The strip is 9 CONTIGUOUS bytes of the 19-byte-stride buffer (the reference walks patch.data with p++).
+__device__ __forceinline__ uint64_t mip_bits(const uint8_t *cur19, const uint8_t *prev19, int mip_theta)
+{
+    const int lane = lane_id();
+    const int c = lane >> 3, i = lane & 7;
+    const int cx = (0xDDD99555u >> (4 * c)) & 15;         // centres x: 5,5,5,9,9,13,13,13
+    const int cy = (0xD95D5D95u >> (4 * c)) & 15;         //         y: 5,9,13,5,13,5,9,13
+    const int dx = (int)((0x14787410u >> (4 * i)) & 15) - 4;  // offsets dx: -4,-3,0,3,4,3,0,-3
+    const int dy = (int)((0x10147874u >> (4 * i)) & 15) - 4;  //         dy: 0,3,4,3,0,-3,-4,-3
+    const uint8_t *p = cur19 + (cy - 1) * kPatch + (cx - 1);
+    const uint8_t *p2 = prev19 + (cy + dy - 1) * kPatch + (cx + dx - 1);
+    int ssd = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int d = (int)p[k] - (int)p2[k];
+        ssd += d * d;
+    }
+    return __ballot(ssd > mip_theta);
+}
+
+// One output pixel of cv::resize(8UC1 -> 19x19, INTER_LINEAR) from its four source pixels.
+__device__ __forceinline__ uint8_t resize_px(int s00, int s01, int s10, int s11, const ResizeTap tx, const ResizeTap ty)
+{
+    const int t0 = s00 * tx.c0 + s01 * tx.c1;
+    const int t1 = s10 * tx.c0 + s11 * tx.c1;
+    return (uint8_t)(((((int)ty.c0 * (t0 >> 4)) >> 16) + (((int)ty.c1 * (t1 >> 4)) >> 16) + 2) >> 2);
+}
+
+constexpr int kRoiLdsSide = 32;  // ROIs up to 32x32 are staged in LDS; larger ones are sampled from global memory
+constexpr int kP19Pad = 368;
+
+struct WaveScratch {
+    uint8_t roi[2][kRoiLdsSide * kRoiLdsSide];
+    ResizeTap taps[2][20];
+    uint8_t p19[2][kP19Pad];
+};
+
+// ------------------------------------------------------------------------------------------------
+// describe_kernel: one wavefront per keypoint instance (grid-stride over the chunk's instances).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a)
+{
+    __shared__ __attribute__((aligned(16))) SmallTables st;
+    __shared__ __attribute__((aligned(16))) WaveScratch scratch[4];
+
+    for (int i = threadIdx.x; i < (int)(sizeof(SmallTables) / 4); i += 256)
+        reinterpret_cast<int32_t *>(&st)[i] = reinterpret_cast<const int32_t *>(a.small)[i];
+    __syncthreads();
+
+    const int lane = lane_id();
+    const int wave_in_block = threadIdx.x >> 6;
+    WaveScratch &ws = scratch[wave_in_block];
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int W = a.f.W, H = a.f.H;
+
+    for (int64_t item = (int64_t)blockIdx.x * 4 + wave_in_block; item < a.n_items; item += n_waves) {
+        // ---- which keypoint of which pair
+        int64_t g, out_idx;
+        int pair_local;
+        if (a.kp_offsets == nullptr) {
+            pair_local = (int)((uint64_t)item / (uint64_t)a.n_kp);
+            g = item - (int64_t)pair_local * a.n_kp;
+            out_idx = a.item_base + item;
+        } else {
+            g = a.item_base + item;
+            out_idx = g;
+            int lo = 0, hi = a.n_pairs;  // kp_offsets[first_pair+lo] <= g < kp_offsets[first_pair+hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (a.kp_offsets[a.first_pair + mid] <= g)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            pair_local = lo;
+        }
+        const mofreak_keypoint kp = a.kps[g];
+        const float kx = kp.x, ky = kp.y, size = kp.size;
+
+        // ---- DescriptorExtractor::compute + FREAK::computeImpl keypoint filter
+        bool ok = (size >= FLT_EPSILON) && (size <= FLT_MAX) && (fabsf(kx) <= FLT_MAX) && (fabsf(ky) <= FLT_MAX);
+        int idx;
+        if (st.scale_normalized) {
+            const bool ge = (lane < kNbScales - 1) && (size >= st.scale_thresholds[lane]);
+            idx = __popcll(__ballot(ge));
+        } else {
+            idx = st.fixed_scale_index;
+        }
+        const int ps = st.pattern_sizes[idx];
+        if (kx <= ps || ky <= ps || kx >= W - ps || ky >= H - ps) ok = false;
+
+        uint64_t app = 0, mot = 0;
+        int theta = -1, direction0 = 0, direction1 = 0;
+        const uint8_t *cur = a.f.cur + (int64_t)pair_local * a.f.pair_stride;
+        const uint8_t *prev = a.f.prev + (int64_t)pair_local * a.f.pair_stride;
+        const int x_i = (int)kx, y_i = (int)ky;                  // :460 float -> int parameters
+        const int tl_x = x_i - ((int)size) / 2, tl_y = y_i - ((int)size) / 2;  // :293-294
+        const int L = (int)ceilf(size);                                          // :295
+        if (ok) {
+            if (L > kMaxRoiSide) {
+                if (lane == 0) atomicOr(a.status, 2);
+                ok = false;
+            } else if (tl_x < 0 || tl_y < 0 || tl_x + L > W || tl_y + L > H) {
+                if (lane == 0) atomicOr(a.status, 1);  // the reference throws from cv::Mat::operator()(Rect)
+                ok = false;
+            }
+        }
+
+        if (ok) {
+            // ================= FREAK on the difference image (through its integral)
+            const int32_t *integ = a.integral + (int64_t)pair_local * (H + 1) * a.pitch;
+            const PatternPoint *lut_scale = a.lut + (int64_t)idx * kNbOrientation * kNbPoints;
+            theta = 0;
+            if (st.orientation_normalized) {
+                int v0 = 0;
+                if (lane < kNbPoints) v0 = mean_intensity(integ, a.pitch, kx, ky, lut_scale[lane]);
+                int t0 = 0, t1 = 0;
+                {
+                    const OrientPair op = st.orient[lane < kNbOrientPairs ? lane : 0];
+                    const int delta = __shfl(v0, op.i) - __shfl(v0, op.j);
+                    if (lane < kNbOrientPairs) {
+                        t0 = delta * op.weight_dx / 2048;  // C division: truncates toward zero, per term
+                        t1 = delta * op.weight_dy / 2048;
+                    }
+                }
+                direction0 = wave_sum(t0);
+                direction1 = wave_sum(t1);
+                theta = theta_index(direction0, direction1);
+            }
+            int v = 0;
+            if (lane < kNbPoints) v = mean_intensity(integ, a.pitch, kx, ky, lut_scale[theta * kNbPoints + lane]);
+            {
+                const int va = __shfl(v, (int)st.bit_pair_i[lane]);
+                const int vb = __shfl(v, (int)st.bit_pair_j[lane]);
+                bool bit;
+                if (st.bit_mode == MOFREAK_BITS_SSE)
+                    bit = va >= vb;
+                else if (st.bit_mode == MOFREAK_BITS_NATURAL)
+                    bit = va > vb;
+                else
+                    bit = (int)(int8_t)va > (int)(int8_t)vb;
+                app = __ballot(bit);
+            }
+
+            // ================= MIP on (current, previous) gray frames
+            {
+                const ResizeTap *tab = a.resize + (int64_t)L * 2 * kPatch;
+                if (lane < 2 * kPatch) ws.taps[lane / kPatch][lane % kPatch] = tab[lane];
+            }
+            const uint8_t *src_c = cur + (int64_t)tl_y * a.f.row_stride + tl_x;
+            const uint8_t *src_p = prev + (int64_t)tl_y * a.f.row_stride + tl_x;
+            const bool staged = L <= kRoiLdsSide;
+            if (staged) {
+                // lanes = (row, column) of a strip of the ROI; 16-wide strips for small ROIs, 32-wide otherwise
+                const int wshift = L <= 16 ? 4 : 5;
+                const int c = lane & ((1 << wshift) - 1), r0 = lane >> wshift, rstep = 64 >> wshift;
+                if (c < L)
+                    for (int r = r0; r < L; r += rstep) {
+                        ws.roi[0][r * L + c] = src_c[(int64_t)r * a.f.row_stride + c];
+                        ws.roi[1][r * L + c] = src_p[(int64_t)r * a.f.row_stride + c];
+                    }
+            }
+            wave_lds_sync();
+            for (int o = lane; o < kPatch * kPatch; o += 64) {
+                const int dy = o / kPatch, dx = o - dy * kPatch;
+                const ResizeTap tx = ws.taps[0][dx], ty = ws.taps[1][dy];
+                uint8_t oc, op;
+                if (staged) {
+                    const uint8_t *rc0 = ws.roi[0] + ty.ofs * L, *rc1 = ws.roi[0] + ty.ofs1 * L;
+                    const uint8_t *rp0 = ws.roi[1] + ty.ofs * L, *rp1 = ws.roi[1] + ty.ofs1 * L;
+                    oc = resize_px(rc0[tx.ofs], rc0[tx.ofs1], rc1[tx.ofs], rc1[tx.ofs1], tx, ty);
+                    op = resize_px(rp0[tx.ofs], rp0[tx.ofs1], rp1[tx.ofs], rp1[tx.ofs1], tx, ty);
+                } else {
+                    const uint8_t *rc0 = src_c + (int64_t)ty.ofs * a.f.row_stride, *rc1 = src_c + (int64_t)ty.ofs1 * a.f.row_stride;
+                    const uint8_t *rp0 = src_p + (int64_t)ty.ofs * a.f.row_stride, *rp1 = src_p + (int64_t)ty.ofs1 * a.f.row_stride;
+                    oc = resize_px(rc0[tx.ofs], rc0[tx.ofs1], rc1[tx.ofs], rc1[tx.ofs1], tx, ty);
+                    op = resize_px(rp0[tx.ofs], rp0[tx.ofs1], rp1[tx.ofs], rp1[tx.ofs1], tx, ty);
+                }
+                ws.p19[0][o] = oc;
+                ws.p19[1][o] = op;
+            }
+            wave_lds_sync();
+            mot = mip_bits(ws.p19[0], ws.p19[1], st.mip_theta);
+            if (a.out_roi19 != nullptr) {
+                uint8_t *dst = a.out_roi19 + out_idx * (2 * kPatch * kPatch);
+                for (int o = lane; o < 2 * kPatch * kPatch; o += 64)
+                    dst[o] = o < kPatch * kPatch ? ws.p19[0][o] : ws.p19[1][o - kPatch * kPatch];
+            }
+            wave_lds_sync();  // the next keypoint of this wave overwrites the scratch
+        } else if (a.out_roi19 != nullptr) {
+            uint8_t *dst = a.out_roi19 + out_idx * (2 * kPatch * kPatch);
+            for (int o = lane; o < 2 * kPatch * kPatch; o += 64) dst[o] = 0;
+        }
+
+        if (lane == 0) {
+            uint4 d;
+            d.x = (uint32_t)app;
+            d.y = (uint32_t)(app >> 32);
+            d.z = (uint32_t)mot;
+            d.w = (uint32_t)(mot >> 32);
+            *reinterpret_cast<uint4 *>(a.out_desc + out_idx * 16) = d;
+            a.out_valid[out_idx] = ok ? 1 : 0;
+            if (a.out_info != nullptr)
+                *reinterpret_cast<int4 *>(a.out_info + out_idx * 4) = make_int4(idx, ok ? theta : -1, direction0, direction1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mip19_kernel(const uint8_t *cur19, const uint8_t *prev19, int64_t n,
+                                                    int mip_theta, uint8_t *out)
+{
+    __shared__ uint8_t buf[4][2][kP19Pad];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    for (int64_t item = (int64_t)blockIdx.x * 4 + w; item < n; item += (int64_t)gridDim.x * 4) {
+        for (int o = lane; o < kPatch * kPatch; o += 64) {
+            buf[w][0][o] = cur19[item * (kPatch * kPatch) + o];
+            buf[w][1][o] = prev19[item * (kPatch * kPatch) + o];
+        }
+        wave_lds_sync();
+        const uint64_t m = mip_bits(buf[w][0], buf[w][1], mip_theta);
+        if (lane < 8) out[item * 8 + lane] = (uint8_t)(m >> (8 * lane));
+        wave_lds_sync();
+    }
+}
+
+__global__ __launch_bounds__(256) void theta_kernel(const int32_t *dirs, int64_t n, int32_t *out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = theta_index(dirs[2 * i], dirs[2 * i + 1]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stable compaction of valid descriptors into 32-byte rows.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int *total)
+{
+    __shared__ int wave_tot[4];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const int incl = wave_inclusive_scan(v);
+    if (lane == 63) wave_tot[w] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < w; ++i) base += wave_tot[i];
+    *total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(256) void compact_count_kernel(CompactArgs a)
+{
+    const int64_t base = (int64_t)blockIdx.x * kCompactItemsPerBlock + threadIdx.x * 4;
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (base + k < a.n_items) cnt += a.valid[base + k] != 0;
+    int total;
+    block_exclusive_scan_256(cnt, &total);
+    if (threadIdx.x == 0) a.block_offsets[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void compact_scan_kernel(int64_t *block_offsets, int n_blocks)
+{
+    // single workgroup: exclusive scan of the per-block counts; block_offsets[n_blocks] = total
+    __shared__ int64_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < n_blocks; b0 += 256) {
+        const int b = b0 + threadIdx.x;
+        const int v = b < n_blocks ? (int)block_offsets[b] : 0;
+        int total;
+        const int excl = block_exclusive_scan_256(v, &total);
+        const int64_t carry = carry_s;
+        if (b < n_blocks) block_offsets[b] = carry + excl;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_offsets[n_blocks] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void compact_scatter_kernel(CompactArgs a)
+{
+    const int64_t base = (int64_t)blockIdx.x * kCompactItemsPerBlock + threadIdx.x * 4;
+    int flags[4], cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        flags[k] = (base + k < a.n_items) && a.valid[base + k] != 0;
+        cnt += flags[k];
+    }
+    int total;
+    int64_t pos = a.block_offsets[blockIdx.x] + block_exclusive_scan_256(cnt, &total);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!flags[k]) continue;
+        const int64_t item = base + k;
+        int64_t g;
+        int pair;
+        if (a.kp_offsets == nullptr) {
+            pair = (int)(item / a.n_kp);
+            g = item - (int64_t)pair * a.n_kp;
+        } else {
+            g = item;
+            int lo = 0, hi = a.n_pairs;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (a.kp_offsets[mid] <= g)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            pair = lo;
+        }
+        if (pos < a.capacity) {
+            const mofreak_keypoint kp = a.kps[g];
+            const uint4 d = *reinterpret_cast<const uint4 *>(a.desc + item * 16);
+            uint4 lo4, hi4;
+            lo4.x = __float_as_uint(kp.x);
+            lo4.y = __float_as_uint(kp.y);
+            lo4.z = (uint32_t)(a.first_frame_number + pair);
+            lo4.w = __float_as_uint(kp.size);
+            hi4 = d;
+            uint4 *dst = reinterpret_cast<uint4 *>(a.rows + pos);
+            dst[0] = lo4;
+            dst[1] = hi4;
+        }
+        ++pos;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+int launch_integral(const IntegralArgs &a, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid(a.n_bands, a.n_pairs);
+    const size_t lds = (size_t)kBandRows * a.pitch * sizeof(int32_t);
+    if (lds > 64 * 1024) {  // more than the default dynamic-LDS limit: opt in (a CU has 160 KiB)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&band_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&band_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    hipLaunchKernelGGL(band_kernel<false>, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(band_scan_kernel, dim3((a.pitch + 255) / 256, a.n_pairs), dim3(256), 0, s, a.band_totals,
+                       a.pitch, a.n_bands);
+    hipLaunchKernelGGL(band_kernel<true>, grid, dim3(256), lds, s, a);
+    return (int)hipGetLastError();
+}
+
+int launch_describe(const DescribeArgs &a, int n_blocks, void *stream)
+{
+    hipLaunchKernelGGL(describe_kernel, dim3(n_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+int launch_mip19(const uint8_t *cur19, const uint8_t *prev19, int64_t n, int mip_theta, uint8_t *out, void *stream)
+{
+    const int blocks = (int)((n + 3) / 4 < 2048 ? (n + 3) / 4 : 2048);
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(mip19_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), cur19, prev19, n,
+                       mip_theta, out);
+    return (int)hipGetLastError();
+}
+
+int launch_theta(const int32_t *dirs, int64_t n, int32_t *out, void *stream)
+{
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(theta_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dirs, n, out);
+    return (int)hipGetLastError();
+}
+
+int launch_compact(const CompactArgs &a, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a.n_blocks > 0) {
+        hipLaunchKernelGGL(compact_count_kernel, dim3(a.n_blocks), dim3(256), 0, s, a);
+    }
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(256), 0, s, a.block_offsets, a.n_blocks);
+    if (a.n_blocks > 0) {
+        hipLaunchKernelGGL(compact_scatter_kernel, dim3(a.n_blocks), dim3(256), 0, s, a);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_unpack_integral(const int32_t *src, int pitch, int W, int H, int n_pairs, int32_t *dst, void *stream)
+{
+    hipLaunchKernelGGL(unpack_integral_kernel, dim3(512, n_pairs), dim3(256), 0, static_cast<hipStream_t>(stream), src,
+                       pitch, W, H, dst);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mofreak

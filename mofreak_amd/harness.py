@@ -1,0 +1,193 @@
+"""Host-side mirror of the reference's interface for the path, in Python, over the C ABI.
+
+  MoFREAKUtilities      the reference class (src/MoFREAK/MoFREAKUtilities.h:55-104): same method names,
+                        argument meaning and outputs; "videos" are raw gray frame stacks (.npy, T x H x W u8)
+                        because neither box has a video decoder, and keypoints come from a provider
+                        (dense grid by default; the BRISK detector is SURVEY.md 8(f) row 1, not built yet)
+  compute_mofreak_files computeMoFREAKFiles() (src/MoFREAK/main.cpp:854-924): walk a directory of videos, one
+                        .mofreak file each -- sharded one-video-per-GPU across ranks (no data-path collective)
+  gather_rows           the only exchange step: variable-length gather of 32-byte rows to rank 0
+
+PyTorch is plumbing here (device tensors, torch.distributed); the compute is libmofreak_hip.so.
+"""
+from __future__ import annotations
+
+import os
+from collections import deque
+from typing import Callable, Sequence
+
+import numpy as np
+
+from . import api, synth
+
+# enum datasets {KTH, TRECVID, HOLLYWOOD, UTI1, UTI2, HMDB51, UCF101}  (MoFREAKUtilities.h:103)
+KTH, TRECVID, HOLLYWOOD, UTI1, UTI2, HMDB51, UCF101 = range(7)
+
+KeypointProvider = Callable[[int, int, int], np.ndarray]  # (frame_index, W, H) -> (n, 3) float32
+
+
+def dense_grid_provider(step: int = 16, size: float = 12.0, lo: int = 38) -> KeypointProvider:
+    cache = {}
+
+    def provider(_frame: int, W: int, H: int) -> np.ndarray:
+        if (W, H) not in cache:
+            cache[(W, H)] = synth.dense_grid(W, H, step, size, lo)
+        return cache[(W, H)]
+
+    provider.shared = True  # same list for every frame -> the kp_offsets == NULL fast path
+    return provider
+
+
+class MoFREAKUtilities:
+    """Drop-in for the reference class for the extraction path.
+
+    Reference semantics kept: computeMoFREAKFromFile APPENDS to the internal feature list, ALWAYS writes
+    mofreak_filename with everything accumulated so far, and optionally clears afterwards
+    (MoFREAKUtilities.cpp:374-498); readMoFREAKFeatures appends the file's rows in REVERSE order
+    (:1206-1210); getMoFREAKFeatures returns a copy.
+    """
+
+    NUMBER_OF_BYTES_FOR_APPEARANCE = 8  # MoFREAKUtilities.h:72
+    NUMBER_OF_BYTES_FOR_MOTION = 8      # MoFREAKUtilities.h:73
+
+    def __init__(self, dset: int, device: int = 0, keypoint_provider: KeypointProvider | None = None, **params):
+        self.dataset = dset
+        self.current_action = 0
+        self.actions: dict[str, int] = {}
+        self.features: deque = deque()  # of structured rows (api.ROW_DTYPE arrays)
+        self._labels: deque = deque()
+        self._ctx = api.Context(device, **params)
+        self.keypoint_provider = keypoint_provider or dense_grid_provider()
+
+    # ---- the hot path
+    def computeMoFREAKFromFile(self, video_filename: str, mofreak_filename: str,
+                               clear_features_after_computation: bool) -> None:
+        frames = np.load(video_filename, mmap_mode="r")
+        if frames.ndim != 3 or frames.dtype != np.uint8:
+            raise ValueError(f"{video_filename}: expected a (T, H, W) uint8 gray frame stack")
+        rows = self.extract_rows(np.ascontiguousarray(frames))
+        if len(rows):
+            self.features.append(rows)
+        print(f"Writing this mofreak file: {mofreak_filename}")
+        self.writeMoFREAKFeaturesToFile(mofreak_filename)
+        if clear_features_after_computation:
+            self.clearFeatures()
+
+    # north-star spelling (BASELINE.json names these; the reference snapshot does not have them)
+    computeMoFREAKFeatures = computeMoFREAKFromFile
+
+    def extract_rows(self, frames: np.ndarray) -> np.ndarray:
+        """Rows of one gray frame stack, in the reference's order (frames ascending, keypoints in input order)."""
+        T, H, W = frames.shape
+        gap = self._ctx.params.gap_for_frame_difference
+        if T <= gap:
+            return np.zeros(0, api.ROW_DTYPE)
+        prov = self.keypoint_provider
+        if getattr(prov, "shared", False):
+            return self._ctx.extract_stream_host(frames, prov(gap, W, H))
+        lists = [np.ascontiguousarray(prov(t, W, H), np.float32).reshape(-1, 3) for t in range(gap, T)]
+        offs = np.concatenate([[0], np.cumsum([len(k) for k in lists])]).astype(np.int64)
+        kps = np.concatenate(lists) if offs[-1] else np.zeros((0, 3), np.float32)
+        return self._ctx.extract_stream_host(frames, kps, kp_offsets=offs)
+
+    def buildMoFREAKFeature(self, cur: np.ndarray, prev: np.ndarray, x: float, y: float, size: float):
+        """One keypoint of one frame pair -> (appearance[8], motion[8]) or None if FREAK erases it."""
+        d, v = self._ctx.extract_pairs_host(cur[None], prev[None], np.float32([[x, y, size]]))
+        return (d[0, :8].copy(), d[0, 8:].copy()) if v[0] else None
+
+    # ---- feature list / files
+    def getMoFREAKFeatures(self) -> np.ndarray:
+        return np.concatenate(list(self.features)) if self.features else np.zeros(0, api.ROW_DTYPE)
+
+    def clearFeatures(self) -> None:
+        self.features.clear()
+
+    def writeMoFREAKFeaturesToFile(self, output_file: str) -> None:
+        with open(output_file, "wb") as f:
+            for chunk in self.features:
+                f.write(api.format_rows(chunk))
+
+    def readMoFREAKFeatures(self, filename: str, num_to_sample: int = 0) -> None:
+        with open(filename, "rb") as f:
+            rows = api.parse_rows(f.read())
+        if num_to_sample and len(rows) > num_to_sample:
+            # the reference random_shuffles and takes num_to_sample from the back (:1194-1203); nondeterministic there
+            rng = np.random.default_rng()
+            rows = rows[rng.permutation(len(rows))][-num_to_sample:]
+        if len(rows):
+            self.features.append(rows[::-1].copy())
+
+    def setAllFeaturesToLabel(self, label: int) -> None:
+        self._label = label  # labels are side metadata here; rows carry no action field
+
+    def setCurrentAction(self, folder_name: str) -> None:
+        if folder_name not in self.actions:  # the UCF101 branch (:1049-1059), "the right way to do this"
+            self.actions[folder_name] = len(self.actions)
+        self.current_action = self.actions[folder_name]
+
+    def close(self):
+        self._ctx.close()
+
+
+# ------------------------------------------------------------------ sharding
+def shard_videos(costs: Sequence[float], world_size: int) -> list[list[int]]:
+    """Longest-processing-time-first assignment of videos to ranks; returns per-rank index lists (ascending)."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    load = [0.0] * world_size
+    out: list[list[int]] = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += costs[i]
+    return [sorted(x) for x in out]
+
+
+def gather_rows(rows, n_rows: int, dst: int = 0, group=None):
+    """Variable-length gather of 32-byte rows to rank `dst`: one all_gather of the counts, then every peer sends
+    its rows straight to the root (point-to-point, one xGMI link per peer -- not a ring).
+
+    rows: uint8 tensor (>= n_rows*32 bytes) on the rank's device (cuda for nccl/RCCL, cpu for gloo).
+    Returns on dst: (uint8 tensor of all rows in rank order, list of per-rank counts); elsewhere (None, counts).
+    """
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = rows.device
+    cnt = torch.tensor([n_rows], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, cnt, group=group)
+    counts = [int(c.item()) for c in counts]
+    mine = rows.reshape(-1)[: n_rows * 32]
+    if rank == dst:
+        out = torch.empty(sum(counts) * 32, dtype=torch.uint8, device=dev)
+        offs = np.concatenate([[0], np.cumsum(counts)]) * 32
+        ops = []
+        for r in range(world):
+            seg = out[offs[r]: offs[r + 1]]
+            if r == rank:
+                seg.copy_(mine)
+            elif counts[r]:
+                ops.append(dist.P2POp(dist.irecv, seg, r, group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return out, counts
+    if n_rows:
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine, dst, group)]):
+            req.wait()
+    return None, counts
+
+
+def compute_mofreak_files(video_paths: Sequence[str], out_dir: str, mofreak: MoFREAKUtilities, rank: int = 0,
+                          world_size: int = 1, costs: Sequence[float] | None = None) -> list[str]:
+    """computeMoFREAKFiles (main.cpp:854-924) for this rank's shard: <video> -> <out_dir>/<video>.mofreak."""
+    costs = costs if costs is not None else [os.path.getsize(p) for p in video_paths]
+    mine = shard_videos(costs, world_size)[rank]
+    os.makedirs(out_dir, exist_ok=True)
+    written = []
+    for i in mine:
+        out = os.path.join(out_dir, os.path.basename(video_paths[i]) + ".mofreak")
+        mofreak.computeMoFREAKFromFile(video_paths[i], out, True)
+        written.append(out)
+    return written

@@ -1,0 +1,342 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle -- bit-exact, row by row of
+SURVEY.md section 8(a).  Every test needs a real MI355X and fails (never skips or falls back) without one."""
+import numpy as np
+import pytest
+
+import mofreak_amd as M
+from mofreak_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CENTERS = [(5, 5), (5, 9), (5, 13), (9, 5), (9, 13), (13, 5), (13, 9), (13, 13)]
+OFFSETS = [(-4, 0), (-3, 3), (0, 4), (3, 3), (4, 0), (3, -3), (0, -4), (-3, -3)]
+
+
+def oracle_pairs(oracle, cur, prev, kps, offsets=None, **kw):
+    """Oracle descriptors for a (n_pairs,H,W) batch, shared keypoint list or CSR."""
+    f = oracle.Freak(**kw)
+    descs, valids = [], []
+    for p in range(cur.shape[0]):
+        kp = kps if offsets is None else kps[offsets[p]:offsets[p + 1]]
+        d, v = f.extract_pair(cur[p], prev[p], kp)
+        descs.append(d)
+        valids.append(v)
+    return np.concatenate(descs), np.concatenate(valids)
+
+
+# ------------------------------------------------------------------ R2: absdiff + integral
+@pytest.mark.parametrize("W,H", [(37, 53), (64, 8), (641, 479), (1920, 1080), (5, 3), (1023, 17)])
+def test_diff_integral_matches_oracle(gpu_ctx, oracle, W, H):
+    rng = np.random.default_rng(W * 1000 + H)
+    cur = rng.integers(0, 256, (2, H, W), dtype=np.uint8)
+    prev = rng.integers(0, 256, (2, H, W), dtype=np.uint8)
+    cur[1], prev[1] = 255, 0  # worst case for the int32 range
+    got = gpu_ctx.diff_integral_host(cur, prev)
+    for p in range(2):
+        assert np.array_equal(got[p], oracle.integral(oracle.absdiff(cur[p], prev[p])))
+
+
+# ------------------------------------------------------------------ R3: motionInterchangePattern
+def test_mip19_known_answers_on_gpu(gpu_ctx, oracle):
+    cur, prev, want = [], [], []
+
+    def add(c, p):
+        cur.append(np.asarray(c, np.uint8).reshape(361))
+        prev.append(np.asarray(p, np.uint8).reshape(361))
+        want.append([oracle.mip(cur[-1], prev[-1], x, y) for (x, y) in CENTERS])
+
+    add(np.full(361, 77), np.full(361, 77))       # KAT 1
+    add(np.zeros(361), np.full(361, 255))          # KAT 2
+    for ci, (x, y) in enumerate(CENTERS):          # KAT 3, 4 at every centre and offset
+        for i, (dx, dy) in enumerate(OFFSETS):
+            b = (y + dy - 1) * 19 + (x + dx - 1)
+            p = np.zeros(361, np.uint8); p[b] = 12; p[b + 1] = 12
+            add(np.zeros(361), p)
+            assert (want[-1][ci] >> i) & 1 == 0
+            p = np.zeros(361, np.uint8); p[b] = 17
+            add(np.zeros(361), p)
+            assert (want[-1][ci] >> i) & 1 == 1
+            p = np.zeros(361, np.uint8); p[b + 6] = 255       # byte 6 of the contiguous strip counts
+            add(np.zeros(361), p)
+            assert (want[-1][ci] >> i) & 1 == 1
+            p = np.zeros(361, np.uint8); p[(y + 1 + dy) * 19 + (x + dx)] = 255  # 3rd row of a true 3x3 does not
+            add(np.zeros(361), p)
+            assert (want[-1][ci] >> i) & 1 == 0
+    got = gpu_ctx.mip19_host(np.stack(cur), np.stack(prev))
+    assert np.array_equal(got, np.asarray(want, np.uint8))
+    assert got[0].tolist() == [0] * 8 and got[1].tolist() == [255] * 8
+
+
+def test_mip19_random_buffers(gpu_ctx, oracle):
+    rng = np.random.default_rng(21)
+    n = 3000
+    cur = rng.integers(0, 256, (n, 361), dtype=np.uint8)
+    prev = (cur.astype(np.int64) + rng.integers(-7, 8, (n, 361))).clip(0, 255).astype(np.uint8)
+    prev[: n // 3] = np.roll(cur[: n // 3], 3, axis=1)
+    got = gpu_ctx.mip19_host(cur, prev)
+    want = np.array([[oracle.mip(cur[k], prev[k], x, y) for (x, y) in CENTERS] for k in range(n)], np.uint8)
+    assert np.array_equal(got, want)
+    assert 0.05 < np.unpackbits(got).mean() < 0.95
+
+
+# ------------------------------------------------------------------ R4: ROI + cv::resize
+def test_roi19_matches_oracle_resize_for_every_small_side(gpu_ctx, oracle):
+    W, H = 700, 500
+    fr = synth.synth_stack(6, W, H)
+    rng = np.random.default_rng(8)
+    cur = (fr[5].astype(np.int64) + rng.integers(-40, 41, (H, W))).clip(0, 255).astype(np.uint8)
+    prev = fr[0]
+    sizes = np.concatenate([np.arange(7, 61, dtype=np.float32), np.float32([7.5, 11.01, 12.99, 31.2, 32.0, 32.5, 33.0, 47.3, 64.9, 70.0])])
+    kps = np.stack([np.full(len(sizes), 350.6, np.float32), np.full(len(sizes), 251.3, np.float32), sizes], 1)
+    got = gpu_ctx.roi19_host(cur, prev, kps)
+    for k, s in enumerate(sizes):
+        x, y = int(kps[k, 0]), int(kps[k, 1])
+        tl_x, tl_y, L = x - int(s) // 2, y - int(s) // 2, int(np.ceil(s))
+        assert np.array_equal(got[k, 0], oracle.resize_linear(cur[tl_y:tl_y + L, tl_x:tl_x + L])), s
+        assert np.array_equal(got[k, 1], oracle.resize_linear(prev[tl_y:tl_y + L, tl_x:tl_x + L])), s
+
+
+# ------------------------------------------------------------------ R6: FREAK internals
+def test_freak_scale_theta_directions_match_oracle(gpu_ctx, oracle):
+    W, H = 640, 480
+    fr = synth.synth_stack(6, W, H)
+    rng = np.random.default_rng(17)
+    kps = synth.random_keypoints(rng, 4000, W, H)
+    kps[:500, 2] = rng.uniform(6.0, 60.0, 500).astype(np.float32)
+    info = gpu_ctx.freak_info_host(fr[5], fr[0], kps)
+    f = oracle.Freak()
+    valid, _, theta, dirs = f.compute(oracle.absdiff(fr[5], fr[0]), kps)
+    assert 0.2 < valid.mean() < 0.95
+    want_idx = np.array([f.scale_index(s) for s in kps[:, 2]])
+    assert np.array_equal(info[:, 0], want_idx)
+    assert np.array_equal(info[:, 1], theta)                  # -1 for erased keypoints on both sides
+    assert np.array_equal(info[valid == 1, 2:], dirs[valid == 1])
+    assert len(np.unique(theta[valid == 1])) > 100
+
+
+def test_theta_index_device_matches_oracle(gpu_ctx, oracle):
+    rng = np.random.default_rng(33)
+    d = np.concatenate([
+        rng.integers(-6500, 6501, (400000, 2)),
+        rng.integers(-40, 41, (100000, 2)),
+        np.array([[0, 0], [1, 0], [-1, 0], [0, 1], [0, -1], [1, 1], [-1, -1], [-1, 1], [1, -1], [6000, -1], [-6000, -1], [-6000, 1]]),
+        np.stack(np.meshgrid(np.arange(-60, 61), np.arange(-60, 61)), -1).reshape(-1, 2)]).astype(np.int32)
+    got = gpu_ctx.theta_index_host(d)
+    want = np.array([oracle.theta_index(int(a), int(b)) for a, b in d], np.int32)
+    assert np.array_equal(got, want)
+    assert got.min() == 0 and got.max() == 255
+
+
+# ------------------------------------------------------------------ the composed path (R2+R4+R5+R6)
+def test_c2_dense_grid_bit_exact(gpu_ctx, oracle):
+    """BASELINE config 2 shape (640x480, 16-px grid, size 12), 12 pairs of a stack."""
+    c = synth.CONFIGS["C2"]
+    fr = synth.synth_stack(17, c["W"], c["H"])
+    kps = synth.config_grid("C2")
+    assert len(kps) == 875
+    cur, prev = fr[5:], fr[:-5]
+    desc, valid = gpu_ctx.extract_pairs_host(cur, prev, kps)
+    want_d, want_v = oracle_pairs(oracle, cur, prev, kps)
+    assert valid.all() and np.array_equal(valid, want_v)
+    assert np.array_equal(desc, want_d)
+    ones_app, ones_mot = np.unpackbits(desc[:, :8]).mean(), np.unpackbits(desc[:, 8:]).mean()
+    assert 0.3 < ones_app < 0.7 and 0.3 < ones_mot < 0.8  # non-degenerate data
+
+
+def test_mixed_sizes_random_positions_bit_exact(gpu_ctx, oracle):
+    """Mixed sizes {8.4,12,18,27,40.5}, fractional coordinates, keypoints over the whole frame (some erased)."""
+    W, H = 640, 480
+    fr = synth.synth_stack(8, W, H)
+    rng = np.random.default_rng(5)
+    kps = synth.random_keypoints(rng, 6000, W, H)
+    kps[:50, 2] = np.float32([0.0, 1e-8, 5.0, 6.9, 7.0, 100.0, 107.0, 150.0, 2.5e5, np.inf] * 5)
+    kps[50:60, 0] = np.float32(np.nan)
+    cur, prev = fr[5:], fr[:3]
+    desc, valid = gpu_ctx.extract_pairs_host(cur, prev, kps)
+    want_d, want_v = oracle_pairs(oracle, cur, prev, kps)
+    assert np.array_equal(valid, want_v)
+    assert np.array_equal(desc, want_d)
+    assert 0.3 < valid.mean() < 0.9
+    assert (desc[valid == 0] == 0).all()
+    gpu_ctx.check_status()  # no ROI ever leaves the image for keypoints that survive FREAK's border filter
+
+
+@pytest.mark.parametrize("mode", [M.BITS_NATURAL, M.BITS_SSE_SIGNED])
+def test_other_bit_modes(native_lib, oracle, mode):
+    W, H = 320, 240
+    fr = synth.synth_stack(6, W, H)
+    kps = synth.random_keypoints(np.random.default_rng(1), 1500, W, H, sizes=(7.0, 9.0, 12.0))
+    with M.Context(0, freak_bit_mode=mode) as ctx:
+        desc, valid = ctx.extract_pairs_host(fr[5:6], fr[0:1], kps)
+    want_d, want_v = oracle_pairs(oracle, fr[5:6], fr[0:1], kps, bit_mode=mode)
+    assert np.array_equal(valid, want_v) and np.array_equal(desc, want_d)
+    base_d, _ = oracle_pairs(oracle, fr[5:6], fr[0:1], kps)
+    assert not np.array_equal(base_d[:, :8], want_d[:, :8]) and np.array_equal(base_d[:, 8:], want_d[:, 8:])
+
+
+def test_orientation_and_scale_normalisation_flags(native_lib, oracle):
+    W, H = 320, 240
+    fr = synth.synth_stack(6, W, H)
+    kps = synth.random_keypoints(np.random.default_rng(2), 800, W, H, sizes=(7.0, 12.0, 20.0))
+    for on, sn in [(0, 1), (1, 0), (0, 0)]:
+        with M.Context(0, freak_orientation_normalized=on, freak_scale_normalized=sn) as ctx:
+            desc, valid = ctx.extract_pairs_host(fr[5:6], fr[0:1], kps)
+        want_d, want_v = oracle_pairs(oracle, fr[5:6], fr[0:1], kps, orientation_normalized=bool(on), scale_normalized=bool(sn))
+        assert np.array_equal(valid, want_v) and np.array_equal(desc, want_d), (on, sn)
+
+
+def test_csr_ragged_keypoint_lists(gpu_ctx, oracle):
+    W, H = 320, 240
+    fr = synth.synth_stack(11, W, H)
+    rng = np.random.default_rng(12)
+    counts = [0, 37, 1, 0, 250, 64]
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    kps = synth.random_keypoints(rng, int(offs[-1]), W, H, sizes=(7.0, 8.4, 12.0))
+    cur, prev = fr[5:], fr[:6]
+    desc, valid = gpu_ctx.extract_pairs_host(cur, prev, kps, kp_offsets=offs)
+    want_d, want_v = oracle_pairs(oracle, cur, prev, kps, offs)
+    assert np.array_equal(valid, want_v) and np.array_equal(desc, want_d)
+
+
+def test_empty_inputs(gpu_ctx):
+    z = np.zeros((2, 64, 64), np.uint8)
+    d, v = gpu_ctx.extract_pairs_host(z, z, np.zeros((0, 3), np.float32))
+    assert d.shape == (0, 16) and v.shape == (0,)
+    d, v = gpu_ctx.extract_pairs_host(z[:0], z[:0], np.float32([[32, 32, 7]]))
+    assert d.shape == (0, 16)
+    rows = gpu_ctx.extract_stream_host(z, np.float32([[32, 32, 7]]))  # T=2 <= gap
+    assert len(rows) == 0
+
+
+def test_bad_arguments_are_reported(gpu_ctx):
+    z = np.zeros((1, 64, 64), np.uint8)
+    kp = np.float32([[32, 32, 7]])
+    out_d, out_v = np.zeros((1, 16), np.uint8), np.zeros(1, np.uint8)
+    with pytest.raises(M.MoFREAKError) as e:
+        gpu_ctx.extract_pairs(z, z, 64, 64, 1, kp, out_d, out_v, row_stride=32)
+    assert e.value.code == -1 and "row_stride" in str(e.value)
+    with pytest.raises(M.MoFREAKError):
+        gpu_ctx.extract_pairs_host(z, z, kp, kp_offsets=np.array([0, 5], np.int64))  # offsets[n_pairs] != n_kp
+    with pytest.raises(M.MoFREAKError):
+        gpu_ctx.extract_pairs(z, z, 0, 64, 1, kp, out_d, out_v)
+
+
+def test_strides_and_unaligned_frames(gpu_ctx, oracle):
+    """row_stride > W, pair_stride with padding, and a frame base that is not 4-byte aligned."""
+    W, H, n = 203, 150, 3
+    fr = synth.synth_stack(n + 5, 256, 160)
+    rs, ps = 256 + 3, (256 + 3) * 160 + 7
+    buf_c = np.zeros(ps * n + 1, np.uint8)
+    buf_p = np.zeros(ps * n + 1, np.uint8)
+    cur = np.zeros((n, H, W), np.uint8)
+    prev = np.zeros((n, H, W), np.uint8)
+    for p in range(n):
+        cur[p], prev[p] = fr[p + 5, :H, :W], fr[p, :H, :W]
+        for y in range(H):
+            buf_c[1 + p * ps + y * rs: 1 + p * ps + y * rs + W] = cur[p, y]
+            buf_p[1 + p * ps + y * rs: 1 + p * ps + y * rs + W] = prev[p, y]
+    kps = synth.random_keypoints(np.random.default_rng(3), 900, W, H, sizes=(7.0, 8.4, 12.0))
+    import torch
+    dc, dp = torch.from_numpy(buf_c).cuda(), torch.from_numpy(buf_p).cuda()
+    dk = torch.from_numpy(kps).cuda()
+    out_d = torch.zeros((n * len(kps), 16), dtype=torch.uint8, device="cuda")
+    out_v = torch.zeros(n * len(kps), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # the context runs on its own stream: torch's fills above must have landed
+    gpu_ctx.extract_pairs(dc[1:], dp[1:], W, H, n, dk, out_d, out_v, row_stride=rs, pair_stride=ps)
+    gpu_ctx.synchronize()
+    want_d, want_v = oracle_pairs(oracle, cur, prev, kps)
+    assert np.array_equal(out_v.cpu().numpy(), want_v) and np.array_equal(out_d.cpu().numpy(), want_d)
+
+
+def test_device_pointers_on_torch_stream(native_lib, oracle):
+    """The zero-copy path: torch tensors in HBM, work queued on torch's current stream."""
+    import torch
+    W, H = 640, 480
+    fr = synth.synth_stack(9, W, H)
+    kps = synth.config_grid("C2")
+    with M.Context(0) as ctx:
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            ctx.use_torch_stream()
+            frames = torch.from_numpy(fr).cuda()
+            dk = torch.from_numpy(kps).cuda()
+            n_pairs = 4
+            out_d = torch.empty((n_pairs * len(kps), 16), dtype=torch.uint8, device="cuda")
+            out_v = torch.empty(n_pairs * len(kps), dtype=torch.uint8, device="cuda")
+            ctx.extract_pairs(frames[5:], frames[:4], W, H, n_pairs, dk, out_d, out_v)
+            rows = torch.zeros(n_pairs * len(kps) * 32, dtype=torch.uint8, device="cuda")
+            n = ctx.compact_rows(dk, n_pairs, 4, out_d, out_v, rows)
+        s.synchronize()
+        ctx.set_stream(None)
+    want_d, want_v = oracle_pairs(oracle, fr[5:], fr[:4], kps)
+    assert np.array_equal(out_d.cpu().numpy(), want_d) and np.array_equal(out_v.cpu().numpy(), want_v)
+    assert n == int(want_v.sum())
+    r = rows.cpu().numpy().view(M.ROW_DTYPE)[:n]
+    assert np.array_equal(np.concatenate([r["appearance"], r["motion"]], 1), want_d[want_v == 1])
+    assert sorted(set(r["frame_number"].tolist())) == [4, 5, 6, 7]
+
+
+# ------------------------------------------------------------------ R1 + R7: streams and rows
+def test_stream_rows_and_text_match_oracle(gpu_ctx, oracle):
+    """computeMoFREAKFromFile's frame loop on a 12-frame stack: pairing, frame labels, erase order, text."""
+    W, H, T = 320, 240, 12
+    fr = synth.synth_stack(T, W, H)
+    rng = np.random.default_rng(44)
+    counts = rng.integers(0, 300, T - 5)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    kps = synth.random_keypoints(rng, int(offs[-1]), W, H, sizes=(7.0, 8.4, 12.0, 18.0))
+    rows = gpu_ctx.extract_stream_host(fr, kps, kp_offsets=offs)
+    want = oracle.Freak().extract_stream(fr, kps, offs)
+    assert len(rows) == len(want) > 100
+    assert rows.tobytes() == want.tobytes()
+    assert M.format_rows(rows) == oracle.format_rows(want)
+    assert rows["frame_number"].min() == 4 and rows["frame_number"].max() == T - 2
+    assert (np.diff(rows["frame_number"]) >= 0).all()
+    # shared keypoint list form
+    grid = synth.dense_grid(W, H, 16, 7.0, 23)
+    rows2 = gpu_ctx.extract_stream_host(fr, grid)
+    offs2 = np.arange(T - 5 + 1, dtype=np.int64) * len(grid)
+    want2 = oracle.Freak().extract_stream(fr, np.tile(grid, (T - 5, 1)), offs2)
+    assert rows2.tobytes() == want2.tobytes() and len(rows2) == (T - 5) * len(grid)
+
+
+def test_compact_rows_capacity_error(gpu_ctx):
+    W, H = 320, 240
+    fr = synth.synth_stack(7, W, H)
+    grid = synth.dense_grid(W, H, 16, 7.0, 23)
+    rows = np.zeros(10, M.ROW_DTYPE)
+    with pytest.raises(M.MoFREAKError) as e:
+        gpu_ctx.extract_stream(fr, 7, W, H, grid, rows)
+    assert e.value.code == -7
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE config 3)
+def test_c3_full_resolution_pairs_bit_exact_and_chunk_independent(gpu_ctx, oracle):
+    """1920x1080, 8-px grid (29 106 keypoints/pair): bit-exact vs the oracle on every pair of a 12-pair batch
+    (spans two integral chunks), and a pair described alone gives the same bytes as inside the batch."""
+    c = synth.CONFIGS["C3"]
+    W, H = c["W"], c["H"]
+    n_pairs = 12
+    fr = synth.synth_stack(n_pairs + 5, W, H)
+    kps = synth.config_grid("C3")
+    assert len(kps) == 29106
+    cur, prev = fr[5:], fr[:n_pairs]
+    desc, valid = gpu_ctx.extract_pairs_host(cur, prev, kps)
+    assert valid.all()
+    want_d, want_v = oracle_pairs(oracle, cur, prev, kps)
+    assert np.array_equal(desc, want_d) and np.array_equal(valid, want_v)
+    d1, v1 = gpu_ctx.extract_pairs_host(cur[9:10], prev[9:10], kps)
+    assert np.array_equal(d1, desc[9 * len(kps):10 * len(kps)])
+    # idempotence: same call again, same bytes
+    d2, _ = gpu_ctx.extract_pairs_host(cur, prev, kps)
+    assert np.array_equal(d2, desc)
+
+
+def test_identical_frames_give_zero_motion_and_ff_appearance(gpu_ctx):
+    """cur == prev: the difference image is 0 -> every FREAK box mean is equal -> mode S bytes 0xFF (KAT 7),
+    theta 0; every MIP SSD is between a strip and shifted copies of the same frame."""
+    W, H = 640, 480
+    fr = np.full((1, H, W), 91, np.uint8)
+    kps = synth.config_grid("C2")
+    desc, valid = gpu_ctx.extract_pairs_host(fr, fr, kps)
+    assert valid.all() and (desc[:, :8] == 0xFF).all() and (desc[:, 8:] == 0).all()
