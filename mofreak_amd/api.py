@@ -66,6 +66,14 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise MoFREAKError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: run `python -m mofreak_amd.build` "
                            "(hipcc, gfx950).  There is no CPU fallback.")
+    # One HIP runtime per process: the torch wheel bundles its own libamdhip64.so.7 / libhsa-runtime64, and a
+    # process that loads /opt/rocm's copy first and torch's second ends up with two HSA runtimes, the second of
+    # which sees no GPU.  Importing torch first makes our NEEDED libamdhip64.so.7 bind to the copy torch loaded.
+    if os.environ.get("MOFREAK_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
     L.mofreak_abi_version.restype = i32

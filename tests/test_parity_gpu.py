@@ -70,8 +70,11 @@ def test_mip19_known_answers_on_gpu(gpu_ctx, oracle):
 def test_mip19_random_buffers(gpu_ctx, oracle):
     rng = np.random.default_rng(21)
     n = 3000
-    cur = rng.integers(0, 256, (n, 361), dtype=np.uint8)
-    prev = (cur.astype(np.int64) + rng.integers(-7, 8, (n, 361))).clip(0, 255).astype(np.uint8)
+    yy, xx = np.mgrid[0:19, 0:19]
+    gx, gy = rng.uniform(-3, 3, (2, n, 1, 1))  # per-buffer ramps: SSDs land on both sides of THETA
+    base = rng.integers(60, 200, (n, 1, 1)) + gx * xx + gy * yy
+    cur = (base + rng.integers(-2, 3, (n, 19, 19))).clip(0, 255).astype(np.uint8).reshape(n, 361)
+    prev = (base + rng.integers(-3, 4, (n, 19, 19))).clip(0, 255).astype(np.uint8).reshape(n, 361)
     prev[: n // 3] = np.roll(cur[: n // 3], 3, axis=1)
     got = gpu_ctx.mip19_host(cur, prev)
     want = np.array([[oracle.mip(cur[k], prev[k], x, y) for (x, y) in CENTERS] for k in range(n)], np.uint8)
