@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libmofreak_hip.so")
+# MOFREAK_HIP_LIBRARY points at another build of the same ABI (kernel experiments); default: the in-tree build
+LIB_PATH = os.environ.get("MOFREAK_HIP_LIBRARY") or os.path.join(PKG_DIR, "libmofreak_hip.so")
 
 OK = 0
 ERR_BAD_ARG, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_ROI, ERR_CAPACITY = -1, -2, -3, -4, -5, -6, -7

@@ -1,0 +1,349 @@
+// MoFREAKUtilities over the C ABI of libmofreak_hip.so.  See MoFREAKUtilities.h.
+// Reference lines cited are src/MoFREAK/MoFREAKUtilities.cpp of ChrisWhiten/MoFREAK.
+#include "MoFREAKUtilities.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+
+using std::cout;
+using std::endl;
+using std::string;
+
+namespace {
+
+// Gray frame stack in NumPy .npy format (v1/v2), dtype uint8, C order, shape (T, H, W).
+bool load_npy_u8_3d(const string &path, std::vector<uint8_t> &data, int &T, int &H, int &W)
+{
+    std::ifstream f(path.c_str(), std::ios::binary);
+    if (!f) return false;
+    char magic[8];
+    f.read(magic, 8);
+    if (!f || std::memcmp(magic, "\x93NUMPY", 6) != 0) return false;
+    size_t hlen = 0;
+    if (magic[6] == 1) {
+        unsigned char b[2];
+        f.read(reinterpret_cast<char *>(b), 2);
+        hlen = b[0] | (b[1] << 8);
+    } else {
+        unsigned char b[4];
+        f.read(reinterpret_cast<char *>(b), 4);
+        hlen = b[0] | (b[1] << 8) | (b[2] << 16) | ((size_t)b[3] << 24);
+    }
+    string header(hlen, '\0');
+    f.read(&header[0], (std::streamsize)hlen);
+    if (!f) return false;
+    if (header.find("'|u1'") == string::npos && header.find("'u1'") == string::npos && header.find("'<u1'") == string::npos)
+        return false;
+    if (header.find("'fortran_order': False") == string::npos) return false;
+    const size_t sp = header.find("'shape':");
+    if (sp == string::npos) return false;
+    const size_t lp = header.find('(', sp), rp = header.find(')', sp);
+    if (lp == string::npos || rp == string::npos) return false;
+    long dims[3] = {0, 0, 0};
+    int nd = 0;
+    std::stringstream ss(header.substr(lp + 1, rp - lp - 1));
+    string item;
+    while (std::getline(ss, item, ',')) {
+        std::stringstream is(item);
+        long v;
+        if (is >> v) {
+            if (nd >= 3) return false;
+            dims[nd++] = v;
+        }
+    }
+    if (nd != 3 || dims[0] < 0 || dims[1] <= 0 || dims[2] <= 0) return false;
+    T = (int)dims[0];
+    H = (int)dims[1];
+    W = (int)dims[2];
+    data.resize((size_t)T * H * W);
+    f.read(reinterpret_cast<char *>(data.data()), (std::streamsize)data.size());
+    return (size_t)f.gcount() == data.size();
+}
+
+string file_name_of(const string &path)
+{
+    const size_t p = path.find_last_of("/\\");
+    return p == string::npos ? path : path.substr(p + 1);
+}
+
+std::vector<string> split(const string &s, char delim)
+{
+    std::vector<string> out;
+    std::stringstream ss(s);
+    string item;
+    while (std::getline(ss, item, delim)) out.push_back(item);
+    return out;
+}
+
+const char *const kHmdbFolders[] = {  // enum HMDB_action order (MoSIFTUtilities.h:15-20)
+    "brush_hair", "cartwheel", "catch", "chew", "clap", "climb", "climb_stairs", "dive", "draw_sword", "dribble",
+    "drink", "eat", "fall_floor", "fencing", "flic_flac", "golf", "handstand", "hit", "hug", "jump", "kick",
+    "kick_ball", "kiss", "laugh", "pick", "pour", "pullup", "punch", "push", "pushup", "ride_bike", "ride_horse",
+    "run", "shake_hands", "shoot_ball", "shoot_bow", "shoot_gun", "sit", "situp", "smile", "smoke", "somersault",
+    "stand", "swing_baseball", "sword", "sword_exercise", "talk", "throw", "turn", "walk", "wave"};
+
+void check(mofreak_ctx *ctx, int rc, const char *what)
+{
+    if (rc == MOFREAK_OK) return;
+    std::ostringstream m;
+    m << what << " failed (" << rc << "): " << mofreak_last_error(ctx);
+    throw std::runtime_error(m.str());
+}
+
+}  // namespace
+
+MoFREAKUtilities::MoFREAKUtilities(int dset)
+    : current_action(0), dataset(dset), device_(0), ctx_(nullptr), provider_shared_(true)
+{
+    mofreak_default_params(&params_);
+    setDenseGrid(16, 12.0f, 38);
+}
+
+MoFREAKUtilities::~MoFREAKUtilities()
+{
+    if (ctx_) mofreak_destroy(ctx_);
+}
+
+void MoFREAKUtilities::setDevice(int device_id) { device_ = device_id; }
+void MoFREAKUtilities::setParams(const mofreak_params &p) { params_ = p; }
+
+void MoFREAKUtilities::setKeypointProvider(KeypointProvider provider, bool same_for_every_frame)
+{
+    provider_ = provider;
+    provider_shared_ = same_for_every_frame;
+}
+
+void MoFREAKUtilities::setDenseGrid(int step, float size, int lo)
+{
+    provider_ = [step, size, lo](int, int W, int H) {
+        std::vector<mofreak_keypoint> k;
+        for (int y = 0; y < H; y += step)
+            if (y > lo && y < H - lo)
+                for (int x = 0; x < W; x += step)
+                    if (x > lo && x < W - lo) k.push_back(mofreak_keypoint{(float)x, (float)y, size});
+        return k;
+    };
+    provider_shared_ = true;
+}
+
+mofreak_ctx *MoFREAKUtilities::context()
+{
+    if (!ctx_) {
+        mofreak_ctx *c = nullptr;
+        const int rc = mofreak_create(device_, &params_, &c);
+        if (rc != MOFREAK_OK) {
+            std::ostringstream m;
+            m << "mofreak_create failed (" << rc << "): " << mofreak_last_error(nullptr);
+            throw std::runtime_error(m.str());
+        }
+        ctx_ = c;
+    }
+    return ctx_;
+}
+
+// ---------------------------------------------------------------------------------------------- the hot path
+void MoFREAKUtilities::computeMoFREAKFromFile(std::string video_filename, std::string mofreak_filename,
+                                              bool clear_features_after_computation)
+{
+    std::vector<uint8_t> frames;
+    int T = 0, H = 0, W = 0;
+    if (!load_npy_u8_3d(video_filename, frames, T, H, W)) {
+        cout << "Could not open file: " << video_filename << endl;  // :383-386
+        return;  // the reference carries on and dies on the empty frame; nothing sensible to do here
+    }
+    computeMoFREAKFromFrames(frames.data(), T, W, H, video_filename);
+
+    // in the end, print the mofreak file and reset the features for a new file (:491-496)
+    cout << "Writing this mofreak file: " << mofreak_filename << endl;
+    writeMoFREAKFeaturesToFile(mofreak_filename);
+    if (clear_features_after_computation) features.clear();
+}
+
+void MoFREAKUtilities::computeMoFREAKFromFrames(const uint8_t *frames, int T, int W, int H,
+                                                const std::string &video_filename)
+{
+    const int gap = params_.gap_for_frame_difference;  // GAP_FOR_FRAME_DIFFERENCE (:378)
+    const int n_pairs = T - gap;
+    if (n_pairs <= 0) return;
+    mofreak_ctx *ctx = context();
+
+    // keypoints of every processed frame (frame index gap .. T-1), detector order
+    std::vector<mofreak_keypoint> kps;
+    std::vector<int64_t> offsets;
+    if (provider_shared_) {
+        kps = provider_(gap, W, H);
+    } else {
+        offsets.push_back(0);
+        for (int t = gap; t < T; ++t) {
+            const std::vector<mofreak_keypoint> k = provider_(t, W, H);
+            kps.insert(kps.end(), k.begin(), k.end());
+            offsets.push_back((int64_t)kps.size());
+        }
+    }
+    const int64_t capacity = provider_shared_ ? (int64_t)n_pairs * (int64_t)kps.size() : (int64_t)kps.size();
+    if (capacity == 0) return;
+    std::vector<mofreak_row> rows((size_t)capacity);
+    int64_t n_rows = 0;
+    check(ctx,
+          mofreak_extract_stream(ctx, frames, T, W, H, kps.data(), provider_shared_ ? nullptr : offsets.data(),
+                                 (int64_t)kps.size(), rows.data(), capacity, &n_rows, MOFREAK_MEM_HOST),
+          "mofreak_extract_stream");
+
+    int action = 0, person = 0, video_number = 0;
+    readMetadata(video_filename, action, video_number, person);  // the reference re-parses this per keypoint (:469)
+    for (int64_t i = 0; i < n_rows; ++i) {
+        const mofreak_row &r = rows[(size_t)i];
+        MoFREAKFeature ftr(NUMBER_OF_BYTES_FOR_MOTION, NUMBER_OF_BYTES_FOR_APPEARANCE);
+        ftr.frame_number = r.frame_number;
+        ftr.scale = r.scale;
+        ftr.x = r.x;
+        ftr.y = r.y;
+        for (int b = 0; b < NUMBER_OF_BYTES_FOR_APPEARANCE; ++b) ftr.appearance[b] = r.appearance[b];
+        for (int b = 0; b < NUMBER_OF_BYTES_FOR_MOTION; ++b) ftr.motion[b] = r.motion[b];
+        ftr.action = action;
+        ftr.video_number = video_number;
+        ftr.person = person;
+        ftr.motion_x = 0;  // :476-477
+        ftr.motion_y = 0;
+        features.push_back(ftr);
+    }
+}
+
+bool MoFREAKUtilities::buildMoFREAKFeature(const uint8_t *current_frame, const uint8_t *prev_frame, int W, int H,
+                                           float x, float y, float size, int frame_number, MoFREAKFeature &out)
+{
+    mofreak_ctx *ctx = context();
+    const mofreak_keypoint kp = {x, y, size};
+    uint8_t desc[MOFREAK_DESC_BYTES];
+    uint8_t valid = 0;
+    check(ctx,
+          mofreak_extract_pairs(ctx, current_frame, prev_frame, W, H, W, (int64_t)W * H, 1, &kp, nullptr, 1, desc, &valid,
+                                MOFREAK_MEM_HOST),
+          "mofreak_extract_pairs");
+    if (!valid) return false;
+    out = MoFREAKFeature(NUMBER_OF_BYTES_FOR_MOTION, NUMBER_OF_BYTES_FOR_APPEARANCE);
+    out.x = x;
+    out.y = y;
+    out.scale = size;
+    out.frame_number = frame_number;
+    for (int b = 0; b < 8; ++b) out.appearance[b] = desc[b];
+    for (int b = 0; b < 8; ++b) out.motion[b] = desc[8 + b];
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------- files
+void MoFREAKUtilities::writeMoFREAKFeaturesToFile(string output_file)
+{
+    // :691-719 verbatim in behaviour: default ostream formatting, one space after every value
+    std::ofstream f(output_file.c_str());
+    for (auto it = features.begin(); it != features.end(); ++it) {
+        f << it->x << " " << it->y << " " << it->frame_number << " " << it->scale << " " << it->motion_x << " "
+          << it->motion_y << " ";
+        for (int i = 0; i < NUMBER_OF_BYTES_FOR_APPEARANCE; ++i) f << it->appearance[i] << " ";
+        for (int i = 0; i < NUMBER_OF_BYTES_FOR_MOTION; ++i) {
+            int z = it->motion[i];
+            f << z << " ";
+        }
+        f << "\n";
+    }
+    f.close();
+}
+
+void MoFREAKUtilities::readMoFREAKFeatures(std::string filename, int num_to_sample)
+{
+    // :1136-1212
+    std::deque<MoFREAKFeature> new_features;
+    int action = 0, video_number = 0, person = 0;
+    readMetadata(filename, action, video_number, person);
+
+    std::ifstream stream;
+    stream.open(filename.c_str());
+    while (stream.good() && !stream.eof()) {
+        MoFREAKFeature ftr(NUMBER_OF_BYTES_FOR_MOTION, NUMBER_OF_BYTES_FOR_APPEARANCE);
+        stream >> ftr.x >> ftr.y >> ftr.frame_number >> ftr.scale >> ftr.motion_x >> ftr.motion_y;
+        if (stream.eof() || stream.fail()) break;  // trailing whitespace, not an actual feature point
+        for (unsigned i = 0; i < (unsigned)NUMBER_OF_BYTES_FOR_APPEARANCE; ++i) {
+            unsigned int a = 0;
+            stream >> a;
+            ftr.appearance[i] = a;
+        }
+        for (unsigned i = 0; i < (unsigned)NUMBER_OF_BYTES_FOR_MOTION; ++i) {
+            unsigned int a = 0;
+            stream >> a;
+            ftr.motion[i] = a;
+        }
+        ftr.action = action;
+        ftr.video_number = video_number;
+        ftr.person = person;
+        new_features.push_back(ftr);
+    }
+    stream.close();
+
+    if (num_to_sample && ((int)new_features.size() > num_to_sample)) {
+        std::random_shuffle(new_features.begin(), new_features.end());
+        for (int i = 0; i < num_to_sample; ++i) {
+            features.push_back(new_features.back());
+            new_features.pop_back();
+        }
+    } else {
+        while (!new_features.empty()) {  // reverse order, as the reference (:1206-1210)
+            features.push_back(new_features.back());
+            new_features.pop_back();
+        }
+    }
+}
+
+std::deque<MoFREAKFeature> MoFREAKUtilities::getMoFREAKFeatures() { return features; }
+
+void MoFREAKUtilities::setAllFeaturesToLabel(int label)
+{
+    for (unsigned i = 0; i < features.size(); ++i) features[i].action = label;
+}
+
+void MoFREAKUtilities::clearFeatures() { features.clear(); }
+
+// ---------------------------------------------------------------------------------------------- labels
+void MoFREAKUtilities::setCurrentAction(string folder_name)
+{
+    // :782-1060
+    if (dataset == HMDB51) {
+        for (int i = 0; i < (int)(sizeof(kHmdbFolders) / sizeof(kHmdbFolders[0])); ++i)
+            if (folder_name == kHmdbFolders[i]) {
+                current_action = i;
+                return;
+            }
+        // the reference prints, system("PAUSE")s and exit(1)s here (:1041-1047); a library must not
+        current_action = BRUSH_HAIR;
+        cout << "****Didn't find action" << endl;
+        throw std::runtime_error("MoFREAKUtilities::setCurrentAction: unknown HMDB51 folder '" + folder_name + "'");
+    } else if (dataset == UCF101) {
+        if (actions.find(folder_name) == actions.end()) {
+            const int id = (int)actions.size();  // (the reference's actions[f] = actions.size() is order-ambiguous)
+            actions[folder_name] = id;
+        }
+        current_action = actions[folder_name];
+    }
+}
+
+void MoFREAKUtilities::readMetadata(const std::string &filename, int &action, int &video_number, int &person)
+{
+    // :1062-1134 (the KTH branch is disabled upstream with `if (false)`)
+    const string file_name_str = file_name_of(filename);
+    if (dataset == HMDB51) {
+        video_number = 0;
+        person = 0;
+        action = current_action;
+    } else if (dataset == UTI2) {
+        const std::vector<string> parts = split(file_name_str, '_');
+        if (parts.size() >= 3) {
+            std::stringstream(parts[1]) >> person;
+            std::stringstream(parts[2].substr(0, 1)) >> action;
+            std::stringstream(parts[0]) >> video_number;
+        }
+    }
+}

@@ -1,0 +1,139 @@
+"""The C++ MoFREAKUtilities facade (mofreak_amd/host) -- the reference's class interface over the C ABI --
+driven through its small command-line driver, and the Python mirror (mofreak_amd.harness)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import mofreak_amd as M
+from mofreak_amd import harness, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "mofreak_amd", "host")
+EXE = os.path.join(HOST, "facade_main")
+
+
+@pytest.fixture(scope="module")
+def facade(native_lib):
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    return EXE
+
+
+def _random_rows(n, seed):
+    rng = np.random.default_rng(seed)
+    rows = np.zeros(n, M.ROW_DTYPE)
+    rows["x"] = rng.integers(0, 640, n) + rng.choice([0, 0.25, 0.5], n)
+    rows["y"] = rng.integers(0, 480, n)
+    rows["frame_number"] = np.sort(rng.integers(4, 90, n))
+    rows["scale"] = rng.choice(np.float32([12, 8.5, 14.25, 7]), n)
+    rows["appearance"] = rng.integers(0, 256, (n, 8))
+    rows["motion"] = rng.integers(0, 256, (n, 8))
+    return rows
+
+
+def test_cpp_reader_reverses_and_writer_matches_the_c_abi_formatter(facade, tmp_path):
+    """readMoFREAKFeatures pushes rows in reverse file order (reference :1206-1210); the facade's writer uses real
+    ostream << float like the reference, and must give the same bytes as mofreak_format_rows."""
+    rows = _random_rows(200, 1)
+    src, dst = tmp_path / "in.mofreak", tmp_path / "out.mofreak"
+    src.write_bytes(M.format_rows(rows))
+    out = subprocess.check_output([facade, "roundtrip", str(src), str(dst)], text=True)
+    assert "200 features" in out
+    assert dst.read_bytes() == M.format_rows(rows[::-1])
+
+
+def test_python_mirror_io_semantics(native_lib, tmp_path):
+    rows = _random_rows(50, 2)
+    p = tmp_path / "a.mofreak"
+    p.write_bytes(M.format_rows(rows))
+    mf = harness.MoFREAKUtilities.__new__(harness.MoFREAKUtilities)  # no GPU context needed for file I/O
+    from collections import deque
+    mf.features, mf.actions, mf.current_action = deque(), {}, 0
+    mf.readMoFREAKFeatures(str(p))
+    got = mf.getMoFREAKFeatures()
+    assert got.tobytes() == rows[::-1].tobytes()
+    mf.readMoFREAKFeatures(str(p), num_to_sample=10)
+    assert len(mf.getMoFREAKFeatures()) == 60
+    q = tmp_path / "b.mofreak"
+    mf.clearFeatures()
+    mf.readMoFREAKFeatures(str(p))
+    mf.writeMoFREAKFeaturesToFile(str(q))
+    assert q.read_bytes() == M.format_rows(rows[::-1])
+    mf.setCurrentAction("walk")
+    mf.setCurrentAction("run")
+    mf.setCurrentAction("walk")
+    assert mf.current_action == 0 and mf.actions == {"walk": 0, "run": 1}
+
+
+@pytest.mark.gpu
+def test_cpp_facade_extracts_a_clip_like_the_reference(facade, oracle, tmp_path):
+    """BASELINE config 1 shape: one 320x240 clip, DETECT_MOFREAK: .mofreak text identical to the oracle's."""
+    c = synth.CONFIGS["C1"]
+    T = 30
+    fr = synth.synth_stack(T, c["W"], c["H"])
+    vid, out = tmp_path / "person01_boxing_d1.npy", tmp_path / "clip.mofreak"
+    np.save(vid, fr)
+    msg = subprocess.check_output([facade, "extract", str(vid), str(out), str(c["step"]), str(c["size"]), str(c["lo"])], text=True)
+    grid = synth.config_grid("C1")
+    assert len(grid) == 204
+    offs = np.arange(T - 5 + 1, dtype=np.int64) * len(grid)
+    want = oracle.Freak().extract_stream(fr, np.tile(grid, (T - 5, 1)), offs)
+    assert f"{len(want)} features" in msg and len(want) == (T - 5) * 204
+    assert out.read_bytes() == oracle.format_rows(want)
+
+
+@pytest.mark.gpu
+def test_cpp_compute_mofreak_files_layout(facade, oracle, tmp_path):
+    """computeMoFREAKFiles (reference main.cpp:854-924): <video> -> <MOFREAK_PATH>[/<action>]/<video>.mofreak"""
+    vdir, mdir = tmp_path / "videos", tmp_path / "mofreak"
+    (vdir / "walk").mkdir(parents=True)
+    (vdir / "run").mkdir()
+    mdir.mkdir()
+    clips = {"top.npy": synth.synth_stack(8, 160, 120, t0=1), "walk/w1.npy": synth.synth_stack(7, 160, 120, t0=20),
+             "run/r1.npy": synth.synth_stack(9, 160, 120, t0=50), "run/short.npy": synth.synth_stack(4, 160, 120, t0=70)}
+    for name, fr in clips.items():
+        np.save(vdir / name, fr)
+    subprocess.check_call([facade, "files", str(vdir), str(mdir)])
+    grid = synth.dense_grid(160, 120, 16, 7.0, 23)
+    for name, fr in clips.items():
+        out = mdir / (name + ".mofreak")
+        assert out.exists(), name
+        n_pairs = max(len(fr) - 5, 0)
+        offs = np.arange(n_pairs + 1, dtype=np.int64) * len(grid)
+        want = oracle.Freak().extract_stream(fr, np.tile(grid, (n_pairs, 1)), offs)
+        assert out.read_bytes() == oracle.format_rows(want), name
+    assert (mdir / "run" / "short.npy.mofreak").read_bytes() == b""  # T <= gap: the reference writes an empty file
+
+
+@pytest.mark.gpu
+def test_python_mirror_extracts_and_shards(native_lib, oracle, tmp_path):
+    vdir = tmp_path / "v"
+    vdir.mkdir()
+    paths = []
+    for i, T in enumerate([12, 7, 9, 6]):
+        p = vdir / f"clip{i}.npy"
+        np.save(p, synth.synth_stack(T, 160, 120, t0=10 * i))
+        paths.append(str(p))
+    prov = harness.dense_grid_provider(16, 7.0, 23)
+    mf = harness.MoFREAKUtilities(harness.KTH, device=0, keypoint_provider=prov)
+    done = []
+    for rank in range(2):  # two logical ranks on one device: together they cover every video exactly once
+        done += harness.compute_mofreak_files(paths, str(tmp_path / "out"), mf, rank=rank, world_size=2,
+                                              costs=[12, 7, 9, 6])
+    assert sorted(os.path.basename(d) for d in done) == [f"clip{i}.npy.mofreak" for i in range(4)]
+    grid = synth.dense_grid(160, 120, 16, 7.0, 23)
+    for i, p in enumerate(paths):
+        fr = np.load(p)
+        n_pairs = len(fr) - 5
+        want = oracle.Freak().extract_stream(fr, np.tile(grid, (n_pairs, 1)), np.arange(n_pairs + 1, dtype=np.int64) * len(grid))
+        assert open(os.path.join(tmp_path, "out", f"clip{i}.npy.mofreak"), "rb").read() == oracle.format_rows(want)
+    # append semantics: without clearing, the second file also carries the first video's rows (reference :479, :493-496)
+    a, b = str(tmp_path / "a.mofreak"), str(tmp_path / "b.mofreak")
+    mf.computeMoFREAKFromFile(paths[1], a, False)
+    mf.computeMoFREAKFromFile(paths[3], b, True)
+    assert open(b, "rb").read().startswith(open(a, "rb").read()) and len(open(b, "rb").read()) > len(open(a, "rb").read())
+    one = mf.buildMoFREAKFeature(np.load(paths[0])[5], np.load(paths[0])[0], 80, 64, 7.0)
+    d, v = oracle.Freak().extract_pair(np.load(paths[0])[5], np.load(paths[0])[0], np.float32([[80, 64, 7.0]]))
+    assert v[0] == 1 and np.array_equal(one[0], d[0, :8]) and np.array_equal(one[1], d[0, 8:])
+    mf.close()

@@ -1,0 +1,58 @@
+"""Committed golden vectors (tests/golden/, made by make_golden.py from the oracle): the oracle must still
+reproduce them on CPU, and the HIP path must reproduce them on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+import mofreak_amd as M
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MODES = [("sse", 0), ("natural", 1), ("sse_signed", 2)]
+
+
+def test_oracle_reproduces_golden_pair(oracle):
+    g = np.load(os.path.join(GOLD, "golden_pair.npz"))
+    for name, mode in MODES:
+        d, v = oracle.Freak(bit_mode=mode).extract_pair(g["cur"], g["prev"], g["kps"])
+        assert np.array_equal(v, g[f"valid_{name}"]) and np.array_equal(d, g[f"desc_{name}"])
+    # the layouts really differ, and only in the appearance half
+    assert not np.array_equal(g["desc_sse"][:, :8], g["desc_natural"][:, :8])
+    assert np.array_equal(g["desc_sse"][:, 8:], g["desc_natural"][:, 8:])
+
+
+def test_oracle_reproduces_golden_stream(oracle):
+    g = np.load(os.path.join(GOLD, "golden_stream.npz"))
+    rows = oracle.Freak().extract_stream(g["frames"], g["kps"], g["kp_offsets"])
+    assert rows.view(np.uint8).reshape(-1, 32).tobytes() == g["rows"].tobytes()
+    assert oracle.format_rows(rows) == g["text"].tobytes()
+
+
+def test_golden_text_round_trips_through_the_product_parser(native_lib):
+    g = np.load(os.path.join(GOLD, "golden_stream.npz"))
+    rows = g["rows"].copy().view(M.ROW_DTYPE).reshape(-1)
+    text = g["text"].tobytes()
+    assert M.format_rows(rows) == text                      # the product writer = the golden text
+    back = M.parse_rows(text)
+    assert len(back) == len(rows)
+    assert np.array_equal(back["appearance"], rows["appearance"]) and np.array_equal(back["motion"], rows["motion"])
+    assert np.array_equal(back["frame_number"], rows["frame_number"])
+    assert np.array_equal(back["x"], rows["x"]) and np.array_equal(back["scale"], rows["scale"])  # quarter-pixel values survive %g
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden_pair(native_lib):
+    g = np.load(os.path.join(GOLD, "golden_pair.npz"))
+    for name, mode in MODES:
+        with M.Context(0, freak_bit_mode=mode) as ctx:
+            d, v = ctx.extract_pairs_host(g["cur"], g["prev"], g["kps"])
+        assert np.array_equal(v, g[f"valid_{name}"]), name
+        assert np.array_equal(d, g[f"desc_{name}"]), name
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden_stream(gpu_ctx):
+    g = np.load(os.path.join(GOLD, "golden_stream.npz"))
+    rows = gpu_ctx.extract_stream_host(g["frames"], g["kps"], kp_offsets=g["kp_offsets"])
+    assert rows.view(np.uint8).reshape(-1, 32).tobytes() == g["rows"].tobytes()
+    assert M.format_rows(rows) == g["text"].tobytes()

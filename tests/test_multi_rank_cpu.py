@@ -1,0 +1,79 @@
+"""The N > 1 path on CPU: video sharding and the final row gather with world_size-2 (and 3) gloo groups.
+
+The data path has no collective (videos are independent); the only exchange is gather_rows, which is the
+same code for gloo on CPU tensors and RCCL on device tensors."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mofreak_amd import api, harness
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rows_for_rank(rank: int, n: int) -> np.ndarray:
+    rng = np.random.default_rng(1000 + rank)
+    rows = np.zeros(n, api.ROW_DTYPE)
+    rows["x"] = rng.integers(0, 1920, n)
+    rows["y"] = rng.integers(0, 1080, n)
+    rows["frame_number"] = np.sort(rng.integers(4, 400, n))
+    rows["scale"] = 12.0
+    rows["appearance"] = rng.integers(0, 256, (n, 8))
+    rows["motion"] = rng.integers(0, 256, (n, 8))
+    return rows
+
+
+def _worker(rank, world, port, counts, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rows = _rows_for_rank(rank, counts[rank])
+        buf = torch.zeros((counts[rank] + 5) * 32, dtype=torch.uint8)  # capacity > count, like the device buffers
+        buf[: counts[rank] * 32] = torch.from_numpy(rows.view(np.uint8).reshape(-1).copy())
+        got, cnts = harness.gather_rows(buf, counts[rank], dst=0)
+        assert cnts == list(counts)
+        if rank == 0:
+            np.save(os.path.join(outdir, "gathered.npy"), got.numpy())
+        else:
+            assert got is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("counts", [(300, 45), (0, 17), (64, 0), (5, 0, 9)])
+def test_gather_rows_equals_rank_order_concatenation(tmp_path, counts):
+    world = len(counts)
+    mp.spawn(_worker, args=(world, _free_port(), counts, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(os.path.join(tmp_path, "gathered.npy"))
+    want = np.concatenate([_rows_for_rank(r, counts[r]) for r in range(world)])
+    assert got.tobytes() == want.view(np.uint8).tobytes()
+    # rank 0 formats text in (rank, frame, keypoint) order: identical to formatting the concatenation
+    assert api.format_rows(got.view(api.ROW_DTYPE).reshape(-1)) == b"".join(
+        api.format_rows(_rows_for_rank(r, counts[r])) for r in range(world))
+
+
+def test_shard_videos_lpt():
+    rng = np.random.default_rng(0)
+    # HMDB51-shaped clip lengths: log-normal, median 80, clamped to [20, 650]
+    lengths = np.clip(np.exp(rng.normal(np.log(80), 0.6, 6766)), 20, 650).astype(int)
+    for world in (1, 2, 4, 8):
+        shards = harness.shard_videos(lengths, world)
+        allidx = sorted(i for s in shards for i in s)
+        assert allidx == list(range(len(lengths)))           # a partition: every video exactly once
+        loads = [int(lengths[s].sum()) for s in shards]
+        assert max(loads) - min(loads) <= lengths.max()       # LPT balance
+        assert shards == harness.shard_videos(lengths, world)  # deterministic
+    assert harness.shard_videos([5, 1], 4) == [[0], [1], [], []]
+    assert harness.shard_videos([], 2) == [[], []]
