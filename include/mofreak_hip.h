@@ -105,14 +105,22 @@ int mofreak_reserve(mofreak_ctx *ctx, int W, int H, int chunk_pairs);
  * MOFREAK_ERR_ROI / MOFREAK_ERR_UNSUPPORTED, else MOFREAK_OK.  Affected keypoints have out_valid = 0. */
 int mofreak_check_status(mofreak_ctx *ctx);
 
-/* Per-launch device timing, measured with HIP events on the context's stream around (a) the absdiff+integral
- * kernel group and (b) the describe kernel of every chunk.  Off by default. */
+/* Which kernels describe the keypoints.  AUTO: the fused tile kernel for every keypoint whose FREAK pattern fits a
+ * tile's 48-px halo (size < ~14.9), the gather path (global integral + one wavefront per keypoint) for the rest.
+ * GATHER: the gather path for everything (the round-1 v1 kernels; kept for large keypoints and for A/B tests). */
+#define MOFREAK_PATH_AUTO 0
+#define MOFREAK_PATH_GATHER 1
+int mofreak_set_path(mofreak_ctx *ctx, int path);
+
+/* Per-call device timing, measured with HIP events on the context's stream around the binning kernels, the tile
+ * kernel and the gather path of every extract call.  Off by default. */
 typedef struct mofreak_profile {
-    double integral_ms;  /* sum over chunks: band_kernel<A> + band_scan + band_kernel<C> */
-    double describe_ms;  /* sum over chunks: describe_kernel */
-    int64_t launches;    /* chunks timed (= describe_kernel launches) */
-    int64_t pairs;       /* frame pairs those launches covered */
-    int64_t descriptors; /* keypoint instances those launches covered */
+    double bin_ms;       /* keypoint binning (bin_count / bin_scan / bin_scatter) */
+    double tile_ms;      /* tile_kernel: the fused kernel that describes everything that fits a tile's halo */
+    double gather_ms;    /* gather path: integral kernels + describe_kernel (large keypoints; ~0 when there are none) */
+    int64_t calls;       /* extract calls timed; each launches tile_kernel once (per 32768 pairs) */
+    int64_t pairs;       /* frame pairs those calls covered */
+    int64_t descriptors; /* keypoint instances those calls covered */
 } mofreak_profile;
 int mofreak_set_profiling(mofreak_ctx *ctx, int enable);
 /* Synchronises, folds the recorded events into the running totals and returns them (reset != 0 clears them). */

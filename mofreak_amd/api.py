@@ -20,6 +20,7 @@ ERR_BAD_ARG, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_ROI, ERR_CAPA
 MEM_DEVICE, MEM_HOST = 0, 1
 BITS_SSE, BITS_NATURAL, BITS_SSE_SIGNED = 0, 1, 2
 TABLES_ONLY = -1
+PATH_AUTO, PATH_GATHER = 0, 1
 
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4")])
 ROW_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("frame_number", "<i4"), ("scale", "<f4"),
@@ -30,7 +31,7 @@ assert ROW_DTYPE.itemsize == 32
 EXPORTS = [
     "mofreak_abi_version", "mofreak_default_params", "mofreak_create", "mofreak_destroy", "mofreak_last_error",
     "mofreak_set_stream", "mofreak_synchronize", "mofreak_reserve", "mofreak_check_status",
-    "mofreak_set_profiling", "mofreak_get_profile",
+    "mofreak_set_profiling", "mofreak_get_profile", "mofreak_set_path",
     "mofreak_extract_pairs", "mofreak_compact_rows", "mofreak_extract_stream", "mofreak_format_rows",
     "mofreak_parse_rows", "mofreak_diff_integral", "mofreak_mip19", "mofreak_roi19", "mofreak_freak_info",
     "mofreak_theta_index", "mofreak_pattern_sizes", "mofreak_scale_index", "mofreak_table_pattern",
@@ -46,7 +47,7 @@ class Params(C.Structure):
 
 
 class Profile(C.Structure):
-    _fields_ = [("integral_ms", C.c_double), ("describe_ms", C.c_double), ("launches", C.c_int64),
+    _fields_ = [("bin_ms", C.c_double), ("tile_ms", C.c_double), ("gather_ms", C.c_double), ("calls", C.c_int64),
                 ("pairs", C.c_int64), ("descriptors", C.c_int64)]
 
 
@@ -89,6 +90,7 @@ def load() -> C.CDLL:
     L.mofreak_reserve.argtypes = [vp, i32, i32, i32]
     L.mofreak_check_status.argtypes = [vp]
     L.mofreak_set_profiling.argtypes = [vp, i32]
+    L.mofreak_set_path.argtypes = [vp, i32]
     L.mofreak_get_profile.argtypes = [vp, C.POINTER(Profile), i32]
     L.mofreak_extract_pairs.argtypes = [vp, vp, vp, i32, i32, i64, i64, i32, vp, vp, i64, vp, vp, C.c_uint]
     L.mofreak_compact_rows.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, i64, C.POINTER(i64), C.c_uint]
@@ -206,6 +208,10 @@ class Context:
 
     def check_status(self):
         self._check(self._lib.mofreak_check_status(self._h))
+
+    def set_path(self, path: int):
+        """PATH_AUTO (tile kernel + gather path for large keypoints) or PATH_GATHER (gather path for everything)."""
+        self._check(self._lib.mofreak_set_path(self._h, path))
 
     def set_profiling(self, enable: bool):
         self._check(self._lib.mofreak_set_profiling(self._h, int(enable)))

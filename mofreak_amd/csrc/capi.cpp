@@ -36,11 +36,15 @@ struct mofreak_ctx {
     int32_t *d_status = nullptr;
     // workspace (grown on demand, never shrunk)
     DeviceBuffer integral, band_totals, scratch_desc, scratch_valid, compact_offsets, stage[6], offsets_dev;
+    DeviceBuffer kp_key, sorted_idx, slow_list, tile_start, tile_cursor, slow_count;  // keypoint binning
+    MipSample *d_mip_samples = nullptr;
+    uint16_t *d_mip_pos = nullptr;
+    int path_mode = MOFREAK_PATH_AUTO;
     int chunk_pairs_hint = 0;
     // optional per-launch timing (mofreak_set_profiling): events around the integral group and the describe launch
     bool profiling = false;
     struct Span {
-        hipEvent_t e0, e1, e2;
+        hipEvent_t ev[4];
         int64_t pairs, items;
     };
     std::vector<Span> spans;
@@ -129,7 +133,8 @@ int validate_frames(const mofreak_ctx *ctx, const void *cur, const void *prev, i
 }
 
 // integral images of pairs [p0, p0+np) into ctx->integral
-int run_integral(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, const Geometry &g, int p0, int np)
+int run_integral(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, const Geometry &g, int p0, int np,
+                 const int32_t *gate = nullptr)
 {
     const int pitch = integral_pitch(g.W);
     const int n_bands = (g.H + kBandRows - 1) / kBandRows;
@@ -138,6 +143,7 @@ int run_integral(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, cons
     rc = ensure(ctx, ctx->band_totals, (size_t)np * n_bands * pitch * sizeof(int32_t));
     if (rc) return rc;
     IntegralArgs a;
+    a.gate = gate;
     a.f.cur = cur + (int64_t)p0 * g.pair_stride;
     a.f.prev = prev + (int64_t)p0 * g.pair_stride;
     a.f.W = g.W;
@@ -154,13 +160,35 @@ int run_integral(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, cons
     return MOFREAK_OK;
 }
 
-// The device-pointer implementation behind mofreak_extract_pairs and the component entry points.
-int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, const Geometry &g, int n_pairs,
-                   const mofreak_keypoint *kps, const int64_t *d_offsets, const int64_t *h_offsets, int64_t n_kp,
-                   uint8_t *out_desc, uint8_t *out_valid, int32_t *out_info, uint8_t *out_roi19)
+// Events for mofreak_set_profiling: [0] start, [1] after binning, [2] after the tile kernel, [3] after the gather path.
+int span_begin(mofreak_ctx *ctx, mofreak_ctx::Span &span)
 {
-    if (n_pairs == 0 || n_kp == 0) return MOFREAK_OK;
-    const int chunk = choose_chunk(ctx, g.W, g.H, n_pairs);
+    for (auto &e : span.ev) {
+        if (!ctx->event_pool.empty()) {
+            e = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+        } else {
+            HIP_TRY(ctx, hipEventCreate(&e));
+        }
+    }
+    HIP_TRY(ctx, hipEventRecord(span.ev[0], ctx->stream));
+    return MOFREAK_OK;
+}
+
+// Gather path ("v1"): global integral of a chunk of pairs + one wavefront per keypoint instance.
+// With slow_mode the instance list is the binning pass's slow list and all kernels are gated on its count.
+int run_gather(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, const Geometry &g, int n_pairs,
+               const mofreak_keypoint *kps, const int64_t *d_offsets, const int64_t *h_offsets, int64_t n_kp,
+               uint8_t *out_desc, uint8_t *out_valid, int32_t *out_info, uint8_t *out_roi19, bool slow_mode)
+{
+    const size_t per_pair = (size_t)(g.H + 1) * integral_pitch(g.W) * sizeof(int32_t);
+    int chunk;
+    if (slow_mode)  // usually nothing to do here: few big chunks keep the number of (gated, empty) launches small
+        chunk = (int)std::max<size_t>(1, ((size_t)1 << 30) / per_pair);
+    else
+        chunk = choose_chunk(ctx, g.W, g.H, n_pairs);
+    chunk = std::max(1, std::min(chunk, n_pairs));
+    const int32_t *gate = slow_mode ? static_cast<const int32_t *>(ctx->slow_count.ptr) : nullptr;
     for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
         const int np = std::min(chunk, n_pairs - p0);
         int64_t item_base, n_items;
@@ -172,24 +200,8 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
             n_items = (int64_t)np * n_kp;
         }
         if (n_items == 0) continue;
-        mofreak_ctx::Span span{};
-        if (ctx->profiling) {
-            hipEvent_t *ev[3] = {&span.e0, &span.e1, &span.e2};
-            for (auto *e : ev) {
-                if (!ctx->event_pool.empty()) {
-                    *e = ctx->event_pool.back();
-                    ctx->event_pool.pop_back();
-                } else {
-                    HIP_TRY(ctx, hipEventCreate(e));
-                }
-            }
-            span.pairs = np;
-            span.items = n_items;
-            HIP_TRY(ctx, hipEventRecord(span.e0, ctx->stream));
-        }
-        int rc = run_integral(ctx, cur, prev, g, p0, np);
+        int rc = run_integral(ctx, cur, prev, g, p0, np, gate);
         if (rc) return rc;
-        if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(span.e1, ctx->stream));
         DescribeArgs a;
         a.f.cur = cur + (int64_t)p0 * g.pair_stride;
         a.f.prev = prev + (int64_t)p0 * g.pair_stride;
@@ -214,14 +226,114 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
         a.out_info = out_info;
         a.out_roi19 = out_roi19;
         a.status = ctx->d_status;
+        a.slow_list = slow_mode ? static_cast<const int32_t *>(ctx->slow_list.ptr) : nullptr;
+        a.slow_count = gate;
+        a.n_pairs_total = n_pairs;
         const int64_t want = (n_items + 3) / 4;
         const int n_blocks = (int)std::min<int64_t>(want, (int64_t)ctx->n_cus * 8);
         const int e = launch_describe(a, n_blocks, ctx->stream);
         if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("describe launch: ") + hipGetErrorString((hipError_t)e));
+    }
+    return MOFREAK_OK;
+}
+
+// The device-pointer implementation behind mofreak_extract_pairs and the component entry points:
+// bin the keypoints by image tile, describe them with the fused tile kernel, and leave what does not fit a tile's
+// halo (large keypoints) to the gather path.
+int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, const Geometry &g, int n_pairs,
+                   const mofreak_keypoint *kps, const int64_t *d_offsets, const int64_t *h_offsets, int64_t n_kp,
+                   uint8_t *out_desc, uint8_t *out_valid, int32_t *out_info, uint8_t *out_roi19)
+{
+    if (n_pairs == 0 || n_kp == 0) return MOFREAK_OK;
+    if (n_kp >= ((int64_t)1 << 31)) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "more than 2^31 keypoints in one call");
+    const int64_t n_items = h_offsets ? n_kp : (int64_t)n_pairs * n_kp;
+    mofreak_ctx::Span span{};
+    int rc;
+    if (ctx->profiling && (rc = span_begin(ctx, span))) return rc;
+    span.pairs = n_pairs;
+    span.items = n_items;
+
+    const bool gather_only = ctx->path_mode == MOFREAK_PATH_GATHER || out_roi19 != nullptr;
+    if (gather_only) {
         if (ctx->profiling) {
-            HIP_TRY(ctx, hipEventRecord(span.e2, ctx->stream));
-            ctx->spans.push_back(span);
+            HIP_TRY(ctx, hipEventRecord(span.ev[1], ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(span.ev[2], ctx->stream));
         }
+        rc = run_gather(ctx, cur, prev, g, n_pairs, kps, d_offsets, h_offsets, n_kp, out_desc, out_valid, out_info, out_roi19, false);
+        if (rc) return rc;
+    } else {
+        const int tiles_x = (g.W + kTileW - 1) / kTileW, tiles_y = (g.H + kTileH - 1) / kTileH;
+        const int64_t n_keys = (int64_t)tiles_x * tiles_y * (d_offsets ? n_pairs : 1);
+        if (n_keys >= ((int64_t)1 << 31)) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "too many (pair, tile) bins in one call");
+        if ((rc = ensure(ctx, ctx->kp_key, (size_t)n_kp * 4))) return rc;
+        if ((rc = ensure(ctx, ctx->sorted_idx, (size_t)n_kp * sizeof(SortedKp)))) return rc;
+        if ((rc = ensure(ctx, ctx->slow_list, (size_t)n_kp * 4))) return rc;
+        if ((rc = ensure(ctx, ctx->tile_start, (size_t)(n_keys + 1) * 4))) return rc;
+        if ((rc = ensure(ctx, ctx->tile_cursor, (size_t)n_keys * 4))) return rc;
+        if ((rc = ensure(ctx, ctx->slow_count, 256))) return rc;
+        BinArgs b;
+        b.kps = kps;
+        b.kp_offsets = d_offsets;
+        b.n_kp = n_kp;
+        b.n_pairs = n_pairs;
+        b.W = g.W;
+        b.H = g.H;
+        b.tiles_x = tiles_x;
+        b.tiles_y = tiles_y;
+        b.force_slow = 0;
+        b.small = ctx->d_small;
+        b.kp_key = static_cast<int32_t *>(ctx->kp_key.ptr);
+        b.tile_start = static_cast<int32_t *>(ctx->tile_start.ptr);
+        b.tile_cursor = static_cast<int32_t *>(ctx->tile_cursor.ptr);
+        b.sorted_kp = static_cast<SortedKp *>(ctx->sorted_idx.ptr);
+        b.slow_list = static_cast<int32_t *>(ctx->slow_list.ptr);
+        b.slow_count = static_cast<int32_t *>(ctx->slow_count.ptr);
+        b.out_desc = out_desc;
+        b.out_valid = out_valid;
+        b.out_info = out_info;
+        b.n_keys = n_keys;
+        int e = launch_bin(b, ctx->stream);
+        if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("binning launch: ") + hipGetErrorString((hipError_t)e));
+        if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(span.ev[1], ctx->stream));
+
+        const int kMaxGridY = 32768;
+        for (int p0 = 0; p0 < n_pairs; p0 += kMaxGridY) {
+            const int np = std::min(kMaxGridY, n_pairs - p0);
+            TileArgs t;
+            t.f.cur = cur + (int64_t)p0 * g.pair_stride;
+            t.f.prev = prev + (int64_t)p0 * g.pair_stride;
+            t.f.W = g.W;
+            t.f.H = g.H;
+            t.f.row_stride = g.row_stride;
+            t.f.pair_stride = g.pair_stride;
+            t.n_pairs = np;
+            t.tiles_x = tiles_x;
+            t.tiles_y = tiles_y;
+            t.lut = ctx->d_lut;
+            t.small = ctx->d_small;
+            t.mip_samples = ctx->d_mip_samples;
+            t.mip_pos = ctx->d_mip_pos;
+            t.mip_n_cur = ctx->tables.mip_n_cur;
+            t.mip_n = ctx->tables.mip_n;
+            t.mip_stride = ctx->tables.mip_stride;
+            t.kp_offsets = d_offsets;
+            t.n_kp = n_kp;
+            // CSR: bins are per (pair, tile); shared list: per tile, outputs offset by the pair
+            t.tile_start = static_cast<const int32_t *>(ctx->tile_start.ptr) + (d_offsets ? (int64_t)p0 * tiles_x * tiles_y : 0);
+            t.sorted_kp = static_cast<const SortedKp *>(ctx->sorted_idx.ptr);
+            t.out_desc = d_offsets ? out_desc : out_desc + (int64_t)p0 * n_kp * 16;
+            t.out_valid = d_offsets ? out_valid : out_valid + (int64_t)p0 * n_kp;
+            t.out_info = out_info ? (d_offsets ? out_info : out_info + (int64_t)p0 * n_kp * 4) : nullptr;
+            e = launch_tile(t, ctx->stream);
+            if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("tile kernel launch: ") + hipGetErrorString((hipError_t)e));
+        }
+        if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(span.ev[2], ctx->stream));
+        rc = run_gather(ctx, cur, prev, g, n_pairs, kps, d_offsets, h_offsets, n_kp, out_desc, out_valid, out_info, nullptr, true);
+        if (rc) return rc;
+    }
+    if (ctx->profiling) {
+        HIP_TRY(ctx, hipEventRecord(span.ev[3], ctx->stream));
+        ctx->spans.push_back(span);
     }
     return MOFREAK_OK;
 }
@@ -381,6 +493,10 @@ int mofreak_create(int device_id, const mofreak_params *params, mofreak_ctx **ou
     CREATE_TRY(hipMalloc((void **)&ctx->d_resize, t.resize.size() * sizeof(ResizeTap)));
     CREATE_TRY(hipMalloc((void **)&ctx->d_small, sizeof(SmallTables)));
     CREATE_TRY(hipMalloc((void **)&ctx->d_status, sizeof(int32_t)));
+    CREATE_TRY(hipMalloc((void **)&ctx->d_mip_samples, t.mip_samples.size() * sizeof(MipSample)));
+    CREATE_TRY(hipMalloc((void **)&ctx->d_mip_pos, t.mip_pos.size() * sizeof(uint16_t)));
+    CREATE_TRY(hipMemcpy(ctx->d_mip_samples, t.mip_samples.data(), t.mip_samples.size() * sizeof(MipSample), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(ctx->d_mip_pos, t.mip_pos.data(), t.mip_pos.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     SmallTables st;
     std::memset(&st, 0, sizeof(st));
     std::memcpy(st.pattern_sizes, t.pattern_sizes, sizeof(st.pattern_sizes));
@@ -415,6 +531,14 @@ void mofreak_destroy(mofreak_ctx *ctx)
     if (ctx->d_resize) (void)hipFree(ctx->d_resize);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->d_mip_samples) (void)hipFree(ctx->d_mip_samples);
+    if (ctx->d_mip_pos) (void)hipFree(ctx->d_mip_pos);
+    release(ctx->kp_key);
+    release(ctx->sorted_idx);
+    release(ctx->slow_list);
+    release(ctx->tile_start);
+    release(ctx->tile_cursor);
+    release(ctx->slow_count);
     release(ctx->integral);
     release(ctx->band_totals);
     release(ctx->scratch_desc);
@@ -422,11 +546,8 @@ void mofreak_destroy(mofreak_ctx *ctx)
     release(ctx->compact_offsets);
     release(ctx->offsets_dev);
     for (auto &s : ctx->stage) release(s);
-    for (auto &sp : ctx->spans) {
-        (void)hipEventDestroy(sp.e0);
-        (void)hipEventDestroy(sp.e1);
-        (void)hipEventDestroy(sp.e2);
-    }
+    for (auto &sp : ctx->spans)
+        for (auto e : sp.ev) (void)hipEventDestroy(e);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -471,6 +592,14 @@ int mofreak_reserve(mofreak_ctx *ctx, int W, int H, int chunk_pairs)
     return ensure(ctx, ctx->band_totals, (size_t)chunk * n_bands * pitch * sizeof(int32_t));
 }
 
+int mofreak_set_path(mofreak_ctx *ctx, int path)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    if (path != MOFREAK_PATH_AUTO && path != MOFREAK_PATH_GATHER) return fail(ctx, MOFREAK_ERR_BAD_ARG, "unknown path");
+    ctx->path_mode = path;
+    return MOFREAK_OK;
+}
+
 int mofreak_set_profiling(mofreak_ctx *ctx, int enable)
 {
     if (!ctx) return MOFREAK_ERR_BAD_ARG;
@@ -485,17 +614,17 @@ int mofreak_get_profile(mofreak_ctx *ctx, mofreak_profile *out, int reset)
     NEED_DEVICE(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (auto &sp : ctx->spans) {
-        float a = 0, b = 0;
-        HIP_TRY(ctx, hipEventElapsedTime(&a, sp.e0, sp.e1));
-        HIP_TRY(ctx, hipEventElapsedTime(&b, sp.e1, sp.e2));
-        ctx->prof.integral_ms += a;
-        ctx->prof.describe_ms += b;
-        ctx->prof.launches += 1;
+        float a = 0, b = 0, c = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&a, sp.ev[0], sp.ev[1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&b, sp.ev[1], sp.ev[2]));
+        HIP_TRY(ctx, hipEventElapsedTime(&c, sp.ev[2], sp.ev[3]));
+        ctx->prof.bin_ms += a;
+        ctx->prof.tile_ms += b;
+        ctx->prof.gather_ms += c;
+        ctx->prof.calls += 1;
         ctx->prof.pairs += sp.pairs;
         ctx->prof.descriptors += sp.items;
-        ctx->event_pool.push_back(sp.e0);
-        ctx->event_pool.push_back(sp.e1);
-        ctx->event_pool.push_back(sp.e2);
+        for (auto e : sp.ev) ctx->event_pool.push_back(e);
     }
     ctx->spans.clear();
     *out = ctx->prof;

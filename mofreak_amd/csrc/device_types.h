@@ -38,6 +38,7 @@ struct FrameArgs {
 };
 
 struct IntegralArgs {
+    const int32_t *gate;  // optional device word: the kernels return at once when *gate == 0 (no slow keypoints)
     FrameArgs f;          // cur/prev already point at the first pair of the chunk
     int32_t *integral;    // [n_pairs][H+1][pitch]
     int32_t *band_totals; // [n_pairs][n_bands][pitch]
@@ -65,6 +66,58 @@ struct DescribeArgs {
     int32_t *out_info;         // optional: 4 x int32 per instance
     uint8_t *out_roi19;        // optional: 722 bytes per instance
     int32_t *status;           // device status word (bit 0: ROI left the image, bit 1: ROI side too large)
+    // gather ("slow") path behind the tile kernel: instances = the keypoints the binning pass could not give to a
+    // tile (slow_list, *slow_count of them), in every pair of the chunk (shared list) or in their own pair (CSR)
+    const int32_t *slow_list;
+    const int32_t *slow_count;
+    int64_t n_pairs_total;     // pairs of the whole call (CSR pair search in slow-list mode)
+};
+
+// Binning output: the keypoint itself next to its index, grouped by tile (one dwordx4 per entry).
+struct SortedKp {
+    float x, y, size;
+    int32_t g;
+};
+
+// Binning of keypoints by image tile for the fused tile kernel (tile_kernel.hip).
+// key = tile (shared keypoint list) or pair * n_tiles + tile (CSR).
+struct BinArgs {
+    const mofreak_keypoint *kps;
+    const int64_t *kp_offsets;  // nullptr: shared list
+    int64_t n_kp;
+    int32_t n_pairs;
+    int32_t W, H;
+    int32_t tiles_x, tiles_y;
+    int32_t force_slow;         // every valid keypoint goes to the gather path (tests, roi19 dumps)
+    const SmallTables *small;
+    int32_t *kp_key;            // [n_kp] key >= 0, -1 erased, -2 slow
+    int32_t *tile_start;        // [n_keys + 1] counts, then exclusive starts
+    int32_t *tile_cursor;       // [n_keys]
+    SortedKp *sorted_kp;        // [n_kp] keypoints grouped by key
+    int32_t *slow_list;         // [n_kp]
+    int32_t *slow_count;        // [1]
+    uint8_t *out_desc;          // erased keypoints are finalised by the binning pass (zeros, valid = 0)
+    uint8_t *out_valid;
+    int32_t *out_info;
+    int64_t n_keys;
+};
+
+struct TileArgs {
+    FrameArgs f;
+    int32_t n_pairs;
+    int32_t tiles_x, tiles_y;
+    const PatternPoint *lut;
+    const SmallTables *small;
+    const MipSample *mip_samples;
+    const uint16_t *mip_pos;
+    int32_t mip_n_cur, mip_n, mip_stride;
+    const int64_t *kp_offsets;  // nullptr: shared list (tile lists are the same for every pair)
+    int64_t n_kp;
+    const int32_t *tile_start;
+    const SortedKp *sorted_kp;
+    uint8_t *out_desc;
+    uint8_t *out_valid;
+    int32_t *out_info;          // optional
 };
 
 struct CompactArgs {
@@ -90,6 +143,8 @@ int launch_describe(const DescribeArgs &a, int n_blocks, void *stream);
 int launch_mip19(const uint8_t *cur19, const uint8_t *prev19, int64_t n, int mip_theta, uint8_t *out, void *stream);
 int launch_theta(const int32_t *dirs, int64_t n, int32_t *out, void *stream);
 int launch_compact(const CompactArgs &a, void *stream);
+int launch_bin(const BinArgs &a, void *stream);   // zeroes the counters, classifies, scans, scatters
+int launch_tile(const TileArgs &a, void *stream);
 int launch_unpack_integral(const int32_t *src, int pitch, int W, int H, int n_pairs, int32_t *dst, void *stream);
 
 }  // namespace mofreak

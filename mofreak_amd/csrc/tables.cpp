@@ -246,6 +246,47 @@ void build_tables(const FreakParams &p, Tables &t)
         build_resize_axis(L, true, &t.resize[(static_cast<size_t>(L) * 2 + 0) * kPatch]);
         build_resize_axis(L, false, &t.resize[(static_cast<size_t>(L) * 2 + 1) * kPatch]);
     }
+
+    // ---- the subset of the two 19x19 buffers the MIP reads, and its per-L sample table for the tile kernel
+    {
+        const int centers[8][2] = {{5, 5}, {5, 9}, {5, 13}, {9, 5}, {9, 13}, {13, 5}, {13, 9}, {13, 13}};  // (x, y)
+        const int offs[8][2] = {{-4, 0}, {-3, 3}, {0, 4}, {3, 3}, {4, 0}, {3, -3}, {0, -4}, {-3, -3}};     // (dx, dy)
+        std::vector<char> need_cur(kPatch * kPatch, 0), need_prev(kPatch * kPatch, 0);
+        for (const auto &c : centers) {
+            const int bc = (c[1] - 1) * kPatch + (c[0] - 1);
+            for (int k = 0; k < 9; ++k) need_cur[bc + k] = 1;
+            for (const auto &o : offs) {
+                const int bp = (c[1] + o[1] - 1) * kPatch + (c[0] + o[0] - 1);
+                for (int k = 0; k < 9; ++k) need_prev[bp + k] = 1;
+            }
+        }
+        t.mip_pos.clear();
+        for (int i = 0; i < kPatch * kPatch; ++i)
+            if (need_cur[i]) t.mip_pos.push_back(static_cast<uint16_t>(i));
+        t.mip_n_cur = static_cast<int>(t.mip_pos.size());
+        for (int i = 0; i < kPatch * kPatch; ++i)
+            if (need_prev[i]) t.mip_pos.push_back(static_cast<uint16_t>(kP19Pad + i));
+        t.mip_n = static_cast<int>(t.mip_pos.size());
+        t.mip_stride = (t.mip_n + 63) / 64 * 64;
+        t.mip_pos.resize(t.mip_stride, 0);
+        t.mip_samples.assign(static_cast<size_t>(kTileMaxRoi + 1) * t.mip_stride, MipSample{0, 0, 0, 0, 0, 0, 0, 0});
+        for (int L = 1; L <= kTileMaxRoi; ++L) {
+            const ResizeTap *tx = &t.resize[(static_cast<size_t>(L) * 2 + 0) * kPatch];
+            const ResizeTap *ty = &t.resize[(static_cast<size_t>(L) * 2 + 1) * kPatch];
+            for (int j = 0; j < t.mip_n; ++j) {
+                const int pos = t.mip_pos[j] % kP19Pad, dy = pos / kPatch, dx = pos % kPatch;
+                MipSample &m = t.mip_samples[static_cast<size_t>(L) * t.mip_stride + j];
+                m.off00 = static_cast<uint16_t>(ty[dy].ofs * kTileCW + tx[dx].ofs);
+                m.off01 = static_cast<uint16_t>(ty[dy].ofs * kTileCW + tx[dx].ofs1);
+                m.off10 = static_cast<uint16_t>(ty[dy].ofs1 * kTileCW + tx[dx].ofs);
+                m.off11 = static_cast<uint16_t>(ty[dy].ofs1 * kTileCW + tx[dx].ofs1);
+                m.c0x = tx[dx].c0;
+                m.c1x = tx[dx].c1;
+                m.c0y = ty[dy].c0;
+                m.c1y = ty[dy].c1;
+            }
+        }
+    }
 }
 
 }  // namespace mofreak

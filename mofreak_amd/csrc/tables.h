@@ -39,6 +39,22 @@ struct ResizeTap {
     int16_t c0, c1; // fixed-point weights (11 bits); x axis at d >= xmax: {2048, 0}
 };
 
+// ---- geometry of the fused tile kernel (tile_kernel.hip); the MIP sample table below bakes in kTileCW
+constexpr int kTileW = 96, kTileH = 64;  // pixels a workgroup owns
+constexpr int kTileHalo = 48;            // FREAK: keypoints whose patternSizes[scale] <= kTileHalo take the tile path
+constexpr int kTileMipHalo = 8;          // MIP: ROI reach beyond the tile
+constexpr int kTileRW = kTileW + 2 * kTileHalo, kTileRH = kTileH + 2 * kTileHalo;           // integral region 192 x 160
+constexpr int kTileCW = kTileW + 2 * kTileMipHalo, kTileCH = kTileH + 2 * kTileMipHalo;     // gray tiles 112 x 80
+constexpr int kTileMaxRoi = 16;          // largest ROI side the tile path samples
+constexpr int kP19Pad = 368;             // bytes reserved per 19x19 buffer
+
+// One of the 19x19 output pixels the MIP actually reads, for one ROI side L: the four source bytes (offsets from
+// the ROI's top-left inside a kTileCW-pitch gray tile) and the fixed-point weights of cv::resize.
+struct MipSample {
+    uint16_t off00, off01, off10, off11;
+    int16_t c0x, c1x, c0y, c1y;
+};
+
 struct FreakParams {
     float pattern_scale = 22.0f;
     int n_octaves = 4;
@@ -61,6 +77,12 @@ struct Tables {
     int max_abs_direction;                // bound on |direction0|, |direction1|
     // resize taps: [L][axis(0=x,1=y)][19], L = 0..kMaxRoiSide (row 0 unused)
     std::vector<ResizeTap> resize;
+    // The 19x19 positions motionInterchangePattern reads at the 8 patch centres (MoFREAKUtilities.cpp:56-70, 79-88,
+    // 308-316): current-frame positions first (mip_n_cur of them), then previous-frame positions; value =
+    // frame * kP19Pad + row * 19 + col.  mip_samples[L][j] is position j's MipSample for ROI side L (L <= kTileMaxRoi).
+    std::vector<uint16_t> mip_pos;
+    int mip_n_cur = 0, mip_n = 0, mip_stride = 0;  // mip_stride: entries per L in mip_samples (mip_n rounded up to 64)
+    std::vector<MipSample> mip_samples;
 };
 
 // Scale index by the reference expression (freak.cpp computeImpl) -- the chain the thresholds are derived from.

@@ -12,6 +12,14 @@ CENTERS = [(5, 5), (5, 9), (5, 13), (9, 5), (9, 13), (13, 5), (13, 9), (13, 13)]
 OFFSETS = [(-4, 0), (-3, 3), (0, 4), (3, 3), (4, 0), (3, -3), (0, -4), (-3, -3)]
 
 
+@pytest.fixture(params=["auto", "gather"])
+def ctx_path(request, gpu_ctx):
+    """The shared context in both path modes: tile kernel (+ gather path for large keypoints) and gather path only."""
+    gpu_ctx.set_path(M.api.PATH_GATHER if request.param == "gather" else M.api.PATH_AUTO)
+    yield gpu_ctx
+    gpu_ctx.set_path(M.api.PATH_AUTO)
+
+
 def oracle_pairs(oracle, cur, prev, kps, offsets=None, **kw):
     """Oracle descriptors for a (n_pairs,H,W) batch, shared keypoint list or CSR."""
     f = oracle.Freak(**kw)
@@ -100,13 +108,13 @@ def test_roi19_matches_oracle_resize_for_every_small_side(gpu_ctx, oracle):
 
 
 # ------------------------------------------------------------------ R6: FREAK internals
-def test_freak_scale_theta_directions_match_oracle(gpu_ctx, oracle):
+def test_freak_scale_theta_directions_match_oracle(ctx_path, oracle):
     W, H = 640, 480
     fr = synth.synth_stack(6, W, H)
     rng = np.random.default_rng(17)
     kps = synth.random_keypoints(rng, 4000, W, H)
     kps[:500, 2] = rng.uniform(6.0, 60.0, 500).astype(np.float32)
-    info = gpu_ctx.freak_info_host(fr[5], fr[0], kps)
+    info = ctx_path.freak_info_host(fr[5], fr[0], kps)
     f = oracle.Freak()
     valid, _, theta, dirs = f.compute(oracle.absdiff(fr[5], fr[0]), kps)
     assert 0.2 < valid.mean() < 0.95
@@ -131,14 +139,14 @@ def test_theta_index_device_matches_oracle(gpu_ctx, oracle):
 
 
 # ------------------------------------------------------------------ the composed path (R2+R4+R5+R6)
-def test_c2_dense_grid_bit_exact(gpu_ctx, oracle):
+def test_c2_dense_grid_bit_exact(ctx_path, oracle):
     """BASELINE config 2 shape (640x480, 16-px grid, size 12), 12 pairs of a stack."""
     c = synth.CONFIGS["C2"]
     fr = synth.synth_stack(17, c["W"], c["H"])
     kps = synth.config_grid("C2")
     assert len(kps) == 875
     cur, prev = fr[5:], fr[:-5]
-    desc, valid = gpu_ctx.extract_pairs_host(cur, prev, kps)
+    desc, valid = ctx_path.extract_pairs_host(cur, prev, kps)
     want_d, want_v = oracle_pairs(oracle, cur, prev, kps)
     assert valid.all() and np.array_equal(valid, want_v)
     assert np.array_equal(desc, want_d)
@@ -146,7 +154,7 @@ def test_c2_dense_grid_bit_exact(gpu_ctx, oracle):
     assert 0.3 < ones_app < 0.7 and 0.3 < ones_mot < 0.8  # non-degenerate data
 
 
-def test_mixed_sizes_random_positions_bit_exact(gpu_ctx, oracle):
+def test_mixed_sizes_random_positions_bit_exact(ctx_path, oracle):
     """Mixed sizes {8.4,12,18,27,40.5}, fractional coordinates, keypoints over the whole frame (some erased)."""
     W, H = 640, 480
     fr = synth.synth_stack(8, W, H)
@@ -155,13 +163,13 @@ def test_mixed_sizes_random_positions_bit_exact(gpu_ctx, oracle):
     kps[:50, 2] = np.float32([0.0, 1e-8, 5.0, 6.9, 7.0, 100.0, 107.0, 150.0, 2.5e5, np.inf] * 5)
     kps[50:60, 0] = np.float32(np.nan)
     cur, prev = fr[5:], fr[:3]
-    desc, valid = gpu_ctx.extract_pairs_host(cur, prev, kps)
+    desc, valid = ctx_path.extract_pairs_host(cur, prev, kps)
     want_d, want_v = oracle_pairs(oracle, cur, prev, kps)
     assert np.array_equal(valid, want_v)
     assert np.array_equal(desc, want_d)
     assert 0.3 < valid.mean() < 0.9
     assert (desc[valid == 0] == 0).all()
-    gpu_ctx.check_status()  # no ROI ever leaves the image for keypoints that survive FREAK's border filter
+    ctx_path.check_status()  # no ROI ever leaves the image for keypoints that survive FREAK's border filter
 
 
 @pytest.mark.parametrize("mode", [M.BITS_NATURAL, M.BITS_SSE_SIGNED])
@@ -188,7 +196,7 @@ def test_orientation_and_scale_normalisation_flags(native_lib, oracle):
         assert np.array_equal(valid, want_v) and np.array_equal(desc, want_d), (on, sn)
 
 
-def test_csr_ragged_keypoint_lists(gpu_ctx, oracle):
+def test_csr_ragged_keypoint_lists(ctx_path, oracle):
     W, H = 320, 240
     fr = synth.synth_stack(11, W, H)
     rng = np.random.default_rng(12)
@@ -196,7 +204,7 @@ def test_csr_ragged_keypoint_lists(gpu_ctx, oracle):
     offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     kps = synth.random_keypoints(rng, int(offs[-1]), W, H, sizes=(7.0, 8.4, 12.0))
     cur, prev = fr[5:], fr[:6]
-    desc, valid = gpu_ctx.extract_pairs_host(cur, prev, kps, kp_offsets=offs)
+    desc, valid = ctx_path.extract_pairs_host(cur, prev, kps, kp_offsets=offs)
     want_d, want_v = oracle_pairs(oracle, cur, prev, kps, offs)
     assert np.array_equal(valid, want_v) and np.array_equal(desc, want_d)
 
@@ -224,7 +232,7 @@ def test_bad_arguments_are_reported(gpu_ctx):
         gpu_ctx.extract_pairs(z, z, 0, 64, 1, kp, out_d, out_v)
 
 
-def test_strides_and_unaligned_frames(gpu_ctx, oracle):
+def test_strides_and_unaligned_frames(ctx_path, oracle):
     """row_stride > W, pair_stride with padding, and a frame base that is not 4-byte aligned."""
     W, H, n = 203, 150, 3
     fr = synth.synth_stack(n + 5, 256, 160)
@@ -245,8 +253,8 @@ def test_strides_and_unaligned_frames(gpu_ctx, oracle):
     out_d = torch.zeros((n * len(kps), 16), dtype=torch.uint8, device="cuda")
     out_v = torch.zeros(n * len(kps), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()  # the context runs on its own stream: torch's fills above must have landed
-    gpu_ctx.extract_pairs(dc[1:], dp[1:], W, H, n, dk, out_d, out_v, row_stride=rs, pair_stride=ps)
-    gpu_ctx.synchronize()
+    ctx_path.extract_pairs(dc[1:], dp[1:], W, H, n, dk, out_d, out_v, row_stride=rs, pair_stride=ps)
+    ctx_path.synchronize()
     want_d, want_v = oracle_pairs(oracle, cur, prev, kps)
     assert np.array_equal(out_v.cpu().numpy(), want_v) and np.array_equal(out_d.cpu().numpy(), want_d)
 
@@ -280,7 +288,7 @@ def test_device_pointers_on_torch_stream(native_lib, oracle):
 
 
 # ------------------------------------------------------------------ R1 + R7: streams and rows
-def test_stream_rows_and_text_match_oracle(gpu_ctx, oracle):
+def test_stream_rows_and_text_match_oracle(ctx_path, oracle):
     """computeMoFREAKFromFile's frame loop on a 12-frame stack: pairing, frame labels, erase order, text."""
     W, H, T = 320, 240, 12
     fr = synth.synth_stack(T, W, H)
@@ -288,7 +296,7 @@ def test_stream_rows_and_text_match_oracle(gpu_ctx, oracle):
     counts = rng.integers(0, 300, T - 5)
     offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     kps = synth.random_keypoints(rng, int(offs[-1]), W, H, sizes=(7.0, 8.4, 12.0, 18.0))
-    rows = gpu_ctx.extract_stream_host(fr, kps, kp_offsets=offs)
+    rows = ctx_path.extract_stream_host(fr, kps, kp_offsets=offs)
     want = oracle.Freak().extract_stream(fr, kps, offs)
     assert len(rows) == len(want) > 100
     assert rows.tobytes() == want.tobytes()
@@ -297,7 +305,7 @@ def test_stream_rows_and_text_match_oracle(gpu_ctx, oracle):
     assert (np.diff(rows["frame_number"]) >= 0).all()
     # shared keypoint list form
     grid = synth.dense_grid(W, H, 16, 7.0, 23)
-    rows2 = gpu_ctx.extract_stream_host(fr, grid)
+    rows2 = ctx_path.extract_stream_host(fr, grid)
     offs2 = np.arange(T - 5 + 1, dtype=np.int64) * len(grid)
     want2 = oracle.Freak().extract_stream(fr, np.tile(grid, (T - 5, 1)), offs2)
     assert rows2.tobytes() == want2.tobytes() and len(rows2) == (T - 5) * len(grid)
@@ -314,7 +322,7 @@ def test_compact_rows_capacity_error(gpu_ctx):
 
 
 # ------------------------------------------------------------------ full-size properties (BASELINE config 3)
-def test_c3_full_resolution_pairs_bit_exact_and_chunk_independent(gpu_ctx, oracle):
+def test_c3_full_resolution_pairs_bit_exact_and_chunk_independent(ctx_path, oracle):
     """1920x1080, 8-px grid (29 106 keypoints/pair): bit-exact vs the oracle on every pair of a 12-pair batch
     (spans two integral chunks), and a pair described alone gives the same bytes as inside the batch."""
     c = synth.CONFIGS["C3"]
@@ -324,22 +332,22 @@ def test_c3_full_resolution_pairs_bit_exact_and_chunk_independent(gpu_ctx, oracl
     kps = synth.config_grid("C3")
     assert len(kps) == 29106
     cur, prev = fr[5:], fr[:n_pairs]
-    desc, valid = gpu_ctx.extract_pairs_host(cur, prev, kps)
+    desc, valid = ctx_path.extract_pairs_host(cur, prev, kps)
     assert valid.all()
     want_d, want_v = oracle_pairs(oracle, cur, prev, kps)
     assert np.array_equal(desc, want_d) and np.array_equal(valid, want_v)
-    d1, v1 = gpu_ctx.extract_pairs_host(cur[9:10], prev[9:10], kps)
+    d1, v1 = ctx_path.extract_pairs_host(cur[9:10], prev[9:10], kps)
     assert np.array_equal(d1, desc[9 * len(kps):10 * len(kps)])
     # idempotence: same call again, same bytes
-    d2, _ = gpu_ctx.extract_pairs_host(cur, prev, kps)
+    d2, _ = ctx_path.extract_pairs_host(cur, prev, kps)
     assert np.array_equal(d2, desc)
 
 
-def test_identical_frames_give_zero_motion_and_ff_appearance(gpu_ctx):
+def test_identical_frames_give_zero_motion_and_ff_appearance(ctx_path):
     """cur == prev: the difference image is 0 -> every FREAK box mean is equal -> mode S bytes 0xFF (KAT 7),
     theta 0; every MIP SSD is between a strip and shifted copies of the same frame."""
     W, H = 640, 480
     fr = np.full((1, H, W), 91, np.uint8)
     kps = synth.config_grid("C2")
-    desc, valid = gpu_ctx.extract_pairs_host(fr, fr, kps)
+    desc, valid = ctx_path.extract_pairs_host(fr, fr, kps)
     assert valid.all() and (desc[:, :8] == 0xFF).all() and (desc[:, 8:] == 0).all()
