@@ -126,6 +126,11 @@ int mofreak_set_profiling(mofreak_ctx *ctx, int enable);
 /* Synchronises, folds the recorded events into the running totals and returns them (reset != 0 clears them). */
 int mofreak_get_profile(mofreak_ctx *ctx, mofreak_profile *out, int reset);
 
+/* Diagnostics: per-phase s_memtime tick sums of the instrumented tile kernel (one thread per workgroup, summed over
+ * workgroups), available only on a context created with MOFREAK_TILE_STAMPS=1 in the environment; such a context
+ * runs the instrumented kernel, whose run time must not be quoted.  Slots: see tile_kernel.hip TILE_STAMP. */
+int mofreak_get_tile_stamps(mofreak_ctx *ctx, uint64_t *out, int n, int reset);
+
 /* ------------------------------------------------------------------ the hot path */
 /*
  * Descriptors for n_pairs frame pairs.  Replaces, per frame of computeMoFREAKFromFile's loop:

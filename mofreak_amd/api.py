@@ -31,7 +31,7 @@ assert ROW_DTYPE.itemsize == 32
 EXPORTS = [
     "mofreak_abi_version", "mofreak_default_params", "mofreak_create", "mofreak_destroy", "mofreak_last_error",
     "mofreak_set_stream", "mofreak_synchronize", "mofreak_reserve", "mofreak_check_status",
-    "mofreak_set_profiling", "mofreak_get_profile", "mofreak_set_path",
+    "mofreak_set_profiling", "mofreak_get_profile", "mofreak_set_path", "mofreak_get_tile_stamps",
     "mofreak_extract_pairs", "mofreak_compact_rows", "mofreak_extract_stream", "mofreak_format_rows",
     "mofreak_parse_rows", "mofreak_diff_integral", "mofreak_mip19", "mofreak_roi19", "mofreak_freak_info",
     "mofreak_theta_index", "mofreak_pattern_sizes", "mofreak_scale_index", "mofreak_table_pattern",
@@ -91,6 +91,7 @@ def load() -> C.CDLL:
     L.mofreak_check_status.argtypes = [vp]
     L.mofreak_set_profiling.argtypes = [vp, i32]
     L.mofreak_set_path.argtypes = [vp, i32]
+    L.mofreak_get_tile_stamps.argtypes = [vp, vp, i32, i32]
     L.mofreak_get_profile.argtypes = [vp, C.POINTER(Profile), i32]
     L.mofreak_extract_pairs.argtypes = [vp, vp, vp, i32, i32, i64, i64, i32, vp, vp, i64, vp, vp, C.c_uint]
     L.mofreak_compact_rows.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, i64, C.POINTER(i64), C.c_uint]
@@ -212,6 +213,11 @@ class Context:
     def set_path(self, path: int):
         """PATH_AUTO (tile kernel + gather path for large keypoints) or PATH_GATHER (gather path for everything)."""
         self._check(self._lib.mofreak_set_path(self._h, path))
+
+    def get_tile_stamps(self, reset: bool = True) -> np.ndarray:
+        out = np.zeros(32, np.uint64)
+        self._check(self._lib.mofreak_get_tile_stamps(self._h, _ptr(out), 32, int(reset)))
+        return out
 
     def set_profiling(self, enable: bool):
         self._check(self._lib.mofreak_set_profiling(self._h, int(enable)))

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -37,6 +38,8 @@ struct mofreak_ctx {
     // workspace (grown on demand, never shrunk)
     DeviceBuffer integral, band_totals, scratch_desc, scratch_valid, compact_offsets, stage[6], offsets_dev;
     DeviceBuffer kp_key, sorted_idx, slow_list, tile_start, tile_cursor, slow_count;  // keypoint binning
+    ThetaBound *d_theta = nullptr;
+    unsigned long long *d_stamps = nullptr;  // MOFREAK_TILE_STAMPS=1: per-phase tick sums of the diagnostic tile kernel
     MipSample *d_mip_samples = nullptr;
     uint16_t *d_mip_pos = nullptr;
     int path_mode = MOFREAK_PATH_AUTO;
@@ -215,6 +218,7 @@ int run_gather(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, const 
         a.lut = ctx->d_lut;
         a.resize = ctx->d_resize;
         a.small = ctx->d_small;
+        a.theta = ctx->d_theta;
         a.kps = kps;
         a.kp_offsets = d_offsets;
         a.n_kp = n_kp;
@@ -311,6 +315,7 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
             t.tiles_y = tiles_y;
             t.lut = ctx->d_lut;
             t.small = ctx->d_small;
+            t.theta = ctx->d_theta;
             t.mip_samples = ctx->d_mip_samples;
             t.mip_pos = ctx->d_mip_pos;
             t.mip_n_cur = ctx->tables.mip_n_cur;
@@ -323,6 +328,7 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
             t.sorted_kp = static_cast<const SortedKp *>(ctx->sorted_idx.ptr);
             t.out_desc = d_offsets ? out_desc : out_desc + (int64_t)p0 * n_kp * 16;
             t.out_valid = d_offsets ? out_valid : out_valid + (int64_t)p0 * n_kp;
+            t.stamps = ctx->d_stamps;
             t.out_info = out_info ? (d_offsets ? out_info : out_info + (int64_t)p0 * n_kp * 4) : nullptr;
             e = launch_tile(t, ctx->stream);
             if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("tile kernel launch: ") + hipGetErrorString((hipError_t)e));
@@ -493,6 +499,12 @@ int mofreak_create(int device_id, const mofreak_params *params, mofreak_ctx **ou
     CREATE_TRY(hipMalloc((void **)&ctx->d_resize, t.resize.size() * sizeof(ResizeTap)));
     CREATE_TRY(hipMalloc((void **)&ctx->d_small, sizeof(SmallTables)));
     CREATE_TRY(hipMalloc((void **)&ctx->d_status, sizeof(int32_t)));
+    if (const char *ev = std::getenv("MOFREAK_TILE_STAMPS"); ev && ev[0] == '1') {
+        CREATE_TRY(hipMalloc((void **)&ctx->d_stamps, kTileStampSlots * sizeof(unsigned long long)));
+        CREATE_TRY(hipMemset(ctx->d_stamps, 0, kTileStampSlots * sizeof(unsigned long long)));
+    }
+    CREATE_TRY(hipMalloc((void **)&ctx->d_theta, t.theta_bounds.size() * sizeof(ThetaBound)));
+    CREATE_TRY(hipMemcpy(ctx->d_theta, t.theta_bounds.data(), t.theta_bounds.size() * sizeof(ThetaBound), hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc((void **)&ctx->d_mip_samples, t.mip_samples.size() * sizeof(MipSample)));
     CREATE_TRY(hipMalloc((void **)&ctx->d_mip_pos, t.mip_pos.size() * sizeof(uint16_t)));
     CREATE_TRY(hipMemcpy(ctx->d_mip_samples, t.mip_samples.data(), t.mip_samples.size() * sizeof(MipSample), hipMemcpyHostToDevice));
@@ -531,6 +543,8 @@ void mofreak_destroy(mofreak_ctx *ctx)
     if (ctx->d_resize) (void)hipFree(ctx->d_resize);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->d_theta) (void)hipFree(ctx->d_theta);
+    if (ctx->d_stamps) (void)hipFree(ctx->d_stamps);
     if (ctx->d_mip_samples) (void)hipFree(ctx->d_mip_samples);
     if (ctx->d_mip_pos) (void)hipFree(ctx->d_mip_pos);
     release(ctx->kp_key);
@@ -597,6 +611,18 @@ int mofreak_set_path(mofreak_ctx *ctx, int path)
     if (!ctx) return MOFREAK_ERR_BAD_ARG;
     if (path != MOFREAK_PATH_AUTO && path != MOFREAK_PATH_GATHER) return fail(ctx, MOFREAK_ERR_BAD_ARG, "unknown path");
     ctx->path_mode = path;
+    return MOFREAK_OK;
+}
+
+int mofreak_get_tile_stamps(mofreak_ctx *ctx, uint64_t *out, int n, int reset)
+{
+    if (!ctx || !out || n < 0) return MOFREAK_ERR_BAD_ARG;
+    NEED_DEVICE(ctx);
+    if (!ctx->d_stamps) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "create the context with MOFREAK_TILE_STAMPS=1 in the environment");
+    n = std::min(n, kTileStampSlots);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->d_stamps, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(ctx, hipMemset(ctx->d_stamps, 0, kTileStampSlots * sizeof(unsigned long long)));
     return MOFREAK_OK;
 }
 
@@ -924,7 +950,7 @@ int mofreak_theta_index(mofreak_ctx *ctx, const int32_t *dirs, int64_t n, int32_
         dd = static_cast<const int32_t *>(ctx->stage[0].ptr);
         dout = static_cast<int32_t *>(ctx->stage[3].ptr);
     }
-    const int e = launch_theta(dd, n, dout, ctx->stream);
+    const int e = launch_theta(ctx->d_theta, dd, n, dout, ctx->stream);
     if (e) return fail(ctx, MOFREAK_ERR_HIP, "theta launch failed");
     if (host) {
         HIP_TRY(ctx, hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -58,7 +58,7 @@ __device__ __forceinline__ int absdiff_u8(uint32_t a, uint32_t b, int k)
 __device__ __forceinline__ int div_box(int v, int a)
 {
     int q = (int)((float)v * __builtin_amdgcn_rcpf((float)a));
-    int r = v - q * a;
+    int r = v - q * a;  // (a can exceed 24 bits for the largest patterns of the gather path: full multiply)
     if (r < 0) {
         --q;
         r += a;
@@ -91,14 +91,33 @@ __device__ __forceinline__ int mean_intensity(const int32_t *__restrict__ integ,
 //   angle = (float)(atan2((float)direction1,(float)direction0)*(180.0/CV_PI));  atan2(float,float) -> float
 //   thetaIdx = int(FREAK_NB_ORIENTATION*angle*(1/360.0)+0.5); wrap into [0,256)
 // The float atan2 is taken as the double result rounded once (the reference's x86 MSVC CRT does exactly that).
-__device__ __forceinline__ int theta_index(int direction0, int direction1)
+//
+// No atan2 runs on the device.  thetaIdx is a monotone step function of the true angle of (direction0, direction1);
+// the host finds every step's exact position through the float chain above (tables.cpp, theta_bounds) and stores
+// its direction (cos, sin) in double.  Which side of a step an INTEGER direction lies on is the sign of a cross
+// product, evaluated in double: the product's rounding error (~1e-12 at these magnitudes) is orders of magnitude
+// below the smallest cross product an integer direction can have with a generic angle, so the result is exact and
+// independent of any libm.  7 bisection steps of 2 mul + 1 sub instead of a ~300-instruction double atan2.
+//   tb[0..127]   upper half plane: idx counts the steps with angle >= beta_k
+//   tb[128..254] lower half plane: idx = 256 - (steps with |angle| > mu_m)
+__device__ __forceinline__ int theta_index(const ThetaBound *__restrict__ tb, int direction0, int direction1)
 {
-    const float a = (float)atan2((double)(float)direction1, (double)(float)direction0);
-    const float angle = (float)((double)a * (180.0 / kCvPi));
-    int t = (int)((double)(256.0f * angle) * (1 / 360.0) + 0.5);
-    if (t < 0) t += kNbOrientation;
-    if (t >= kNbOrientation) t -= kNbOrientation;
-    return t;
+    if ((direction0 | direction1) == 0) return 0;  // atan2(0, 0) = 0
+    const bool upper = direction1 >= 0;
+    const double y = upper ? (double)direction1 : -(double)direction1, x = (double)direction0;
+    const ThetaBound *t = upper ? tb : tb + 128;
+    const int n = upper ? 128 : 127;
+    int lo = 0, hi = n;  // count = number of leading steps the direction has passed
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const double cross = y * t[mid].c - x * t[mid].s;
+        const bool passed = upper ? (cross >= 0.0) : (cross > 0.0);
+        if (passed)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return upper ? lo : (lo == 0 ? 0 : kNbOrientation - lo);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -55,6 +55,7 @@ struct DescribeArgs {
     const PatternPoint *lut;
     const ResizeTap *resize;
     const SmallTables *small;
+    const ThetaBound *theta;
     const mofreak_keypoint *kps;
     const int64_t *kp_offsets; // device CSR offsets of the WHOLE call (nullptr: shared list)
     int64_t n_kp;              // shared list length (kp_offsets == nullptr)
@@ -108,6 +109,7 @@ struct TileArgs {
     int32_t tiles_x, tiles_y;
     const PatternPoint *lut;
     const SmallTables *small;
+    const ThetaBound *theta;
     const MipSample *mip_samples;
     const uint16_t *mip_pos;
     int32_t mip_n_cur, mip_n, mip_stride;
@@ -118,7 +120,9 @@ struct TileArgs {
     uint8_t *out_desc;
     uint8_t *out_valid;
     int32_t *out_info;          // optional
+    unsigned long long *stamps; // optional [kTileStampSlots]: diagnostic per-phase tick sums (tile_kernel<true>)
 };
+constexpr int kTileStampSlots = 32;
 
 struct CompactArgs {
     const mofreak_keypoint *kps;
@@ -141,7 +145,7 @@ constexpr int kCompactItemsPerBlock = 1024;
 int launch_integral(const IntegralArgs &a, void *stream);
 int launch_describe(const DescribeArgs &a, int n_blocks, void *stream);
 int launch_mip19(const uint8_t *cur19, const uint8_t *prev19, int64_t n, int mip_theta, uint8_t *out, void *stream);
-int launch_theta(const int32_t *dirs, int64_t n, int32_t *out, void *stream);
+int launch_theta(const ThetaBound *tb, const int32_t *dirs, int64_t n, int32_t *out, void *stream);
 int launch_compact(const CompactArgs &a, void *stream);
 int launch_bin(const BinArgs &a, void *stream);   // zeroes the counters, classifies, scans, scatters
 int launch_tile(const TileArgs &a, void *stream);

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a)
                 }
                 direction0 = wave_sum(t0);
                 direction1 = wave_sum(t1);
-                theta = theta_index(direction0, direction1);
+                theta = theta_index(a.theta, direction0, direction1);
             }
             int v = 0;
             if (lane < kNbPoints) v = mean_intensity(integ, a.pitch, kx, ky, lut_scale[theta * kNbPoints + lane]);
@@ -331,10 +331,10 @@ __global__ __launch_bounds__(256) void mip19_kernel(const uint8_t *cur19, const 
     }
 }
 
-__global__ __launch_bounds__(256) void theta_kernel(const int32_t *dirs, int64_t n, int32_t *out)
+__global__ __launch_bounds__(256) void theta_kernel(const ThetaBound *tb, const int32_t *dirs, int64_t n, int32_t *out)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        out[i] = theta_index(dirs[2 * i], dirs[2 * i + 1]);
+        out[i] = theta_index(tb, dirs[2 * i], dirs[2 * i + 1]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -471,11 +471,11 @@ int launch_mip19(const uint8_t *cur19, const uint8_t *prev19, int64_t n, int mip
     return (int)hipGetLastError();
 }
 
-int launch_theta(const int32_t *dirs, int64_t n, int32_t *out, void *stream)
+int launch_theta(const ThetaBound *tb, const int32_t *dirs, int64_t n, int32_t *out, void *stream)
 {
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     if (blocks == 0) return 0;
-    hipLaunchKernelGGL(theta_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dirs, n, out);
+    hipLaunchKernelGGL(theta_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), tb, dirs, n, out);
     return (int)hipGetLastError();
 }
 

@@ -126,7 +126,56 @@ void build_resize_axis(int L, bool is_x, ResizeTap *out)
     }
 }
 
+// thetaIdx before wrapping, from the float angle in radians (freak.cpp computeImpl; the chain after atan2)
+int theta_raw_from_float(float a)
+{
+    const float angle = static_cast<float>(static_cast<double>(a) * (180.0 / kCvPi));
+    return static_cast<int>(static_cast<double>(256.0f * angle) * (1 / 360.0) + 0.5);
+}
+
+inline float float_from_bits(uint32_t b)
+{
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+
 }  // namespace
+
+void build_theta_bounds(std::vector<ThetaBound> &out)
+{
+    out.assign(kThetaBounds, ThetaBound{1.0, 0.0});
+    const float pi_f = static_cast<float>(M_PI);
+    uint32_t pi_bits;
+    std::memcpy(&pi_bits, &pi_f, 4);
+    // upper half plane: beta_k = the real angle above which the rounded float angle gives an index >= k.
+    // The float atan2 is the correctly rounded one, so the step sits at the midpoint of two adjacent floats.
+    for (int k = 1; k <= 128; ++k) {
+        uint32_t lo = 0, hi = pi_bits;  // raw(+0) = 0 < k <= raw(pi_f) = 128; positive floats order like their bits
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (theta_raw_from_float(float_from_bits(mid)) >= k)
+                hi = mid;
+            else
+                lo = mid;
+        }
+        const double beta = (static_cast<double>(float_from_bits(hi - 1)) + static_cast<double>(float_from_bits(hi))) / 2;
+        out[k - 1] = ThetaBound{std::cos(beta), std::sin(beta)};
+    }
+    // lower half plane: the index is <= -m once |angle| exceeds mu_m
+    for (int m = 1; m <= 127; ++m) {
+        uint32_t lo = 0, hi = pi_bits;  // raw(-0) = 0 > -m; raw(-pi_f) = -127 <= -m
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (theta_raw_from_float(-float_from_bits(mid)) <= -m)
+                hi = mid;
+            else
+                lo = mid;
+        }
+        const double mu = (static_cast<double>(float_from_bits(hi - 1)) + static_cast<double>(float_from_bits(hi))) / 2;
+        out[128 + m - 1] = ThetaBound{std::cos(mu), std::sin(mu)};
+    }
+}
 
 int scale_index_from_size(float size, int n_octaves)
 {
@@ -246,6 +295,8 @@ void build_tables(const FreakParams &p, Tables &t)
         build_resize_axis(L, true, &t.resize[(static_cast<size_t>(L) * 2 + 0) * kPatch]);
         build_resize_axis(L, false, &t.resize[(static_cast<size_t>(L) * 2 + 1) * kPatch]);
     }
+
+    build_theta_bounds(t.theta_bounds);
 
     // ---- the subset of the two 19x19 buffers the MIP reads, and its per-L sample table for the tile kernel
     {

@@ -55,6 +55,12 @@ struct MipSample {
     int16_t c0x, c1x, c0y, c1y;
 };
 
+// One step of the thetaIdx staircase: the direction (cos, sin) of the exact angle at which the index changes.
+struct ThetaBound {
+    double c, s;
+};
+constexpr int kThetaBounds = 256;  // [0..127] upper half plane beta_1..beta_128, [128..254] lower half mu_1..mu_127
+
 struct FreakParams {
     float pattern_scale = 22.0f;
     int n_octaves = 4;
@@ -80,6 +86,9 @@ struct Tables {
     // The 19x19 positions motionInterchangePattern reads at the 8 patch centres (MoFREAKUtilities.cpp:56-70, 79-88,
     // 308-316): current-frame positions first (mip_n_cur of them), then previous-frame positions; value =
     // frame * kP19Pad + row * 19 + col.  mip_samples[L][j] is position j's MipSample for ROI side L (L <= kTileMaxRoi).
+    // thetaIdx steps (see device_helpers.h theta_index): found by bisection over float angles through the chain
+    // angle = (float)(a * (180.0/CV_PI)); thetaIdx = int(256*angle*(1/360.0)+0.5)
+    std::vector<ThetaBound> theta_bounds;
     std::vector<uint16_t> mip_pos;
     int mip_n_cur = 0, mip_n = 0, mip_stride = 0;  // mip_stride: entries per L in mip_samples (mip_n rounded up to 64)
     std::vector<MipSample> mip_samples;
@@ -88,6 +97,7 @@ struct Tables {
 // Scale index by the reference expression (freak.cpp computeImpl) -- the chain the thresholds are derived from.
 int scale_index_from_size(float size, int n_octaves);
 
+void build_theta_bounds(std::vector<ThetaBound> &out);
 void build_tables(const FreakParams &p, Tables &t);
 
 }  // namespace mofreak

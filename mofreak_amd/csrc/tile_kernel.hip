@@ -46,7 +46,8 @@ constexpr int kOffPrev = kOffCur + kTileCW * kTileCH;
 constexpr int kOffScratch = kOffPrev + kTileCW * kTileCH;
 constexpr int kScratchBytes = kTileRH * kRunsPerRow * 4;  // 7680: row carries; also column carries / per-keypoint arrays
 constexpr int kOffSmall = kOffScratch + kScratchBytes;
-constexpr int kTileLdsBytes = kOffSmall + (int)((sizeof(SmallTables) + 15) / 16 * 16);
+constexpr int kOffTheta = kOffSmall + (int)((sizeof(SmallTables) + 15) / 16 * 16);
+constexpr int kTileLdsBytes = kOffTheta + kThetaBounds * (int)sizeof(ThetaBound);
 static_assert(kOffCur % 16 == 0 && kOffPrev % 16 == 0 && kOffScratch % 16 == 0 && kOffSmall % 16 == 0, "LDS carve alignment");
 static_assert(kTileLdsBytes <= 160 * 1024, "tile kernel LDS budget");
 static_assert(kTileRW % 16 == 0 && kTileRH % kColBlocks == 0, "region blocking");
@@ -95,6 +96,15 @@ __device__ __forceinline__ uint2 load_px8(const uint8_t *row, int gx, int W, boo
     return make_uint2(w[0], w[1]);
 }
 
+// (int)((double)a + 0.5) for a float 0 <= a < 2^23 without leaving single precision: the double sum is exact, so the
+// result is trunc(a) plus one when the fraction reaches one half.  (Tile-path taps are always > 0: the keypoint
+// passed FREAK's border filter.)
+__device__ __forceinline__ int round_half_up_pos(float a)
+{
+    const int i = (int)a;
+    return i + ((a - (float)i) >= 0.5f ? 1 : 0);
+}
+
 // FREAK::meanIntensity (box branch) on the tile-local integral; (ox, oy) = image coordinates of the region origin.
 __device__ __forceinline__ int mean_intensity_tile(const int32_t *__restrict__ I, int ox, int oy, float kx, float ky,
                                                    const PatternPoint P)
@@ -102,17 +112,18 @@ __device__ __forceinline__ int mean_intensity_tile(const int32_t *__restrict__ I
     const float xf = P.x + kx;
     const float yf = P.y + ky;
     const float radius = P.sigma;
-    const int x_left = (int)((double)(xf - radius) + 0.5) - ox;
-    const int y_top = (int)((double)(yf - radius) + 0.5) - oy;
-    const int x_right = (int)((double)(xf + radius) + 1.5) - ox;
-    const int y_bottom = (int)((double)(yf + radius) + 1.5) - oy;
-    const int32_t *top = I + y_top * kIP + kIntegralColOffset;
-    const int32_t *bot = I + y_bottom * kIP + kIntegralColOffset;
+    // int(xf - radius + 0.5), int(xf + radius + 1.5): the reference adds 0.5 / 1.5 in double, i.e. exactly
+    const int x_left = round_half_up_pos(xf - radius) - ox;
+    const int y_top = round_half_up_pos(yf - radius) - oy;
+    const int x_right = round_half_up_pos(xf + radius) + 1 - ox;
+    const int y_bottom = round_half_up_pos(yf + radius) + 1 - oy;
+    const int32_t *top = I + __mul24(y_top, kIP) + kIntegralColOffset;
+    const int32_t *bot = I + __mul24(y_bottom, kIP) + kIntegralColOffset;
     int ret_val = bot[x_right];
     ret_val -= bot[x_left];
     ret_val += top[x_left];
     ret_val -= top[x_right];
-    return div_box(ret_val, (x_right - x_left) * (y_bottom - y_top)) & 0xff;
+    return div_box(ret_val, __mul24(x_right - x_left, y_bottom - y_top)) & 0xff;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -238,8 +249,22 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs a)
 // ------------------------------------------------------------------------------------------------
 // the tile kernel
 // ------------------------------------------------------------------------------------------------
+// Diagnostic build of the same kernel (STAMPS = true, launched only when the context was created with
+// MOFREAK_TILE_STAMPS=1): thread 0 of every workgroup adds the s_memtime ticks spent between consecutive
+// workgroup barriers into a.stamps[phase].  In the product instantiation no stamp executes.
+#define TILE_STAMP(i)                                                               \
+    do {                                                                            \
+        if (STAMPS && tid == 0) {                                                   \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();           \
+            atomicAdd(&a.stamps[i], now_ - last_stamp);                             \
+            last_stamp = now_;                                                      \
+        }                                                                           \
+    } while (0)
+
+template <bool STAMPS>
 __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
 {
+    unsigned long long last_stamp = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int n_tiles = a.tiles_x * a.tiles_y;
     const int tile = blockIdx.x, pair = blockIdx.y;
@@ -267,6 +292,8 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
 
     for (int i = tid; i < (int)(sizeof(SmallTables) / 4); i += kTileThreads)
         reinterpret_cast<int32_t *>(&st)[i] = reinterpret_cast<const int32_t *>(a.small)[i];
+    ThetaBound *s_theta = reinterpret_cast<ThetaBound *>(lds + kOffTheta);
+    for (int i = tid; i < kThetaBounds; i += kTileThreads) s_theta[i] = a.theta[i];
 
     // ================= stage 0: gray tiles (tile + 8-px rim), 8 bytes per lane; all loads first, then the stores
     {
@@ -290,7 +317,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
             }
         }
     }
-    __syncthreads();
+    __syncthreads();  TILE_STAMP(0);
 
     // ================= stage 1: MIP
     {
@@ -307,12 +334,13 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
         const int mdx = (int)((0x14787410u >> (4 * mi)) & 15) - 4, mdy = (int)((0x10147874u >> (4 * mi)) & 15) - 4;
         const int base_c = (mcy - 1) * kPatch + (mcx - 1);
         const int base_p = kP19Pad + (mcy + mdy - 1) * kPatch + (mcx + mdx - 1);
+        const int cw = base_c >> 2, cs = base_c & 3, pw = base_p >> 2, ps = base_p & 3;  // covering dword, byte shift
         MipSample sm[kMipIters];
         int have_L = -1;
         for (int b0 = 0; b0 < n_tile_kp; b0 += kBatch) {
             const int nb = min(kBatch, n_tile_kp - b0);
             if (tid < 2) s_flags[tid] = 0;
-            __syncthreads();
+            __syncthreads();  TILE_STAMP(1);
             if (tid < nb) {
                 const SortedKp kp = tile_kps[b0 + tid];
                 const int x_i = (int)kp.x, y_i = (int)kp.y;                    // :460 float -> int parameters
@@ -325,9 +353,9 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
                 km[tid] = m;
                 if (tid == 0) s_flags[0] = L;
             }
-            __syncthreads();
+            __syncthreads();  TILE_STAMP(2);
             if (tid < nb && km[tid].L != s_flags[0]) s_flags[1] = 1;
-            __syncthreads();
+            __syncthreads();  TILE_STAMP(3);
             const bool uniform = s_flags[1] == 0;
             if (uniform && s_flags[0] != have_L) {  // one ROI side in the batch (the usual case): samples stay in registers
                 have_L = s_flags[0];
@@ -349,34 +377,47 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
 #pragma unroll
                 for (int u = 0; u < kMipIters; ++u) {
                     const uint8_t *src = ((lane + 64 * u) < a.mip_n_cur ? s_cur : s_prev) + m.roi_off;
-                    const int t0 = (int)src[sm[u].off00] * sm[u].c0x + (int)src[sm[u].off01] * sm[u].c1x;
-                    const int t1 = (int)src[sm[u].off10] * sm[u].c0x + (int)src[sm[u].off11] * sm[u].c1x;
-                    px[u] = ((((int)sm[u].c0y * (t0 >> 4)) >> 16) + (((int)sm[u].c1y * (t1 >> 4)) >> 16) + 2) >> 2;
+                    // every factor fits 24 bits: full-rate v_mul_i32_i24 / v_mad_i32_i24
+                    const int t0 = __mul24((int)src[sm[u].off00], sm[u].c0x) + __mul24((int)src[sm[u].off01], sm[u].c1x);
+                    const int t1 = __mul24((int)src[sm[u].off10], sm[u].c0x) + __mul24((int)src[sm[u].off11], sm[u].c1x);
+                    px[u] = ((__mul24((int)sm[u].c0y, t0 >> 4) >> 16) + (__mul24((int)sm[u].c1y, t1 >> 4) >> 16) + 2) >> 2;
                 }
 #pragma unroll
                 for (int u = 0; u < kMipIters; ++u)
                     if (lane + 64 * u < a.mip_n) dst[pos[u]] = (uint8_t)px[u];
             }
-            __syncthreads();
+            __syncthreads();  TILE_STAMP(4);
             for (int kk = wave; kk < nb; kk += kTileWaves) {
-                const uint8_t *b = p19 + kk * (2 * kP19Pad);
-                int ssd = 0;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const int d = (int)b[base_c + k] - (int)b[base_p + k];
-                    ssd += d * d;
-                }
+                // the two 9-byte strips sit at arbitrary byte offsets: fetch the covering aligned dwords (a byte-wise
+                // formulation lets the compiler fuse the loads into misaligned ds_read_b64s, 64 cycles each) and
+                // shift the strips out; SSD = sum c^2 + sum p^2 - 2 sum c*p with packed u8 dot products
+                const uint32_t *b32 = reinterpret_cast<const uint32_t *>(p19 + kk * (2 * kP19Pad));
+                const uint32_t cd0 = b32[cw], cd1 = b32[cw + 1], cd2 = b32[cw + 2];
+                const uint32_t pd0 = b32[pw], pd1 = b32[pw + 1], pd2 = b32[pw + 2];
+                const uint32_t c0 = __builtin_amdgcn_alignbyte(cd1, cd0, cs), c1 = __builtin_amdgcn_alignbyte(cd2, cd1, cs);
+                const uint32_t c2 = (cd2 >> (8 * cs)) & 0xffu;
+                const uint32_t p0 = __builtin_amdgcn_alignbyte(pd1, pd0, ps), p1 = __builtin_amdgcn_alignbyte(pd2, pd1, ps);
+                const uint32_t p2 = (pd2 >> (8 * ps)) & 0xffu;
+                const uint32_t sq = __builtin_amdgcn_udot4(c0, c0, __builtin_amdgcn_udot4(c1, c1, c2 * c2, false), false) +
+                                    __builtin_amdgcn_udot4(p0, p0, __builtin_amdgcn_udot4(p1, p1, p2 * p2, false), false);
+                const uint32_t cross = __builtin_amdgcn_udot4(c0, p0, __builtin_amdgcn_udot4(c1, p1, c2 * p2, false), false);
+                const int ssd = (int)(sq - 2u * cross);
                 const uint64_t mot = __ballot(ssd > st.mip_theta);
                 if (lane == 0)
                     *reinterpret_cast<uint2 *>(a.out_desc + (out_base + km[kk].g) * 16 + 8) = make_uint2((uint32_t)mot, (uint32_t)(mot >> 32));
             }
-            __syncthreads();
+            __syncthreads();  TILE_STAMP(5);
         }
     }
 
     // ================= stage 2: integral of |cur - prev| over tile + halo, in LDS
+    // Two blocked scans, each keeping its values in registers across the carry exchange, so that every pixel costs
+    // one LDS write (row pass) plus one read and one write (column pass).
     {
-        // 2a: per 16-pixel run: absolute differences and their running sum inside the run
+        int32_t *carry = reinterpret_cast<int32_t *>(scratch);  // run totals, then block totals; then their prefixes
+        // 2a: row pass.  A thread owns 16-pixel runs: |cur - prev| and the running sum inside the run (v_sad_u8 on
+        //     masked dwords), run total -> LDS.
+        int4 rv[kRunIters][4];
         {
             uint4 c[kRunIters], p[kRunIters];
 #pragma unroll
@@ -391,87 +432,97 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
             }
 #pragma unroll
             for (int u = 0; u < kRunIters; ++u) {
-                const int t = tid + u * kTileThreads;
-                if (t < kTileRH * kRunsPerRow) {
-                    const int r = t / kRunsPerRow, q = t - r * kRunsPerRow;
-                    const uint32_t cw[4] = {c[u].x, c[u].y, c[u].z, c[u].w}, pw[4] = {p[u].x, p[u].y, p[u].z, p[u].w};
-                    int4 *dst = reinterpret_cast<int4 *>(I + (r + 1) * kIP + 4 + 16 * q);
-                    int acc = 0;
+                const uint32_t cw4[4] = {c[u].x, c[u].y, c[u].z, c[u].w}, pw4[4] = {p[u].x, p[u].y, p[u].z, p[u].w};
+                uint32_t acc = 0;
 #pragma unroll
-                    for (int w4 = 0; w4 < 4; ++w4) {
-                        int4 o;
-                        acc += absdiff_u8(cw[w4], pw[w4], 0);
-                        o.x = acc;
-                        acc += absdiff_u8(cw[w4], pw[w4], 1);
-                        o.y = acc;
-                        acc += absdiff_u8(cw[w4], pw[w4], 2);
-                        o.z = acc;
-                        acc += absdiff_u8(cw[w4], pw[w4], 3);
-                        o.w = acc;
-                        dst[w4] = o;
-                    }
+                for (int w4 = 0; w4 < 4; ++w4) {
+                    const uint32_t x = cw4[w4], y = pw4[w4];
+                    rv[u][w4].x = (int)__builtin_amdgcn_sad_u8(x & 0xffu, y & 0xffu, acc);
+                    rv[u][w4].y = (int)__builtin_amdgcn_sad_u8(x & 0xffffu, y & 0xffffu, acc);
+                    rv[u][w4].z = (int)__builtin_amdgcn_sad_u8(x & 0xffffffu, y & 0xffffffu, acc);
+                    acc = __builtin_amdgcn_sad_u8(x, y, acc);
+                    rv[u][w4].w = (int)acc;
                 }
+                const int t = tid + u * kTileThreads;
+                if (t < kTileRH * kRunsPerRow) carry[t] = (int)acc;
             }
         }
         for (int i = tid; i < kIP; i += kTileThreads) I[i] = 0;                                    // integral row 0
         for (int r = tid; r <= kTileRH; r += kTileThreads) I[r * kIP + kIntegralColOffset] = 0;     // logical column 0
-        __syncthreads();
-        // 2b: per row, exclusive prefix of the run totals
-        int32_t *rowcarry = reinterpret_cast<int32_t *>(scratch);
+        __syncthreads();  TILE_STAMP(6);
+        // 2b: per row, exclusive prefix of its 12 run totals (in place)
         if (tid < kTileRH) {
             int tot[kRunsPerRow];
 #pragma unroll
-            for (int q = 0; q < kRunsPerRow; ++q) tot[q] = I[(tid + 1) * kIP + kIntegralColOffset + 16 * q + 16];
+            for (int q = 0; q < kRunsPerRow; ++q) tot[q] = carry[tid * kRunsPerRow + q];
             int run = 0;
 #pragma unroll
             for (int q = 0; q < kRunsPerRow; ++q) {
-                rowcarry[tid * kRunsPerRow + q] = run;
+                carry[tid * kRunsPerRow + q] = run;
                 run += tot[q];
             }
         }
-        __syncthreads();
-        // 2c: column pass in blocks of 20 rows, adding the row carries on the way
-        for (int t = tid; t < kColBlocks * kTileRW; t += kTileThreads) {
-            const int j = t / kTileRW, c = t - j * kTileRW;  // logical column c + 1
-            int32_t *e = I + (j * kColBlockRows + 1) * kIP + kIntegralColOffset + 1 + c;
-            const int32_t *rc = rowcarry + j * kColBlockRows * kRunsPerRow + (c >> 4);
-            int v[kColBlockRows];
+        __syncthreads();  TILE_STAMP(7);
+        // 2c: finish the row pass: add the run's carry, one 16-byte LDS store per 4 pixels
 #pragma unroll
-            for (int r = 0; r < kColBlockRows; ++r) v[r] = e[r * kIP] + rc[r * kRunsPerRow];
+        for (int u = 0; u < kRunIters; ++u) {
+            const int t = tid + u * kTileThreads;
+            if (t < kTileRH * kRunsPerRow) {
+                const int r = t / kRunsPerRow, q = t - r * kRunsPerRow;
+                const int add = carry[t];
+                int4 *dst = reinterpret_cast<int4 *>(I + (r + 1) * kIP + 4 + 16 * q);
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4)
+                    dst[w4] = make_int4(rv[u][w4].x + add, rv[u][w4].y + add, rv[u][w4].z + add, rv[u][w4].w + add);
+            }
+        }
+        __syncthreads();  TILE_STAMP(8);
+        // 2d: column pass.  A thread owns 20-row column segments: running sum in registers, segment total -> LDS
+        constexpr int kColTasks = kColBlocks * kTileRW;
+        constexpr int kColIters = (kColTasks + kTileThreads - 1) / kTileThreads;
+        int cv[kColIters][kColBlockRows];
+#pragma unroll
+        for (int u = 0; u < kColIters; ++u) {
+            const int t = min(tid + u * kTileThreads, kColTasks - 1);
+            const int j = t / kTileRW, c = t - j * kTileRW;  // logical column c + 1
+            const int32_t *e = I + (j * kColBlockRows + 1) * kIP + kIntegralColOffset + 1 + c;
+#pragma unroll
+            for (int r = 0; r < kColBlockRows; ++r) cv[u][r] = e[r * kIP];
             int acc = 0;
 #pragma unroll
             for (int r = 0; r < kColBlockRows; ++r) {
-                acc += v[r];
-                e[r * kIP] = acc;
+                acc += cv[u][r];
+                cv[u][r] = acc;
             }
+            if (tid + u * kTileThreads < kColTasks) carry[t] = acc;
         }
-        __syncthreads();
-        // 2d: per column, exclusive prefix of the block totals
-        int32_t *colcarry = reinterpret_cast<int32_t *>(scratch);
+        __syncthreads();  TILE_STAMP(9);
+        // 2e: per column, exclusive prefix of its 8 segment totals (in place)
         if (tid < kTileRW) {
             int tot[kColBlocks];
 #pragma unroll
-            for (int j = 0; j < kColBlocks; ++j) tot[j] = I[(j + 1) * kColBlockRows * kIP + kIntegralColOffset + 1 + tid];
+            for (int j = 0; j < kColBlocks; ++j) tot[j] = carry[j * kTileRW + tid];
             int run = 0;
 #pragma unroll
             for (int j = 0; j < kColBlocks; ++j) {
-                colcarry[j * kTileRW + tid] = run;
+                carry[j * kTileRW + tid] = run;
                 run += tot[j];
             }
         }
-        __syncthreads();
-        // 2e: add the block carries
-        for (int t = tid; t < (kColBlocks - 1) * kTileRW; t += kTileThreads) {
-            const int j = 1 + t / kTileRW, c = t % kTileRW;
-            const int add = colcarry[j * kTileRW + c];
-            int32_t *e = I + (j * kColBlockRows + 1) * kIP + kIntegralColOffset + 1 + c;
-            int v[kColBlockRows];
+        __syncthreads();  TILE_STAMP(10);
+        // 2f: finish the column pass
 #pragma unroll
-            for (int r = 0; r < kColBlockRows; ++r) v[r] = e[r * kIP];
+        for (int u = 0; u < kColIters; ++u) {
+            const int t = tid + u * kTileThreads;
+            if (t < kColTasks) {
+                const int j = t / kTileRW, c = t - j * kTileRW;
+                const int add = carry[t];
+                int32_t *e = I + (j * kColBlockRows + 1) * kIP + kIntegralColOffset + 1 + c;
 #pragma unroll
-            for (int r = 0; r < kColBlockRows; ++r) e[r * kIP] = v[r] + add;
+                for (int r = 0; r < kColBlockRows; ++r) e[r * kIP] = cv[u][r] + add;
+            }
         }
-        __syncthreads();
+        __syncthreads();  TILE_STAMP(11);
     }
 
     // ================= stage 3: FREAK on the difference image
@@ -490,7 +541,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
                 k.theta = 0;
                 kf[tid] = k;
             }
-            __syncthreads();
+            __syncthreads();  TILE_STAMP(12);
             const int n_box = nb * kNbPoints;
             if (st.orientation_normalized) {
                 // F1: un-rotated box means; pattern points fetched for all of a thread's tasks before any is used
@@ -515,7 +566,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
                         }
                     }
                 }
-                __syncthreads();
+                __syncthreads();  TILE_STAMP(13);
                 // F2: 8 lanes per keypoint share the 45 orientation pairs; theta
                 for (int t = tid; t < nb * kOrientLanes; t += kTileThreads) {
                     const int kk = t / kOrientLanes, sub = t % kOrientLanes;
@@ -527,8 +578,8 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
                         if (m < kNbOrientPairs) {
                             const OrientPair op = st.orient[m];
                             const int delta = (int)v[op.i] - (int)v[op.j];
-                            direction0 += delta * op.weight_dx / 2048;  // C division: truncates toward zero, per term
-                            direction1 += delta * op.weight_dy / 2048;
+                            direction0 += __mul24(delta, op.weight_dx) / 2048;  // C division: truncates toward zero, per term
+                            direction1 += __mul24(delta, op.weight_dy) / 2048;
                         }
                     }
 #pragma unroll
@@ -536,14 +587,14 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
                         direction0 += __shfl_xor(direction0, o);
                         direction1 += __shfl_xor(direction1, o);
                     }
-                    const int theta = theta_index(direction0, direction1);
+                    const int theta = theta_index(s_theta, direction0, direction1);
                     if (sub == 0) {
                         kf[kk].theta = (int16_t)theta;
                         if (a.out_info)
                             *reinterpret_cast<int4 *>(a.out_info + (out_base + kf[kk].g) * 4) = make_int4(kf[kk].idx, theta, direction0, direction1);
                     }
                 }
-                __syncthreads();
+                __syncthreads();  TILE_STAMP(14);
             } else if (a.out_info && tid < nb) {
                 *reinterpret_cast<int4 *>(a.out_info + (out_base + kf[tid].g) * 4) = make_int4(kf[tid].idx, 0, 0, 0);
             }
@@ -569,7 +620,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
                     }
                 }
             }
-            __syncthreads();
+            __syncthreads();  TILE_STAMP(15);
             // F4: lane = descriptor bit
             {
                 const int pi = st.bit_pair_i[lane], pj = st.bit_pair_j[lane];
@@ -591,7 +642,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
                     }
                 }
             }
-            __syncthreads();
+            __syncthreads();  TILE_STAMP(16);
         }
     }
 }
@@ -617,11 +668,14 @@ int launch_bin(const BinArgs &a, void *stream)
 int launch_tile(const TileArgs &a, void *stream)
 {
     if (a.mip_n > 64 * kMipIters || a.mip_stride < a.mip_n) return (int)hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kTileLdsBytes);
+    const void *fn = a.stamps ? reinterpret_cast<const void *>(&tile_kernel<true>) : reinterpret_cast<const void *>(&tile_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kTileLdsBytes);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(tile_kernel, dim3(a.tiles_x * a.tiles_y, a.n_pairs), dim3(kTileThreads), kTileLdsBytes,
-                       static_cast<hipStream_t>(stream), a);
+    const dim3 grid(a.tiles_x * a.tiles_y, a.n_pairs);
+    if (a.stamps)
+        hipLaunchKernelGGL(tile_kernel<true>, grid, dim3(kTileThreads), kTileLdsBytes, static_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(tile_kernel<false>, grid, dim3(kTileThreads), kTileLdsBytes, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 
