@@ -47,7 +47,9 @@ constexpr int kOffScratch = kOffPrev + kTileCW * kTileCH;
 constexpr int kScratchBytes = kTileRH * kRunsPerRow * 4;  // 7680: row carries; also column carries / per-keypoint arrays
 constexpr int kOffSmall = kOffScratch + kScratchBytes;
 constexpr int kOffTheta = kOffSmall + (int)((sizeof(SmallTables) + 15) / 16 * 16);
-constexpr int kTileLdsBytes = kOffTheta + kThetaBounds * (int)sizeof(ThetaBound);
+constexpr int kOffKp = kOffTheta + kThetaBounds * (int)sizeof(ThetaBound);   // the batch's keypoint records
+constexpr int kOffBits = kOffKp + kBatch * (int)sizeof(SortedKp);            // 8 descriptor bytes per keypoint, staged
+constexpr int kTileLdsBytes = kOffBits + kBatch * 8;
 static_assert(kOffCur % 16 == 0 && kOffPrev % 16 == 0 && kOffScratch % 16 == 0 && kOffSmall % 16 == 0, "LDS carve alignment");
 static_assert(kTileLdsBytes <= 160 * 1024, "tile kernel LDS budget");
 static_assert(kTileRW % 16 == 0 && kTileRH % kColBlocks == 0, "region blocking");
@@ -295,7 +297,12 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
     ThetaBound *s_theta = reinterpret_cast<ThetaBound *>(lds + kOffTheta);
     for (int i = tid; i < kThetaBounds; i += kTileThreads) s_theta[i] = a.theta[i];
 
-    // ================= stage 0: gray tiles (tile + 8-px rim), 8 bytes per lane; all loads first, then the stores
+    SortedKp *s_kp = reinterpret_cast<SortedKp *>(lds + kOffKp);
+    uint2 *s_bits = reinterpret_cast<uint2 *>(lds + kOffBits);
+    const bool one_batch = n_tile_kp <= kBatch;
+
+    // ================= stage 0: gray tiles (tile + 8-px rim), 8 bytes per lane; all loads first, then the stores.
+    // The first batch's keypoint records ride along (both descriptor stages read them from LDS).
     {
         uint2 c[kGrayIters], p[kGrayIters];
 #pragma unroll
@@ -308,6 +315,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
             c[u] = load_px8(cur + ro, gx, W, row_ok, fast8);
             p[u] = load_px8(prev + ro, gx, W, row_ok, fast8);
         }
+        if (tid < min(kBatch, n_tile_kp)) s_kp[tid] = tile_kps[tid];
 #pragma unroll
         for (int u = 0; u < kGrayIters; ++u) {
             const int t = tid + u * kTileThreads;
@@ -323,11 +331,32 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
     {
         uint8_t *p19 = lds + kOffP19;
         KpMip *km = reinterpret_cast<KpMip *>(scratch);
-        int *s_flags = reinterpret_cast<int *>(scratch + kBatch * sizeof(KpMip));  // [0] = first L, [1] = mixed sides
-        // per-lane constants of the sampling passes: where each sampled pixel goes, which frame it comes from
-        int pos[kMipIters];
+        int *s_flags = reinterpret_cast<int *>(scratch + kBatch * sizeof(KpMip));  // [0] = mixed ROI sides in the batch
+        // per-lane constants of the sampling passes: where each sampled pixel goes, and (once the ROI side is known)
+        // the LDS byte offsets of its two source rows relative to the ROI origin, frame base included
+        int pos[kMipIters], a0[kMipIters], a1[kMipIters], e0[kMipIters], e1[kMipIters];
+        int c0x[kMipIters], c1x[kMipIters], c0y[kMipIters], c1y[kMipIters];
 #pragma unroll
         for (int u = 0; u < kMipIters; ++u) pos[u] = a.mip_pos[min(lane + 64 * u, a.mip_stride - 1)];
+        auto load_samples = [&](int L) {
+            const MipSample *tab = a.mip_samples + (int64_t)L * a.mip_stride;
+#pragma unroll
+            for (int u = 0; u < kMipIters; ++u) {
+                const MipSample sm = tab[min(lane + 64 * u, a.mip_stride - 1)];
+                const int frame = (lane + 64 * u) < a.mip_n_cur ? kOffCur : kOffPrev;
+                a0[u] = frame + sm.off00;
+                a1[u] = frame + sm.off10;
+                e0[u] = frame + sm.off01;
+                e1[u] = frame + sm.off11;
+                // The four bytes are fetched with four ds_read_u8.  Hide from the optimiser that e = a + 1 in most
+                // lanes: it would fuse the pairs into ds_read_u16 at odd addresses, which the LDS replays slowly.
+                asm volatile("" : "+v"(e0[u]), "+v"(e1[u]));
+                c0x[u] = sm.c0x;
+                c1x[u] = sm.c1x;
+                c0y[u] = sm.c0y;
+                c1y[u] = sm.c1y;
+            }
+        };
         // per-lane constants of the bit pass: lane = 8*centre + offset (MoFREAKUtilities.cpp:56-70, 308-316)
         const int mc = lane >> 3, mi = lane & 7;
         const int mcx = (0xDDD99555u >> (4 * mc)) & 15, mcy = (0xD95D5D95u >> (4 * mc)) & 15;
@@ -335,14 +364,18 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
         const int base_c = (mcy - 1) * kPatch + (mcx - 1);
         const int base_p = kP19Pad + (mcy + mdy - 1) * kPatch + (mcx + mdx - 1);
         const int cw = base_c >> 2, cs = base_c & 3, pw = base_p >> 2, ps = base_p & 3;  // covering dword, byte shift
-        MipSample sm[kMipIters];
         int have_L = -1;
         for (int b0 = 0; b0 < n_tile_kp; b0 += kBatch) {
             const int nb = min(kBatch, n_tile_kp - b0);
-            if (tid < 2) s_flags[tid] = 0;
+            if (b0 > 0) {  // further batches of a crowded tile: fetch their records
+                __syncthreads();
+                if (tid < nb) s_kp[tid] = tile_kps[b0 + tid];
+            }
+            if (tid == 0) s_flags[0] = 0;
             __syncthreads();  TILE_STAMP(1);
+            const int L0 = (int)ceilf(s_kp[0].size);
             if (tid < nb) {
-                const SortedKp kp = tile_kps[b0 + tid];
+                const SortedKp kp = s_kp[tid];
                 const int x_i = (int)kp.x, y_i = (int)kp.y;                    // :460 float -> int parameters
                 const int half = ((int)kp.size) / 2, L = (int)ceilf(kp.size);  // :293-295
                 KpMip m;
@@ -351,62 +384,94 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
                 m.L = (uint8_t)L;
                 m.pad = 0;
                 km[tid] = m;
-                if (tid == 0) s_flags[0] = L;
+                if (L != L0) s_flags[0] = 1;
             }
             __syncthreads();  TILE_STAMP(2);
-            if (tid < nb && km[tid].L != s_flags[0]) s_flags[1] = 1;
-            __syncthreads();  TILE_STAMP(3);
-            const bool uniform = s_flags[1] == 0;
-            if (uniform && s_flags[0] != have_L) {  // one ROI side in the batch (the usual case): samples stay in registers
-                have_L = s_flags[0];
-                const MipSample *tab = a.mip_samples + (int64_t)have_L * a.mip_stride;
-#pragma unroll
-                for (int u = 0; u < kMipIters; ++u) sm[u] = tab[min(lane + 64 * u, a.mip_stride - 1)];
+            const bool uniform = s_flags[0] == 0;
+            if (uniform && L0 != have_L) {  // one ROI side in the batch (the usual case): samples stay in registers
+                have_L = L0;
+                load_samples(L0);
             }
-            // the pixels of the two 19x19 resamples that the MIP reads
-            for (int kk = wave; kk < nb; kk += kTileWaves) {
-                const KpMip m = km[kk];
-                if (!uniform && m.L != have_L) {
-                    have_L = m.L;
-                    const MipSample *tab = a.mip_samples + (int64_t)have_L * a.mip_stride;
+            // Per wave, two keypoints at a time (their LDS reads are issued together, so one's latency hides under
+            // the other's arithmetic): the sampled pixels of the two 19x19 resamples -> LDS, then -- same wave, so
+            // only a wave-level sync -- lane = 8*centre + offset, strip SSD, ballot.
+            for (int kk = wave; kk < nb; kk += 2 * kTileWaves) {
+                const int kk2 = kk + kTileWaves;
+                const bool two = kk2 < nb;
+                const KpMip m = km[kk], m2 = km[two ? kk2 : kk];
+                if (!uniform) {  // mixed ROI sides: rare; one keypoint at a time, reloading the samples when the side changes
+                    for (int h = 0; h < (two ? 2 : 1); ++h) {
+                        const KpMip mm = h ? m2 : m;
+                        if (mm.L != have_L) {
+                            have_L = mm.L;
+                            load_samples(mm.L);
+                        }
+                        uint8_t *dst = p19 + (h ? kk2 : kk) * (2 * kP19Pad);
 #pragma unroll
-                    for (int u = 0; u < kMipIters; ++u) sm[u] = tab[min(lane + 64 * u, a.mip_stride - 1)];
+                        for (int u = 0; u < kMipIters; ++u) {
+                            const int t0 = __mul24((int)lds[a0[u] + mm.roi_off], c0x[u]) + __mul24((int)lds[e0[u] + mm.roi_off], c1x[u]);
+                            const int t1 = __mul24((int)lds[a1[u] + mm.roi_off], c0x[u]) + __mul24((int)lds[e1[u] + mm.roi_off], c1x[u]);
+                            const int px = ((__mul24(c0y[u], t0 >> 4) >> 16) + (__mul24(c1y[u], t1 >> 4) >> 16) + 2) >> 2;
+                            if (lane + 64 * u < a.mip_n) dst[pos[u]] = (uint8_t)px;
+                        }
+                    }
+                } else {
+                    int s00[2][kMipIters], s01[2][kMipIters], s10[2][kMipIters], s11[2][kMipIters];
+#pragma unroll
+                    for (int u = 0; u < kMipIters; ++u) {
+                        s00[0][u] = lds[a0[u] + m.roi_off];
+                        s01[0][u] = lds[e0[u] + m.roi_off];
+                        s10[0][u] = lds[a1[u] + m.roi_off];
+                        s11[0][u] = lds[e1[u] + m.roi_off];
+                        s00[1][u] = lds[a0[u] + m2.roi_off];
+                        s01[1][u] = lds[e0[u] + m2.roi_off];
+                        s10[1][u] = lds[a1[u] + m2.roi_off];
+                        s11[1][u] = lds[e1[u] + m2.roi_off];
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        uint8_t *dst = p19 + (h ? kk2 : kk) * (2 * kP19Pad);
+#pragma unroll
+                        for (int u = 0; u < kMipIters; ++u) {
+                            // every factor fits 24 bits: full-rate v_mul_i32_i24 / v_mad_i32_i24
+                            const int t0 = __mul24(s00[h][u], c0x[u]) + __mul24(s01[h][u], c1x[u]);
+                            const int t1 = __mul24(s10[h][u], c0x[u]) + __mul24(s11[h][u], c1x[u]);
+                            const int px = ((__mul24(c0y[u], t0 >> 4) >> 16) + (__mul24(c1y[u], t1 >> 4) >> 16) + 2) >> 2;
+                            if ((h == 0 || two) && lane + 64 * u < a.mip_n) dst[pos[u]] = (uint8_t)px;
+                        }
+                    }
                 }
-                uint8_t *dst = p19 + kk * (2 * kP19Pad);
-                int px[kMipIters];
-#pragma unroll
-                for (int u = 0; u < kMipIters; ++u) {
-                    const uint8_t *src = ((lane + 64 * u) < a.mip_n_cur ? s_cur : s_prev) + m.roi_off;
-                    // every factor fits 24 bits: full-rate v_mul_i32_i24 / v_mad_i32_i24
-                    const int t0 = __mul24((int)src[sm[u].off00], sm[u].c0x) + __mul24((int)src[sm[u].off01], sm[u].c1x);
-                    const int t1 = __mul24((int)src[sm[u].off10], sm[u].c0x) + __mul24((int)src[sm[u].off11], sm[u].c1x);
-                    px[u] = ((__mul24((int)sm[u].c0y, t0 >> 4) >> 16) + (__mul24((int)sm[u].c1y, t1 >> 4) >> 16) + 2) >> 2;
-                }
-#pragma unroll
-                for (int u = 0; u < kMipIters; ++u)
-                    if (lane + 64 * u < a.mip_n) dst[pos[u]] = (uint8_t)px[u];
-            }
-            __syncthreads();  TILE_STAMP(4);
-            for (int kk = wave; kk < nb; kk += kTileWaves) {
+                wave_lds_sync();
                 // the two 9-byte strips sit at arbitrary byte offsets: fetch the covering aligned dwords (a byte-wise
                 // formulation lets the compiler fuse the loads into misaligned ds_read_b64s, 64 cycles each) and
                 // shift the strips out; SSD = sum c^2 + sum p^2 - 2 sum c*p with packed u8 dot products
-                const uint32_t *b32 = reinterpret_cast<const uint32_t *>(p19 + kk * (2 * kP19Pad));
-                const uint32_t cd0 = b32[cw], cd1 = b32[cw + 1], cd2 = b32[cw + 2];
-                const uint32_t pd0 = b32[pw], pd1 = b32[pw + 1], pd2 = b32[pw + 2];
-                const uint32_t c0 = __builtin_amdgcn_alignbyte(cd1, cd0, cs), c1 = __builtin_amdgcn_alignbyte(cd2, cd1, cs);
-                const uint32_t c2 = (cd2 >> (8 * cs)) & 0xffu;
-                const uint32_t p0 = __builtin_amdgcn_alignbyte(pd1, pd0, ps), p1 = __builtin_amdgcn_alignbyte(pd2, pd1, ps);
-                const uint32_t p2 = (pd2 >> (8 * ps)) & 0xffu;
-                const uint32_t sq = __builtin_amdgcn_udot4(c0, c0, __builtin_amdgcn_udot4(c1, c1, c2 * c2, false), false) +
-                                    __builtin_amdgcn_udot4(p0, p0, __builtin_amdgcn_udot4(p1, p1, p2 * p2, false), false);
-                const uint32_t cross = __builtin_amdgcn_udot4(c0, p0, __builtin_amdgcn_udot4(c1, p1, c2 * p2, false), false);
-                const int ssd = (int)(sq - 2u * cross);
-                const uint64_t mot = __ballot(ssd > st.mip_theta);
-                if (lane == 0)
-                    *reinterpret_cast<uint2 *>(a.out_desc + (out_base + km[kk].g) * 16 + 8) = make_uint2((uint32_t)mot, (uint32_t)(mot >> 32));
+                uint32_t cd[2][3], pd[2][3];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t *b32 = reinterpret_cast<const uint32_t *>(p19 + ((h && two) ? kk2 : kk) * (2 * kP19Pad));
+#pragma unroll
+                    for (int w3 = 0; w3 < 3; ++w3) {
+                        cd[h][w3] = b32[cw + w3];
+                        pd[h][w3] = b32[pw + w3];
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t c0 = __builtin_amdgcn_alignbyte(cd[h][1], cd[h][0], cs), c1 = __builtin_amdgcn_alignbyte(cd[h][2], cd[h][1], cs);
+                    const uint32_t c2 = (cd[h][2] >> (8 * cs)) & 0xffu;
+                    const uint32_t p0 = __builtin_amdgcn_alignbyte(pd[h][1], pd[h][0], ps), p1 = __builtin_amdgcn_alignbyte(pd[h][2], pd[h][1], ps);
+                    const uint32_t p2 = (pd[h][2] >> (8 * ps)) & 0xffu;
+                    const uint32_t sq = __builtin_amdgcn_udot4(c0, c0, __builtin_amdgcn_udot4(c1, c1, c2 * c2, false), false) +
+                                        __builtin_amdgcn_udot4(p0, p0, __builtin_amdgcn_udot4(p1, p1, p2 * p2, false), false);
+                    const uint32_t cross = __builtin_amdgcn_udot4(c0, p0, __builtin_amdgcn_udot4(c1, p1, c2 * p2, false), false);
+                    const int ssd = (int)(sq - 2u * cross);
+                    const uint64_t mot = __ballot(ssd > st.mip_theta);
+                    if (lane == 0 && (h == 0 || two)) s_bits[h ? kk2 : kk] = make_uint2((uint32_t)mot, (uint32_t)(mot >> 32));
+                }
             }
             __syncthreads();  TILE_STAMP(5);
+            // motion bytes out: one 8-byte store per keypoint, issued side by side by nb threads
+            if (tid < nb) *reinterpret_cast<uint2 *>(a.out_desc + (out_base + km[tid].g) * 16 + 8) = s_bits[tid];
         }
     }
 
@@ -531,8 +596,13 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
         KpFreak *kf = reinterpret_cast<KpFreak *>(scratch + kBatch * kVStride);
         for (int b0 = 0; b0 < n_tile_kp; b0 += kBatch) {
             const int nb = min(kBatch, n_tile_kp - b0);
+            if (!one_batch) {  // crowded tile: the records of this batch (a single batch still has them from stage 0)
+                __syncthreads();
+                if (tid < nb) s_kp[tid] = tile_kps[b0 + tid];
+                __syncthreads();
+            }
             if (tid < nb) {
-                const SortedKp kp = tile_kps[b0 + tid];
+                const SortedKp kp = s_kp[tid];
                 KpFreak k;
                 k.kx = kp.x;
                 k.ky = kp.y;
@@ -635,14 +705,15 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
                     else
                         bit = (int)(int8_t)va > (int)(int8_t)vb;
                     const uint64_t app = __ballot(bit);
-                    if (lane == 0) {
-                        const int64_t out_idx = out_base + kf[kk].g;
-                        *reinterpret_cast<uint2 *>(a.out_desc + out_idx * 16) = make_uint2((uint32_t)app, (uint32_t)(app >> 32));
-                        a.out_valid[out_idx] = 1;
-                    }
+                    if (lane == 0) s_bits[kk] = make_uint2((uint32_t)app, (uint32_t)(app >> 32));
                 }
             }
             __syncthreads();  TILE_STAMP(16);
+            if (tid < nb) {  // appearance bytes and the validity flag out, side by side
+                const int64_t out_idx = out_base + kf[tid].g;
+                *reinterpret_cast<uint2 *>(a.out_desc + out_idx * 16) = s_bits[tid];
+                a.out_valid[out_idx] = 1;
+            }
         }
     }
 }
