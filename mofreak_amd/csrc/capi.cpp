@@ -300,7 +300,7 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
         if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("binning launch: ") + hipGetErrorString((hipError_t)e));
         if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(span.ev[1], ctx->stream));
 
-        const int kMaxGridY = 32768;
+        const int kMaxGridY = 32768;  // pairs per tile_kernel launch (keeps the 1-D grid well inside 2^28 work items)
         for (int p0 = 0; p0 < n_pairs; p0 += kMaxGridY) {
             const int np = std::min(kMaxGridY, n_pairs - p0);
             TileArgs t;

@@ -49,7 +49,8 @@ constexpr int kOffSmall = kOffScratch + kScratchBytes;
 constexpr int kOffTheta = kOffSmall + (int)((sizeof(SmallTables) + 15) / 16 * 16);
 constexpr int kOffKp = kOffTheta + kThetaBounds * (int)sizeof(ThetaBound);   // the batch's keypoint records
 constexpr int kOffBits = kOffKp + kBatch * (int)sizeof(SortedKp);            // 8 descriptor bytes per keypoint, staged
-constexpr int kTileLdsBytes = kOffBits + kBatch * 8;
+constexpr int kOffMot = kOffBits + kBatch * 8;                               // motion bytes kept for the fused store
+constexpr int kTileLdsBytes = kOffMot + kBatch * 8;
 static_assert(kOffCur % 16 == 0 && kOffPrev % 16 == 0 && kOffScratch % 16 == 0 && kOffSmall % 16 == 0, "LDS carve alignment");
 static_assert(kTileLdsBytes <= 160 * 1024, "tile kernel LDS budget");
 static_assert(kTileRW % 16 == 0 && kTileRH % kColBlocks == 0, "region blocking");
@@ -269,7 +270,14 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
     unsigned long long last_stamp = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int n_tiles = a.tiles_x * a.tiles_y;
-    const int tile = blockIdx.x, pair = blockIdx.y;
+    // 1-D grid, remapped so that each XCD (workgroups are dealt round-robin over the 8 XCDs) walks a contiguous range
+    // of (pair, tile) work items: neighbouring tiles share halo pixels, and this way they share an L2.  Placement is
+    // a speed matter only; nothing below depends on it.
+    const int n_work = n_tiles * a.n_pairs;
+    const int per_xcd = (n_work + 7) / 8;
+    const int work = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (work >= n_work) return;
+    const int pair = work / n_tiles, tile = work - pair * n_tiles;
     const int key = a.kp_offsets ? pair * n_tiles + tile : tile;
     const int kp_begin = a.tile_start[key];
     const int n_tile_kp = a.tile_start[key + 1] - kp_begin;
@@ -299,6 +307,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
 
     SortedKp *s_kp = reinterpret_cast<SortedKp *>(lds + kOffKp);
     uint2 *s_bits = reinterpret_cast<uint2 *>(lds + kOffBits);
+    uint2 *s_mot = reinterpret_cast<uint2 *>(lds + kOffMot);
     const bool one_batch = n_tile_kp <= kBatch;
 
     // ================= stage 0: gray tiles (tile + 8-px rim), 8 bytes per lane; all loads first, then the stores.
@@ -466,12 +475,13 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
                     const uint32_t cross = __builtin_amdgcn_udot4(c0, p0, __builtin_amdgcn_udot4(c1, p1, c2 * p2, false), false);
                     const int ssd = (int)(sq - 2u * cross);
                     const uint64_t mot = __ballot(ssd > st.mip_theta);
-                    if (lane == 0 && (h == 0 || two)) s_bits[h ? kk2 : kk] = make_uint2((uint32_t)mot, (uint32_t)(mot >> 32));
+                    if (lane == 0 && (h == 0 || two)) s_mot[h ? kk2 : kk] = make_uint2((uint32_t)mot, (uint32_t)(mot >> 32));
                 }
             }
             __syncthreads();  TILE_STAMP(5);
-            // motion bytes out: one 8-byte store per keypoint, issued side by side by nb threads
-            if (tid < nb) *reinterpret_cast<uint2 *>(a.out_desc + (out_base + km[tid].g) * 16 + 8) = s_bits[tid];
+            // a crowded tile (several batches) sends its motion bytes out now; the usual single batch keeps them in
+            // LDS for one 16-byte store per descriptor at the end of stage 3
+            if (!one_batch && tid < nb) *reinterpret_cast<uint2 *>(a.out_desc + (out_base + km[tid].g) * 16 + 8) = s_mot[tid];
         }
     }
 
@@ -709,9 +719,15 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
                 }
             }
             __syncthreads();  TILE_STAMP(16);
-            if (tid < nb) {  // appearance bytes and the validity flag out, side by side
+            if (tid < nb) {  // descriptor and validity flag out, side by side
                 const int64_t out_idx = out_base + kf[tid].g;
-                *reinterpret_cast<uint2 *>(a.out_desc + out_idx * 16) = s_bits[tid];
+                const uint2 app = s_bits[tid];
+                if (one_batch) {
+                    const uint2 mot = s_mot[tid];
+                    *reinterpret_cast<uint4 *>(a.out_desc + out_idx * 16) = make_uint4(app.x, app.y, mot.x, mot.y);
+                } else {
+                    *reinterpret_cast<uint2 *>(a.out_desc + out_idx * 16) = app;
+                }
                 a.out_valid[out_idx] = 1;
             }
         }
@@ -742,7 +758,9 @@ int launch_tile(const TileArgs &a, void *stream)
     const void *fn = a.stamps ? reinterpret_cast<const void *>(&tile_kernel<true>) : reinterpret_cast<const void *>(&tile_kernel<false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kTileLdsBytes);
     if (e != hipSuccess) return (int)e;
-    const dim3 grid(a.tiles_x * a.tiles_y, a.n_pairs);
+    const int64_t n_work = (int64_t)a.tiles_x * a.tiles_y * a.n_pairs;
+    if (n_work > (int64_t)1 << 28) return (int)hipErrorInvalidValue;
+    const dim3 grid((unsigned)(((n_work + 7) / 8) * 8));
     if (a.stamps)
         hipLaunchKernelGGL(tile_kernel<true>, grid, dim3(kTileThreads), kTileLdsBytes, static_cast<hipStream_t>(stream), a);
     else
