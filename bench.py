@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--config", default="C3", help="synthetic config (C3 = the metric's: 1080p, 8-px grid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=64)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL); 'gloo' + "
+                    "--share-device rehearses the N > 1 control flow on a one-GPU box")
+    ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
     args = ap.parse_args()
 
     import torch
@@ -79,9 +82,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    on_device = args.backend == "nccl"  # gloo moves its (small) control tensors and the gathered rows through the host
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if on_device:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     cfg = synth.CONFIGS[args.config]
     W, H = cfg["W"], cfg["H"]
@@ -127,7 +136,7 @@ def main():
     ctx.set_profiling(False)
     ctx.check_status()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_device else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_valid = int(valid.sum().item())
@@ -141,7 +150,7 @@ def main():
     if world > 1:
         fence()
         tg = time.perf_counter()
-        allrows, counts = harness.gather_rows(rows, n_rows, dst=0)
+        allrows, counts = harness.gather_rows(rows if on_device else rows.cpu(), n_rows, dst=0)
         fence()
         gather_ms = (time.perf_counter() - tg) * 1e3
         if rank == 0:
