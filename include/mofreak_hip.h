@@ -175,6 +175,13 @@ int mofreak_extract_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W
                            mofreak_row *rows_out, int64_t rows_capacity, int64_t *n_rows_out,
                            unsigned flags);
 
+/* ------------------------------------------------------------------ frame preparation */
+/* cv::cvtColor(frame, frame, CV_BGR2GRAY) on 8UC3 frames (MoFREAKUtilities.cpp:395, :410): interleaved B,G,R bytes,
+ * rows row_stride bytes apart, frames frame_stride bytes apart -> n_frames contiguous W x H gray frames, ready for
+ * mofreak_extract_stream.  OpenCV 2.4.x fixed point: (1868 B + 9617 G + 4899 R + 8192) >> 14. */
+int mofreak_bgr_to_gray(mofreak_ctx *ctx, const uint8_t *bgr, int W, int H, int64_t row_stride, int64_t frame_stride,
+                        int n_frames, uint8_t *gray_out, unsigned flags);
+
 /* ------------------------------------------------------------------ .mofreak text (host only) */
 /* MoFREAKUtilities::writeMoFREAKFeaturesToFile (MoFREAKUtilities.cpp:691-719), byte for byte.  Writes at
  * most cap bytes to buf (may be NULL) and always stores the full length in *needed. */

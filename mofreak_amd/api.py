@@ -31,7 +31,7 @@ assert ROW_DTYPE.itemsize == 32
 EXPORTS = [
     "mofreak_abi_version", "mofreak_default_params", "mofreak_create", "mofreak_destroy", "mofreak_last_error",
     "mofreak_set_stream", "mofreak_synchronize", "mofreak_reserve", "mofreak_check_status",
-    "mofreak_set_profiling", "mofreak_get_profile", "mofreak_set_path", "mofreak_get_tile_stamps",
+    "mofreak_set_profiling", "mofreak_get_profile", "mofreak_set_path", "mofreak_get_tile_stamps", "mofreak_bgr_to_gray",
     "mofreak_extract_pairs", "mofreak_compact_rows", "mofreak_extract_stream", "mofreak_format_rows",
     "mofreak_parse_rows", "mofreak_diff_integral", "mofreak_mip19", "mofreak_roi19", "mofreak_freak_info",
     "mofreak_theta_index", "mofreak_pattern_sizes", "mofreak_scale_index", "mofreak_table_pattern",
@@ -93,6 +93,7 @@ def load() -> C.CDLL:
     L.mofreak_set_path.argtypes = [vp, i32]
     L.mofreak_get_tile_stamps.argtypes = [vp, vp, i32, i32]
     L.mofreak_get_profile.argtypes = [vp, C.POINTER(Profile), i32]
+    L.mofreak_bgr_to_gray.argtypes = [vp, vp, i32, i32, i64, i64, i32, vp, C.c_uint]
     L.mofreak_extract_pairs.argtypes = [vp, vp, vp, i32, i32, i64, i64, i32, vp, vp, i64, vp, vp, C.c_uint]
     L.mofreak_compact_rows.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, i64, C.POINTER(i64), C.c_uint]
     L.mofreak_extract_stream.argtypes = [vp, vp, i32, i32, i32, vp, vp, i64, vp, i64, C.POINTER(i64), C.c_uint]
@@ -226,6 +227,24 @@ class Context:
         p = Profile()
         self._check(self._lib.mofreak_get_profile(self._h, C.byref(p), int(reset)))
         return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+    # ---- frame preparation
+    def bgr_to_gray(self, bgr, W, H, n_frames, gray_out, row_stride=None, frame_stride=None):
+        """bgr: (n_frames, H, W, 3) u8 numpy array or torch cuda tensor -> gray_out (n_frames, H, W)."""
+        host = _is_host(bgr, gray_out)
+        row_stride = 3 * W if row_stride is None else row_stride
+        frame_stride = row_stride * H if frame_stride is None else frame_stride
+        self._check(self._lib.mofreak_bgr_to_gray(self._h, _ptr(bgr), W, H, row_stride, frame_stride, n_frames, _ptr(gray_out),
+                                                  MEM_HOST if host else MEM_DEVICE))
+
+    def bgr_to_gray_host(self, bgr: np.ndarray) -> np.ndarray:
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        if bgr.ndim == 3:
+            bgr = bgr[None]
+        n, H, W, _ = bgr.shape
+        out = np.empty((n, H, W), np.uint8)
+        self.bgr_to_gray(bgr, W, H, n, out)
+        return out
 
     # ---- hot path
     def extract_pairs(self, cur, prev, W, H, n_pairs, kps, out_desc, out_valid, kp_offsets=None, n_kp=None,

@@ -816,6 +816,37 @@ int mofreak_extract_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W
     return MOFREAK_OK;
 }
 
+int mofreak_bgr_to_gray(mofreak_ctx *ctx, const uint8_t *bgr, int W, int H, int64_t row_stride, int64_t frame_stride,
+                        int n_frames, uint8_t *gray_out, unsigned flags)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    if (W <= 0 || H <= 0 || n_frames < 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "W, H must be positive and n_frames >= 0");
+    if (row_stride < (int64_t)3 * W) return fail(ctx, MOFREAK_ERR_BAD_ARG, "row_stride < 3*W");
+    if (n_frames == 0) return MOFREAK_OK;
+    if (!bgr || !gray_out) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null pointer");
+    if (n_frames > 1 && frame_stride == 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "frame_stride is 0");
+    NEED_DEVICE(ctx);
+    const bool host = (flags & MOFREAK_MEM_HOST) != 0;
+    const uint8_t *d_in = bgr;
+    uint8_t *d_out = gray_out;
+    const size_t out_bytes = (size_t)n_frames * W * H;
+    int rc;
+    if (host) {
+        const size_t span = (size_t)((int64_t)(n_frames - 1) * frame_stride + (int64_t)(H - 1) * row_stride + (int64_t)3 * W);
+        if ((rc = upload(ctx, ctx->stage[0], bgr, span))) return rc;
+        if ((rc = ensure(ctx, ctx->stage[3], out_bytes))) return rc;
+        d_in = static_cast<const uint8_t *>(ctx->stage[0].ptr);
+        d_out = static_cast<uint8_t *>(ctx->stage[3].ptr);
+    }
+    const int e = launch_bgr2gray(d_in, W, H, row_stride, frame_stride, n_frames, d_out, ctx->stream);
+    if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("bgr2gray launch: ") + hipGetErrorString((hipError_t)e));
+    if (host) {
+        HIP_TRY(ctx, hipMemcpyAsync(gray_out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MOFREAK_OK;
+}
+
 // ------------------------------------------------------------------ component entry points
 int mofreak_diff_integral(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, int W, int H, int64_t row_stride,
                           int64_t pair_stride, int n_pairs, int32_t *out, unsigned flags)

@@ -149,6 +149,8 @@ int launch_theta(const ThetaBound *tb, const int32_t *dirs, int64_t n, int32_t *
 int launch_compact(const CompactArgs &a, void *stream);
 int launch_bin(const BinArgs &a, void *stream);   // zeroes the counters, classifies, scans, scatters
 int launch_tile(const TileArgs &a, void *stream);
+int launch_bgr2gray(const uint8_t *bgr, int W, int H, int64_t row_stride, int64_t frame_stride, int n_frames, uint8_t *gray,
+                    void *stream);
 int launch_unpack_integral(const int32_t *src, int pitch, int W, int H, int n_pairs, int32_t *dst, void *stream);
 
 }  // namespace mofreak

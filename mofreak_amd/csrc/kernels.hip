@@ -112,6 +112,61 @@ __global__ __launch_bounds__(256) void unpack_integral_kernel(const int32_t *src
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// cv::cvtColor(CV_BGR2GRAY) on 8UC3 (MoFREAKUtilities.cpp:395, :410): Y = (1868 B + 9617 G + 4899 R + 8192) >> 14.
+// A streaming kernel (3 B in, 1 B out per pixel): a workgroup takes 4096 pixels of one row, pulls its 12 KB in with
+// fully coalesced 16-byte loads into LDS, and every thread then converts 16 pixels and stores 16 bytes.
+// ------------------------------------------------------------------------------------------------
+constexpr int kGrayPxPerBlock = 4096;
+
+__global__ __launch_bounds__(256) void bgr2gray_kernel(const uint8_t *bgr, int W, int H, int64_t row_stride, int64_t frame_stride,
+                                                       uint8_t *gray, int chunks_per_row)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t buf[kGrayPxPerBlock * 3];
+    const int chunk = blockIdx.x % chunks_per_row, y = blockIdx.x / chunks_per_row, frame = blockIdx.y;
+    const int x0 = chunk * kGrayPxPerBlock;
+    const int npx = min(kGrayPxPerBlock, W - x0);
+    const uint8_t *src = bgr + (int64_t)frame * frame_stride + (int64_t)y * row_stride + (int64_t)x0 * 3;
+    uint8_t *dst = gray + ((int64_t)frame * H + y) * W + x0;
+    const int nbytes = npx * 3;
+    if (((uintptr_t)src & 15) == 0) {
+        for (int i = threadIdx.x * 16; i < nbytes; i += 256 * 16) {
+            if (i + 16 <= nbytes)
+                *reinterpret_cast<uint4 *>(buf + i) = *reinterpret_cast<const uint4 *>(src + i);
+            else
+                for (int k = i; k < nbytes; ++k) buf[k] = src[k];
+        }
+    } else {
+        for (int i = threadIdx.x; i < nbytes; i += 256) buf[i] = src[i];
+    }
+    __syncthreads();
+    const int p0 = threadIdx.x * 16;
+    if (p0 >= npx) return;
+    uint32_t out[4] = {0, 0, 0, 0};
+    if (p0 + 16 <= npx) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(buf + p0 * 3), b = *reinterpret_cast<const uint4 *>(buf + p0 * 3 + 16),
+                    c = *reinterpret_cast<const uint4 *>(buf + p0 * 3 + 32);
+        const uint32_t w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int o = 3 * k;
+            const uint32_t B = (w[o >> 2] >> (8 * (o & 3))) & 0xff, G = (w[(o + 1) >> 2] >> (8 * ((o + 1) & 3))) & 0xff,
+                           R = (w[(o + 2) >> 2] >> (8 * ((o + 2) & 3))) & 0xff;
+            out[k >> 2] |= ((B * 1868u + G * 9617u + R * 4899u + 8192u) >> 14) << (8 * (k & 3));
+        }
+        if (((uintptr_t)(dst + p0) & 15) == 0) {
+            *reinterpret_cast<uint4 *>(dst + p0) = make_uint4(out[0], out[1], out[2], out[3]);
+            return;
+        }
+        for (int k = 0; k < 16; ++k) dst[p0 + k] = (uint8_t)(out[k >> 2] >> (8 * (k & 3)));
+        return;
+    }
+    for (int k = 0; p0 + k < npx; ++k) {
+        const uint8_t *q = buf + (p0 + k) * 3;
+        dst[p0 + k] = (uint8_t)((q[0] * 1868u + q[1] * 9617u + q[2] * 4899u + 8192u) >> 14);
+    }
+}
+
 constexpr int kRoiLdsSide = 32;  // ROIs up to 32x32 are staged in LDS; larger ones are sampled from global memory
 
 struct WaveScratch {
@@ -488,6 +543,18 @@ int launch_compact(const CompactArgs &a, void *stream)
     hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(256), 0, s, a.block_offsets, a.n_blocks);
     if (a.n_blocks > 0) {
         hipLaunchKernelGGL(compact_scatter_kernel, dim3(a.n_blocks), dim3(256), 0, s, a);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_bgr2gray(const uint8_t *bgr, int W, int H, int64_t row_stride, int64_t frame_stride, int n_frames, uint8_t *gray,
+                    void *stream)
+{
+    const int chunks = (W + kGrayPxPerBlock - 1) / kGrayPxPerBlock;
+    for (int f0 = 0; f0 < n_frames; f0 += 32768) {
+        const int nf = n_frames - f0 < 32768 ? n_frames - f0 : 32768;
+        hipLaunchKernelGGL(bgr2gray_kernel, dim3((unsigned)chunks * H, nf), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           bgr + (int64_t)f0 * frame_stride, W, H, row_stride, frame_stride, gray + (int64_t)f0 * W * H, chunks);
     }
     return (int)hipGetLastError();
 }

@@ -157,6 +157,15 @@ void mo_freak_destroy(mo_freak *f)
 }
 
 /* ---------------------------------------------------------------- frame prep */
+void mo_bgr2gray(const uint8_t *bgr, int W, int H, uint8_t *gray)
+{
+    /* cv::cvtColor(frame, frame, CV_BGR2GRAY) on 8UC3 (MoFREAKUtilities.cpp:395, :410), OpenCV 2.4.x
+     * imgproc/src/color.cpp RGB2Gray<uchar>: fixed point, B2Y = 1868, G2Y = 9617, R2Y = 4899, yuv_shift = 14,
+     * CV_DESCALE(x, n) = (x + (1 << (n-1))) >> n.  [UPSTREAM: not under /root/reference; parity unpinned] */
+    for (long i = 0; i < (long)W * H; ++i)
+        gray[i] = (uint8_t)((bgr[3 * i] * 1868 + bgr[3 * i + 1] * 9617 + bgr[3 * i + 2] * 4899 + (1 << 13)) >> 14);
+}
+
 void mo_absdiff(const uint8_t *a, const uint8_t *b, uint8_t *d, int W, int H)
 {
     for (long i = 0; i < (long)W * H; ++i) d[i] = (uint8_t)(a[i] > b[i] ? a[i] - b[i] : b[i] - a[i]);

@@ -69,6 +69,8 @@ void mo_freak_get_pairs(const mo_freak *f, uint8_t *out_ij);
 void mo_freak_get_orientation(const mo_freak *f, int *out);
 void mo_freak_get_pattern(const mo_freak *f, int scale, int rot, float *out);
 
+/* cv::cvtColor(BGR2GRAY) on 8UC3 (MoFREAKUtilities.cpp:395, :410). */
+void mo_bgr2gray(const uint8_t *bgr, int W, int H, uint8_t *gray);
 /* cv::absdiff on 8U (MoFREAKUtilities.cpp:414). */
 void mo_absdiff(const uint8_t *a, const uint8_t *b, uint8_t *d, int W, int H);
 /* cv::integral 8U -> 32S, (H+1)x(W+1), first row/col zero. */

@@ -46,6 +46,7 @@ def lib():
     L.mo_freak_get_pairs.argtypes = [C.c_void_p, u8p]
     L.mo_freak_get_orientation.argtypes = [C.c_void_p, i32p]
     L.mo_freak_get_pattern.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p]
+    L.mo_bgr2gray.argtypes = [u8p, C.c_int, C.c_int, u8p]
     L.mo_absdiff.argtypes = [u8p, u8p, u8p, C.c_int, C.c_int]
     L.mo_integral.argtypes = [u8p, C.c_int, C.c_int, i32p]
     L.mo_freak_scale_index.argtypes = [C.c_void_p, C.c_float]
@@ -153,6 +154,14 @@ class Freak:
         n = lib().mo_extract_stream(self.h, _u8(frames), T, W, H, gap, _f32(kps),
                                     offs.ctypes.data_as(C.POINTER(C.c_long)), rows.ctypes.data, cap)
         return rows[:n].copy()
+
+
+def bgr2gray(bgr):
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    H, W, _ = bgr.shape
+    out = np.empty((H, W), np.uint8)
+    lib().mo_bgr2gray(_u8(bgr), W, H, _u8(out))
+    return out
 
 
 def absdiff(a, b):

@@ -401,3 +401,10 @@ def test_extract_pair_feeds_diff_to_freak_and_gray_to_mip(oracle):
         c19 = py_resize(fr[5][y - 6:y + 6, x - 6:x + 6])
         p19 = py_resize(fr[0][y - 6:y + 6, x - 6:x + 6])
         assert mot.tolist() == [py_mip(c19, p19, cx, cy) for (cx, cy) in CENTERS]
+
+
+def test_bgr2gray_known_answers(oracle):
+    # OpenCV 2.4.x RGB2Gray<uchar>: (1868 B + 9617 G + 4899 R + 8192) >> 14; the weights sum to 2^14
+    px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 20, 30]]], np.uint8)
+    assert oracle.bgr2gray(px)[0].tolist() == [255, 0, 29, 150, 76, (10 * 1868 + 20 * 9617 + 30 * 4899 + 8192) >> 14]
+    assert 1868 + 9617 + 4899 == 1 << 14

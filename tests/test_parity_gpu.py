@@ -379,3 +379,38 @@ def test_crowded_tiles_and_tile_borders(gpu_ctx, oracle):
     desc, valid = gpu_ctx.extract_pairs_host(fr[5:6], fr[0:1], kps)
     want_d, want_v = oracle_pairs(oracle, fr[5:6], fr[0:1], kps)
     assert valid.all() and np.array_equal(valid, want_v) and np.array_equal(desc, want_d)
+
+
+# ------------------------------------------------------------------ frame preparation
+@pytest.mark.parametrize("W,H", [(320, 240), (1920, 1080), (37, 5), (4099, 3), (641, 2)])
+def test_bgr_to_gray_matches_oracle(gpu_ctx, oracle, W, H):
+    rng = np.random.default_rng(W + H)
+    bgr = rng.integers(0, 256, (3, H, W, 3), dtype=np.uint8)
+    bgr[0, 0, :8] = [[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [1, 1, 1], [254, 255, 253], [128, 127, 129]][: min(8, W)] if W >= 8 else bgr[0, 0, :8]
+    got = gpu_ctx.bgr_to_gray_host(bgr)
+    for f in range(3):
+        assert np.array_equal(got[f], oracle.bgr2gray(bgr[f]))
+    if W >= 8:
+        assert got[0, 0, 0] == 255 and got[0, 0, 1] == 0  # the three weights sum to 16384: white stays white
+
+
+def test_bgr_stream_to_rows(gpu_ctx, oracle):
+    """Colour frames in, .mofreak rows out: cvtColor on the device, then the frame loop (:391-489)."""
+    import torch
+    W, H, T = 320, 240, 9
+    gray = synth.synth_stack(T, W, H)
+    rng = np.random.default_rng(3)
+    bgr = np.stack([gray + rng.integers(-20, 21, gray.shape), gray, gray + rng.integers(-20, 21, gray.shape)], -1).clip(0, 255).astype(np.uint8)
+    d_bgr = torch.from_numpy(bgr).cuda()
+    d_gray = torch.empty((T, H, W), dtype=torch.uint8, device="cuda")
+    kps = synth.dense_grid(W, H, 16, 7.0, 23)
+    d_kps = torch.from_numpy(kps).cuda()
+    rows = torch.zeros((T - 5) * len(kps) * 32, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.bgr_to_gray(d_bgr, W, H, T, d_gray)
+    n = gpu_ctx.extract_stream(d_gray, T, W, H, d_kps, rows)
+    want_gray = np.stack([oracle.bgr2gray(b) for b in bgr])
+    assert np.array_equal(d_gray.cpu().numpy(), want_gray)
+    offs = np.arange(T - 5 + 1, dtype=np.int64) * len(kps)
+    want = oracle.Freak().extract_stream(want_gray, np.tile(kps, (T - 5, 1)), offs)
+    assert n == len(want) and rows.cpu().numpy()[: n * 32].tobytes() == want.tobytes()
