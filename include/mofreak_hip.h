@@ -182,6 +182,18 @@ int mofreak_extract_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W
 int mofreak_bgr_to_gray(mofreak_ctx *ctx, const uint8_t *bgr, int W, int H, int64_t row_stride, int64_t frame_stride,
                         int n_frames, uint8_t *gray_out, unsigned flags);
 
+/* ------------------------------------------------------------------ bag-of-words assignment */
+/* BagOfWordsRepresentation::bruteForceMatch (BagOfWordsRepresentation.cpp:22-37, hammingDistance :39-72): for each of
+ * n 16-byte descriptors the index of the nearest of n_codewords 16-byte codewords by bitwise Hamming distance, the
+ * FIRST minimum on ties.  valid may be NULL; descriptors with valid[k] == 0 get index -1.  n_codewords <= 10240. */
+int mofreak_bow_assign(mofreak_ctx *ctx, const uint8_t *desc16, const uint8_t *valid, int64_t n, const uint8_t *codebook16,
+                       int n_codewords, int32_t *out_index, unsigned flags);
+/* BagOfWordsRepresentation::buildHistogram (:74-138) on descriptors already in memory: one count per (valid)
+ * descriptor at its codeword, every bin divided by the sum in float.  *success_out (host, optional) is the reference's
+ * `success` flag (0: no descriptor, bins are 0).  Synchronises the stream. */
+int mofreak_bow_histogram(mofreak_ctx *ctx, const uint8_t *desc16, const uint8_t *valid, int64_t n, const uint8_t *codebook16,
+                          int n_codewords, float *hist_out, int32_t *success_out, unsigned flags);
+
 /* ------------------------------------------------------------------ .mofreak text (host only) */
 /* MoFREAKUtilities::writeMoFREAKFeaturesToFile (MoFREAKUtilities.cpp:691-719), byte for byte.  Writes at
  * most cap bytes to buf (may be NULL) and always stores the full length in *needed. */

@@ -31,7 +31,7 @@ assert ROW_DTYPE.itemsize == 32
 EXPORTS = [
     "mofreak_abi_version", "mofreak_default_params", "mofreak_create", "mofreak_destroy", "mofreak_last_error",
     "mofreak_set_stream", "mofreak_synchronize", "mofreak_reserve", "mofreak_check_status",
-    "mofreak_set_profiling", "mofreak_get_profile", "mofreak_set_path", "mofreak_get_tile_stamps", "mofreak_bgr_to_gray",
+    "mofreak_set_profiling", "mofreak_get_profile", "mofreak_set_path", "mofreak_get_tile_stamps", "mofreak_bgr_to_gray", "mofreak_bow_assign", "mofreak_bow_histogram",
     "mofreak_extract_pairs", "mofreak_compact_rows", "mofreak_extract_stream", "mofreak_format_rows",
     "mofreak_parse_rows", "mofreak_diff_integral", "mofreak_mip19", "mofreak_roi19", "mofreak_freak_info",
     "mofreak_theta_index", "mofreak_pattern_sizes", "mofreak_scale_index", "mofreak_table_pattern",
@@ -94,6 +94,8 @@ def load() -> C.CDLL:
     L.mofreak_get_tile_stamps.argtypes = [vp, vp, i32, i32]
     L.mofreak_get_profile.argtypes = [vp, C.POINTER(Profile), i32]
     L.mofreak_bgr_to_gray.argtypes = [vp, vp, i32, i32, i64, i64, i32, vp, C.c_uint]
+    L.mofreak_bow_assign.argtypes = [vp, vp, vp, i64, vp, i32, vp, C.c_uint]
+    L.mofreak_bow_histogram.argtypes = [vp, vp, vp, i64, vp, i32, vp, C.POINTER(C.c_int32), C.c_uint]
     L.mofreak_extract_pairs.argtypes = [vp, vp, vp, i32, i32, i64, i64, i32, vp, vp, i64, vp, vp, C.c_uint]
     L.mofreak_compact_rows.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, i64, C.POINTER(i64), C.c_uint]
     L.mofreak_extract_stream.argtypes = [vp, vp, i32, i32, i32, vp, vp, i64, vp, i64, C.POINTER(i64), C.c_uint]
@@ -245,6 +247,35 @@ class Context:
         out = np.empty((n, H, W), np.uint8)
         self.bgr_to_gray(bgr, W, H, n, out)
         return out
+
+    # ---- bag-of-words assignment
+    def bow_assign(self, desc, codebook, out_index, valid=None, n=None):
+        host = _is_host(desc, codebook, out_index, valid)
+        n = int(desc.shape[0]) if n is None else n
+        self._check(self._lib.mofreak_bow_assign(self._h, _ptr(desc), _ptr(valid), n, _ptr(codebook), int(codebook.shape[0]),
+                                                 _ptr(out_index), MEM_HOST if host else MEM_DEVICE))
+
+    def bow_assign_host(self, desc: np.ndarray, codebook: np.ndarray, valid=None) -> np.ndarray:
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 16)
+        codebook = np.ascontiguousarray(codebook, np.uint8).reshape(-1, 16)
+        out = np.zeros(desc.shape[0], np.int32)
+        self.bow_assign(desc, codebook, out, valid=None if valid is None else np.ascontiguousarray(valid, np.uint8))
+        return out
+
+    def bow_histogram(self, desc, codebook, hist_out, valid=None, n=None) -> bool:
+        host = _is_host(desc, codebook, hist_out, valid)
+        n = int(desc.shape[0]) if n is None else n
+        ok = C.c_int32(0)
+        self._check(self._lib.mofreak_bow_histogram(self._h, _ptr(desc), _ptr(valid), n, _ptr(codebook), int(codebook.shape[0]),
+                                                    _ptr(hist_out), C.byref(ok), MEM_HOST if host else MEM_DEVICE))
+        return bool(ok.value)
+
+    def bow_histogram_host(self, desc: np.ndarray, codebook: np.ndarray, valid=None):
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 16)
+        codebook = np.ascontiguousarray(codebook, np.uint8).reshape(-1, 16)
+        hist = np.zeros(codebook.shape[0], np.float32)
+        ok = self.bow_histogram(desc, codebook, hist, valid=None if valid is None else np.ascontiguousarray(valid, np.uint8))
+        return hist, ok
 
     # ---- hot path
     def extract_pairs(self, cur, prev, W, H, n_pairs, kps, out_desc, out_valid, kp_offsets=None, n_kp=None,

@@ -38,6 +38,7 @@ struct mofreak_ctx {
     // workspace (grown on demand, never shrunk)
     DeviceBuffer integral, band_totals, scratch_desc, scratch_valid, compact_offsets, stage[6], offsets_dev;
     DeviceBuffer kp_key, sorted_idx, slow_list, tile_start, tile_cursor, slow_count;  // keypoint binning
+    DeviceBuffer bow_counts;
     ThetaBound *d_theta = nullptr;
     unsigned long long *d_stamps = nullptr;  // MOFREAK_TILE_STAMPS=1: per-phase tick sums of the diagnostic tile kernel
     MipSample *d_mip_samples = nullptr;
@@ -553,6 +554,7 @@ void mofreak_destroy(mofreak_ctx *ctx)
     release(ctx->tile_start);
     release(ctx->tile_cursor);
     release(ctx->slow_count);
+    release(ctx->bow_counts);
     release(ctx->integral);
     release(ctx->band_totals);
     release(ctx->scratch_desc);
@@ -845,6 +847,80 @@ int mofreak_bgr_to_gray(mofreak_ctx *ctx, const uint8_t *bgr, int W, int H, int6
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     return MOFREAK_OK;
+}
+
+// ------------------------------------------------------------------ bag-of-words assignment
+static int bow_common(mofreak_ctx *ctx, const uint8_t *desc16, const uint8_t *valid, int64_t n, const uint8_t *codebook16,
+                      int n_codewords, int32_t *out_index, float *hist_out, int32_t *success_out, unsigned flags)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    if (n < 0 || n_codewords <= 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "n >= 0 and n_codewords > 0 required");
+    if (n_codewords > 10240) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "codebook larger than the 160 KiB LDS holds (10240 x 16 B)");
+    if (!codebook16 || (n > 0 && !desc16)) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null pointer");
+    NEED_DEVICE(ctx);
+    const bool host = (flags & MOFREAK_MEM_HOST) != 0;
+    int rc;
+    const uint8_t *d_desc = desc16, *d_valid = valid, *d_cb = codebook16;
+    int32_t *d_idx = out_index;
+    float *d_hist = hist_out;
+    if (host) {
+        if ((rc = upload(ctx, ctx->stage[0], desc16, (size_t)n * 16))) return rc;
+        d_desc = static_cast<const uint8_t *>(ctx->stage[0].ptr);
+        if (valid) {
+            if ((rc = upload(ctx, ctx->stage[1], valid, (size_t)n))) return rc;
+            d_valid = static_cast<const uint8_t *>(ctx->stage[1].ptr);
+        }
+        if ((rc = upload(ctx, ctx->stage[2], codebook16, (size_t)n_codewords * 16))) return rc;
+        d_cb = static_cast<const uint8_t *>(ctx->stage[2].ptr);
+        if (out_index) {
+            if ((rc = ensure(ctx, ctx->stage[3], (size_t)std::max<int64_t>(n, 1) * 4))) return rc;
+            d_idx = static_cast<int32_t *>(ctx->stage[3].ptr);
+        }
+        if (hist_out) {
+            if ((rc = ensure(ctx, ctx->stage[4], (size_t)n_codewords * 4 + 16))) return rc;
+            d_hist = static_cast<float *>(ctx->stage[4].ptr);
+        }
+    }
+    unsigned int *d_counts = nullptr;
+    int32_t *d_success = nullptr;
+    if (hist_out) {
+        if ((rc = ensure(ctx, ctx->bow_counts, (size_t)n_codewords * 4 + 16))) return rc;
+        d_counts = static_cast<unsigned int *>(ctx->bow_counts.ptr);
+        d_success = reinterpret_cast<int32_t *>(d_counts + n_codewords);
+        HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, (size_t)n_codewords * 4 + 16, ctx->stream));
+    }
+    if (n > 0) {
+        const int e = launch_bow_assign(d_desc, d_valid, n, d_cb, n_codewords, d_idx, d_counts, ctx->n_cus, ctx->stream);
+        if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("bow_assign launch: ") + hipGetErrorString((hipError_t)e));
+    }
+    if (hist_out) {
+        const int e = launch_bow_normalize(d_counts, n_codewords, d_hist, d_success, ctx->stream);
+        if (e) return fail(ctx, MOFREAK_ERR_HIP, "bow_normalize launch failed");
+        int32_t ok = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&ok, d_success, 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (host) HIP_TRY(ctx, hipMemcpyAsync(hist_out, d_hist, (size_t)n_codewords * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (success_out) *success_out = ok;
+    }
+    if (host && out_index && n > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(out_index, d_idx, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MOFREAK_OK;
+}
+
+int mofreak_bow_assign(mofreak_ctx *ctx, const uint8_t *desc16, const uint8_t *valid, int64_t n, const uint8_t *codebook16,
+                       int n_codewords, int32_t *out_index, unsigned flags)
+{
+    if (ctx && n > 0 && !out_index) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null output");
+    return bow_common(ctx, desc16, valid, n, codebook16, n_codewords, out_index, nullptr, nullptr, flags);
+}
+
+int mofreak_bow_histogram(mofreak_ctx *ctx, const uint8_t *desc16, const uint8_t *valid, int64_t n, const uint8_t *codebook16,
+                          int n_codewords, float *hist_out, int32_t *success_out, unsigned flags)
+{
+    if (ctx && !hist_out) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null output");
+    return bow_common(ctx, desc16, valid, n, codebook16, n_codewords, nullptr, hist_out, success_out, flags);
 }
 
 // ------------------------------------------------------------------ component entry points

@@ -495,6 +495,53 @@ long mo_extract_stream(const mo_freak *f, const uint8_t *frames, int T, int W, i
     return n_rows;
 }
 
+/* ---------------------------------------------------------------- bag-of-words assignment */
+static unsigned bow_hamming_byte(unsigned char a, unsigned char b)
+{
+    /* BagOfWordsRepresentation.cpp:54-72, bit loop kept as written */
+    unsigned int hamming_distance = 0;
+    unsigned int bit = 1;
+    unsigned int xor_result = a ^ b;
+    for (bit = 1; bit != 0; bit <<= 1) {
+        if ((xor_result & bit) != 0) hamming_distance++;
+    }
+    return hamming_distance;
+}
+
+int mo_bow_match(const uint8_t *feature, const uint8_t *codebook, int n_codewords, int dim)
+{
+    /* bruteForceMatch (BagOfWordsRepresentation.cpp:22-37): strict <, so the FIRST minimum wins */
+    int shortest_distance = 0x7fffffff;
+    int shortest_index = -1;
+    for (int i = 0; i < n_codewords; i++) {
+        unsigned int dist = 0;
+        for (int col = 0; col < dim; ++col) dist += bow_hamming_byte(feature[col], codebook[(size_t)i * dim + col]);
+        if ((long long)dist < (long long)shortest_distance) {
+            shortest_distance = (int)dist;
+            shortest_index = i;
+        }
+    }
+    return shortest_index;
+}
+
+int mo_bow_histogram(const uint8_t *desc, long n, const uint8_t *codebook, int n_codewords, int dim, float *hist)
+{
+    /* buildHistogram (BagOfWordsRepresentation.cpp:74-138) after the text parse: +1 per feature in float,
+     * then every bin divided by the float sum; returns `success` (0 when there was no feature: bins stay 0) */
+    int success = 0;
+    for (int c = 0; c < n_codewords; ++c) hist[c] = 0;
+    for (long k = 0; k < n; ++k) {
+        const int best_match = mo_bow_match(desc + (size_t)k * dim, codebook, n_codewords, dim);
+        hist[best_match] = hist[best_match] + 1;
+        success = 1;
+    }
+    if (!success) return 0;
+    float histogram_sum = 0;
+    for (int c = 0; c < n_codewords; ++c) histogram_sum += hist[c];
+    for (int c = 0; c < n_codewords; ++c) hist[c] = hist[c] / histogram_sum;
+    return 1;
+}
+
 int mo_format_row(const mo_row *r, char *buf, size_t cap)
 {
     /* MoFREAKUtilities.cpp:698-715; ostream<<float with default flags == printf("%g"); motion_x/y are 0 (:476-477) */

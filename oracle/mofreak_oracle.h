@@ -114,6 +114,12 @@ void mo_extract_pair(const mo_freak *f, const uint8_t *cur, const uint8_t *prev,
 long mo_extract_stream(const mo_freak *f, const uint8_t *frames, int T, int W, int H, int gap,
                        const float *kps, const long *kp_offsets, mo_row *rows, long max_rows);
 
+/* BagOfWordsRepresentation::bruteForceMatch (BagOfWordsRepresentation.cpp:22-72): index of the nearest codeword
+ * by bitwise Hamming distance over `dim` bytes, first minimum on ties. */
+int mo_bow_match(const uint8_t *feature, const uint8_t *codebook, int n_codewords, int dim);
+/* BagOfWordsRepresentation::buildHistogram (:74-138) on n in-memory descriptors; returns success (0/1). */
+int mo_bow_histogram(const uint8_t *desc, long n, const uint8_t *codebook, int n_codewords, int dim, float *hist);
+
 /* writeMoFREAKFeaturesToFile (:691-719): one text row; returns bytes written (excl. NUL). */
 int mo_format_row(const mo_row *r, char *buf, size_t cap);
 

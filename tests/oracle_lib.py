@@ -62,6 +62,8 @@ def lib():
     L.mo_extract_stream.restype = C.c_long
     L.mo_extract_stream.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, f32p,
                                     C.POINTER(C.c_long), C.c_void_p, C.c_long]
+    L.mo_bow_match.argtypes = [u8p, u8p, C.c_int, C.c_int]
+    L.mo_bow_histogram.argtypes = [u8p, C.c_long, u8p, C.c_int, C.c_int, f32p]
     L.mo_format_row.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     _lib = L
     return L
@@ -218,6 +220,20 @@ def theta_index(d0: int, d1: int) -> int:
 
 def theta_index_atan2f(d0: int, d1: int) -> int:
     return lib().mo_freak_theta_index_atan2f(int(d0), int(d1))
+
+
+def bow_assign(desc: np.ndarray, codebook: np.ndarray) -> np.ndarray:
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 16)
+    codebook = np.ascontiguousarray(codebook, np.uint8).reshape(-1, 16)
+    return np.array([lib().mo_bow_match(_u8(desc[k]), _u8(codebook), codebook.shape[0], 16) for k in range(desc.shape[0])], np.int32)
+
+
+def bow_histogram(desc: np.ndarray, codebook: np.ndarray):
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 16)
+    codebook = np.ascontiguousarray(codebook, np.uint8).reshape(-1, 16)
+    hist = np.zeros(codebook.shape[0], np.float32)
+    ok = lib().mo_bow_histogram(_u8(desc), desc.shape[0], _u8(codebook), codebook.shape[0], 16, _f32(hist))
+    return hist, bool(ok)
 
 
 def format_rows(rows: np.ndarray) -> bytes:

@@ -1,0 +1,92 @@
+"""Bag-of-words codeword assignment: the oracle follows the reference's in-tree
+BagOfWordsRepresentation.cpp:22-138 literally (so this row's parity IS pinned by source), the HIP kernel must match it."""
+import numpy as np
+import pytest
+
+import mofreak_amd as M
+
+
+def test_oracle_bow_known_answers(oracle):
+    cb = np.zeros((4, 16), np.uint8)
+    cb[1] = 0xFF
+    cb[2, 0] = 0x0F
+    cb[3, 0] = 0x0F              # duplicate of codeword 2: the FIRST minimum must win (strict <, :30)
+    d = np.zeros((5, 16), np.uint8)
+    d[1] = 0xFF
+    d[2, 0] = 0x07               # distance 3 to cw0, 1 to cw2/cw3
+    d[3, 8:] = 0xFF              # 64 bits set (away from cw2's byte): equidistant from cw0 and cw1 -> index 0
+    d[4, 0] = 0x03               # distance 2 to cw0 and to cw2 -> index 0
+    assert oracle.bow_assign(d, cb).tolist() == [0, 1, 2, 0, 0]
+    hist, ok = oracle.bow_histogram(d, cb)
+    assert ok and hist.tolist() == [np.float32(3) / np.float32(5), np.float32(1) / np.float32(5), np.float32(1) / np.float32(5), 0.0]
+    hist, ok = oracle.bow_histogram(d[:0], cb)
+    assert not ok and (hist == 0).all()
+
+
+def test_oracle_bow_matches_numpy(oracle):
+    rng = np.random.default_rng(0)
+    cb = rng.integers(0, 256, (300, 16), dtype=np.uint8)
+    d = rng.integers(0, 256, (200, 16), dtype=np.uint8)
+    dist = np.unpackbits(d[:, None, :] ^ cb[None, :, :], axis=2).sum(2)
+    assert np.array_equal(oracle.bow_assign(d, cb), dist.argmin(1))  # argmin returns the first minimum too
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [1, 7, 600, 1000, 7000, 10100])
+def test_bow_assign_matches_oracle(gpu_ctx, oracle, K):
+    rng = np.random.default_rng(K)
+    cb = rng.integers(0, 256, (K, 16), dtype=np.uint8)
+    if K > 10:
+        cb[K // 2] = cb[3]        # duplicates: first-minimum tie-break
+        cb[K - 1] = cb[0]
+    n = 3001 if K <= 1000 else 1203
+    d = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    d[:50] = cb[rng.integers(0, K, 50)]  # exact hits, some on duplicated codewords
+    if K > 10:
+        d[50] = cb[3]
+        d[51] = cb[0]
+    valid = (rng.random(n) > 0.1).astype(np.uint8)
+    got = gpu_ctx.bow_assign_host(d, cb, valid)
+    want = oracle.bow_assign(d, cb)
+    want[valid == 0] = -1
+    assert np.array_equal(got, want)
+    hist, ok = gpu_ctx.bow_histogram_host(d, cb, valid)
+    want_hist, want_ok = oracle.bow_histogram(d[valid == 1], cb)
+    assert ok == want_ok and hist.tobytes() == want_hist.tobytes()
+
+
+@pytest.mark.gpu
+def test_bow_on_extracted_descriptors_and_edge_cases(gpu_ctx, oracle):
+    """Descriptors straight from the extraction path (device pointers), codebook = a sample of them, as Clustering's
+    random codeword pick does; plus the empty case and the size limit."""
+    import torch
+    from mofreak_amd import synth
+    W, H = 640, 480
+    fr = synth.synth_stack(8, W, H)
+    kps = synth.config_grid("C2")
+    d_frames, d_kps = torch.from_numpy(fr).cuda(), torch.from_numpy(kps).cuda()
+    n = 3 * len(kps)
+    desc = torch.empty((n, 16), dtype=torch.uint8, device="cuda")
+    valid = torch.empty(n, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.extract_pairs(d_frames[5:], d_frames[:3], W, H, 3, d_kps, desc, valid)
+    gpu_ctx.synchronize()
+    h_desc = desc.cpu().numpy()
+    cb = h_desc[np.random.default_rng(1).choice(n, 600, replace=False)]
+    d_cb = torch.from_numpy(cb).cuda()
+    idx = torch.empty(n, dtype=torch.int32, device="cuda")
+    hist = torch.empty(600, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.bow_assign(desc, d_cb, idx, valid=valid)
+    ok = gpu_ctx.bow_histogram(desc, d_cb, hist, valid=valid)
+    gpu_ctx.synchronize()
+    assert ok and np.array_equal(idx.cpu().numpy(), oracle.bow_assign(h_desc, cb))
+    want_hist, _ = oracle.bow_histogram(h_desc, cb)
+    assert hist.cpu().numpy().tobytes() == want_hist.tobytes()
+    assert abs(float(hist.sum()) - 1.0) < 1e-4
+    # no descriptors: success = 0, bins 0 (the reference returns the zero histogram and bails out, :121-122)
+    h, ok = gpu_ctx.bow_histogram_host(h_desc[:0], cb)
+    assert not ok and (h == 0).all()
+    with pytest.raises(M.MoFREAKError) as e:
+        gpu_ctx.bow_assign_host(h_desc[:4], np.zeros((10241, 16), np.uint8))
+    assert e.value.code == -4
