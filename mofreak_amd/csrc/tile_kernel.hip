@@ -108,6 +108,14 @@ __device__ __forceinline__ int round_half_up_pos(float a)
     return i + ((a - (float)i) >= 0.5f ? 1 : 0);
 }
 
+// Which 16-pixel run of the region a row-pass task owns.  Eight consecutive tasks (the lane group of one
+// ds_write_b128) take a 4-row x 2-run cell: rows are kIP = 196 dwords apart (4 mod 32) and runs 16 dwords, so the eight
+// 16-byte stores of a group fall into eight different bank quads.  (Row-major task order puts lanes l and l+2 on the
+// same banks: a 4-way conflict on every store of the pass, measured at 29 % of the kernel's LDS cycles.)
+static_assert(kTileRH % 4 == 0 && (kTileRW / 16) % 2 == 0, "run cells");
+__device__ __forceinline__ int run_row(int t) { return 4 * ((t >> 3) / (kTileRW / 32)) + ((t & 7) >> 1); }
+__device__ __forceinline__ int run_col(int t) { return 2 * ((t >> 3) % (kTileRW / 32)) + (t & 1); }
+
 // FREAK::meanIntensity (box branch) on the tile-local integral; (ox, oy) = image coordinates of the region origin.
 __device__ __forceinline__ int mean_intensity_tile(const int32_t *__restrict__ I, int ox, int oy, float kx, float ky,
                                                    const PatternPoint P)
@@ -498,7 +506,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
 #pragma unroll
             for (int u = 0; u < kRunIters; ++u) {
                 const int t = tid + u * kTileThreads;
-                const int r = t / kRunsPerRow, q = t - r * kRunsPerRow;
+                const int r = run_row(t), q = run_col(t);
                 const int gy = oy + r, gx = ox + 16 * q;
                 const bool row_ok = t < kTileRH * kRunsPerRow && gy >= 0 && gy < H;
                 const int64_t ro = (int64_t)gy * a.f.row_stride;
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
                     rv[u][w4].w = (int)acc;
                 }
                 const int t = tid + u * kTileThreads;
-                if (t < kTileRH * kRunsPerRow) carry[t] = (int)acc;
+                if (t < kTileRH * kRunsPerRow) carry[run_row(t) * kRunsPerRow + run_col(t)] = (int)acc;
             }
         }
         for (int i = tid; i < kIP; i += kTileThreads) I[i] = 0;                                    // integral row 0
@@ -543,8 +551,8 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
         for (int u = 0; u < kRunIters; ++u) {
             const int t = tid + u * kTileThreads;
             if (t < kTileRH * kRunsPerRow) {
-                const int r = t / kRunsPerRow, q = t - r * kRunsPerRow;
-                const int add = carry[t];
+                const int r = run_row(t), q = run_col(t);
+                const int add = carry[r * kRunsPerRow + q];
                 int4 *dst = reinterpret_cast<int4 *>(I + (r + 1) * kIP + 4 + 16 * q);
 #pragma unroll
                 for (int w4 = 0; w4 < 4; ++w4)
