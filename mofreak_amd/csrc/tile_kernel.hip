@@ -50,7 +50,8 @@ constexpr int kOffTheta = kOffSmall + (int)((sizeof(SmallTables) + 15) / 16 * 16
 constexpr int kOffKp = kOffTheta + kThetaBounds * (int)sizeof(ThetaBound);   // the batch's keypoint records
 constexpr int kOffBits = kOffKp + kBatch * (int)sizeof(SortedKp);            // 8 descriptor bytes per keypoint, staged
 constexpr int kOffMot = kOffBits + kBatch * 8;                               // motion bytes kept for the fused store
-constexpr int kTileLdsBytes = kOffMot + kBatch * 8;
+constexpr int kOffStamps = kOffMot + kBatch * 8;                             // diagnostic build only: 32 x u64
+constexpr int kTileLdsBytes = kOffStamps + 256;
 static_assert(kOffCur % 16 == 0 && kOffPrev % 16 == 0 && kOffScratch % 16 == 0 && kOffSmall % 16 == 0, "LDS carve alignment");
 static_assert(kTileLdsBytes <= 160 * 1024, "tile kernel LDS budget");
 static_assert(kTileRW % 16 == 0 && kTileRH % kColBlocks == 0, "region blocking");
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs a)
     do {                                                                            \
         if (STAMPS && tid == 0) {                                                   \
             const unsigned long long now_ = __builtin_amdgcn_s_memtime();           \
-            atomicAdd(&a.stamps[i], now_ - last_stamp);                             \
+            s_stamps[i] += now_ - last_stamp; /* LDS; flushed to memory at the end */ \
             last_stamp = now_;                                                      \
         }                                                                           \
     } while (0)
@@ -275,8 +276,11 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs a)
 template <bool STAMPS>
 __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
 {
-    unsigned long long last_stamp = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    unsigned long long *s_stamps = reinterpret_cast<unsigned long long *>(lds + kOffStamps);
+    if (STAMPS && threadIdx.x == 0)
+        for (int i = 0; i < kTileStampSlots; ++i) s_stamps[i] = 0;
+    unsigned long long last_stamp = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
     const int n_tiles = a.tiles_x * a.tiles_y;
     // 1-D grid, remapped so that each XCD (workgroups are dealt round-robin over the 8 XCDs) walks a contiguous range
     // of (pair, tile) work items: neighbouring tiles share halo pixels, and this way they share an L2.  Placement is
@@ -740,6 +744,9 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
             }
         }
     }
+    if (STAMPS && tid == 0)
+        for (int i = 0; i < kTileStampSlots; ++i)
+            if (s_stamps[i]) atomicAdd(&a.stamps[i], s_stamps[i]);
 }
 
 }  // namespace
