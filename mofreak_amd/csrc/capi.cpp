@@ -37,7 +37,7 @@ struct mofreak_ctx {
     int32_t *d_status = nullptr;
     // workspace (grown on demand, never shrunk)
     DeviceBuffer integral, band_totals, scratch_desc, scratch_valid, compact_offsets, stage[6], offsets_dev;
-    DeviceBuffer kp_key, sorted_idx, slow_list, tile_start, tile_cursor, slow_count;  // keypoint binning
+    DeviceBuffer kp_key, sorted_idx, slow_list, tile_start, tile_cursor, slow_count, tile_lmin, tile_lmax;  // keypoint binning
     DeviceBuffer bow_counts;
     ThetaBound *d_theta = nullptr;
     unsigned long long *d_stamps = nullptr;  // MOFREAK_TILE_STAMPS=1: per-phase tick sums of the diagnostic tile kernel
@@ -275,6 +275,8 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
         if ((rc = ensure(ctx, ctx->slow_list, (size_t)n_kp * 4))) return rc;
         if ((rc = ensure(ctx, ctx->tile_start, (size_t)(n_keys + 1) * 4))) return rc;
         if ((rc = ensure(ctx, ctx->tile_cursor, (size_t)n_keys * 4))) return rc;
+        if ((rc = ensure(ctx, ctx->tile_lmin, (size_t)n_keys * 4))) return rc;
+        if ((rc = ensure(ctx, ctx->tile_lmax, (size_t)n_keys * 4))) return rc;
         if ((rc = ensure(ctx, ctx->slow_count, 256))) return rc;
         BinArgs b;
         b.kps = kps;
@@ -290,6 +292,8 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
         b.kp_key = static_cast<int32_t *>(ctx->kp_key.ptr);
         b.tile_start = static_cast<int32_t *>(ctx->tile_start.ptr);
         b.tile_cursor = static_cast<int32_t *>(ctx->tile_cursor.ptr);
+        b.tile_lmin = static_cast<uint32_t *>(ctx->tile_lmin.ptr);
+        b.tile_lmax = static_cast<uint32_t *>(ctx->tile_lmax.ptr);
         b.sorted_kp = static_cast<SortedKp *>(ctx->sorted_idx.ptr);
         b.slow_list = static_cast<int32_t *>(ctx->slow_list.ptr);
         b.slow_count = static_cast<int32_t *>(ctx->slow_count.ptr);
@@ -327,6 +331,8 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
             // CSR: bins are per (pair, tile); shared list: per tile, outputs offset by the pair
             t.tile_start = static_cast<const int32_t *>(ctx->tile_start.ptr) + (d_offsets ? (int64_t)p0 * tiles_x * tiles_y : 0);
             t.sorted_kp = static_cast<const SortedKp *>(ctx->sorted_idx.ptr);
+            t.tile_lmin = static_cast<const uint32_t *>(ctx->tile_lmin.ptr) + (d_offsets ? (int64_t)p0 * tiles_x * tiles_y : 0);
+            t.tile_lmax = static_cast<const uint32_t *>(ctx->tile_lmax.ptr) + (d_offsets ? (int64_t)p0 * tiles_x * tiles_y : 0);
             t.out_desc = d_offsets ? out_desc : out_desc + (int64_t)p0 * n_kp * 16;
             t.out_valid = d_offsets ? out_valid : out_valid + (int64_t)p0 * n_kp;
             t.stamps = ctx->d_stamps;
@@ -553,6 +559,8 @@ void mofreak_destroy(mofreak_ctx *ctx)
     release(ctx->slow_list);
     release(ctx->tile_start);
     release(ctx->tile_cursor);
+    release(ctx->tile_lmin);
+    release(ctx->tile_lmax);
     release(ctx->slow_count);
     release(ctx->bow_counts);
     release(ctx->integral);

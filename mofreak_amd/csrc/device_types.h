@@ -76,7 +76,8 @@ struct DescribeArgs {
 
 // Binning output: the keypoint itself next to its index, grouped by tile (one dwordx4 per entry).
 struct SortedKp {
-    float x, y, size;
+    float x, y;
+    uint32_t packed;  // ROI side L = ceil(size) | (int)size/2 << 8 | FREAK scale index << 16 (all derived once, at binning)
     int32_t g;
 };
 
@@ -94,6 +95,8 @@ struct BinArgs {
     int32_t *kp_key;            // [n_kp] key >= 0, -1 erased, -2 slow
     int32_t *tile_start;        // [n_keys + 1] counts, then exclusive starts
     int32_t *tile_cursor;       // [n_keys]
+    uint32_t *tile_lmin;        // [n_keys] smallest / largest ROI side among the tile's keypoints: equal in the usual
+    uint32_t *tile_lmax;        // case, and then the tile kernel can fetch its sample table before it has seen a keypoint
     SortedKp *sorted_kp;        // [n_kp] keypoints grouped by key
     int32_t *slow_list;         // [n_kp]
     int32_t *slow_count;        // [1]
@@ -116,6 +119,7 @@ struct TileArgs {
     const int64_t *kp_offsets;  // nullptr: shared list (tile lists are the same for every pair)
     int64_t n_kp;
     const int32_t *tile_start;
+    const uint32_t *tile_lmin, *tile_lmax;
     const SortedKp *sorted_kp;
     uint8_t *out_desc;
     uint8_t *out_valid;

@@ -47,8 +47,8 @@ constexpr int kOffScratch = kOffPrev + kTileCW * kTileCH;
 constexpr int kScratchBytes = kTileRH * kRunsPerRow * 4;  // 7680: row carries; also column carries / per-keypoint arrays
 constexpr int kOffSmall = kOffScratch + kScratchBytes;
 constexpr int kOffTheta = kOffSmall + (int)((sizeof(SmallTables) + 15) / 16 * 16);
-constexpr int kOffKp = kOffTheta + kThetaBounds * (int)sizeof(ThetaBound);   // the batch's keypoint records
-constexpr int kOffBits = kOffKp + kBatch * (int)sizeof(SortedKp);            // 8 descriptor bytes per keypoint, staged
+constexpr int kOffKf = kOffTheta + kThetaBounds * (int)sizeof(ThetaBound);   // the batch's FREAK records (outlive the scratch area)
+constexpr int kOffBits = kOffKf + kBatch * 16;                               // 8 descriptor bytes per keypoint, staged
 constexpr int kOffMot = kOffBits + kBatch * 8;                               // motion bytes kept for the fused store
 constexpr int kOffStamps = kOffMot + kBatch * 8;                             // diagnostic build only: 32 x u64
 constexpr int kTileLdsBytes = kOffStamps + 256;
@@ -70,8 +70,9 @@ struct KpMip {     // stage 1 per-keypoint record
     uint16_t roi_off;
     uint8_t L, pad;
 };
-static_assert(kBatch * kVStride + kBatch * (int)sizeof(KpFreak) <= kScratchBytes, "stage-3 arrays fit the scratch area");
-static_assert(kBatch * (int)sizeof(KpMip) + 16 <= kScratchBytes, "stage-1 arrays fit the scratch area");
+static_assert(kBatch * kVStride <= kScratchBytes, "stage-3 box means fit the scratch area");
+static_assert(kBatch * (int)sizeof(KpMip) <= kScratchBytes, "stage-1 records fit the scratch area");
+static_assert(sizeof(KpFreak) == 16, "record size used by the LDS carve");
 
 // 16 pixels of one row starting at image column gx (zero outside the image).
 __device__ __forceinline__ uint4 load_px16(const uint8_t *row, int gx, int W, bool row_ok, bool fast16)
@@ -193,6 +194,8 @@ __global__ __launch_bounds__(256) void bin_count_kernel(BinArgs a)
             const int64_t k64 = a.kp_offsets ? (int64_t)pair_of(a.kp_offsets, a.n_pairs, g) * (a.tiles_x * a.tiles_y) + tile : tile;
             key = (int)k64;
             atomicAdd(&a.tile_start[key], 1);
+            atomicMin(&a.tile_lmin[key], (uint32_t)L);
+            atomicMax(&a.tile_lmax[key], (uint32_t)L);
         } else {
             key = -2;
         }
@@ -236,7 +239,8 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs a)
         SortedKp s;
         s.x = kp.x;
         s.y = kp.y;
-        s.size = kp.size;
+        s.packed = (uint32_t)(int)ceilf(kp.size) | ((uint32_t)(((int)kp.size) / 2) << 8) |
+                   ((uint32_t)scale_index_scalar(a.small, kp.size) << 16);  // :293-295 ROI side / half, FREAK scale index
         s.g = (int)g;
         a.sorted_kp[pos] = s;
     } else if (key == -2) {
@@ -317,13 +321,72 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
     ThetaBound *s_theta = reinterpret_cast<ThetaBound *>(lds + kOffTheta);
     for (int i = tid; i < kThetaBounds; i += kTileThreads) s_theta[i] = a.theta[i];
 
-    SortedKp *s_kp = reinterpret_cast<SortedKp *>(lds + kOffKp);
     uint2 *s_bits = reinterpret_cast<uint2 *>(lds + kOffBits);
     uint2 *s_mot = reinterpret_cast<uint2 *>(lds + kOffMot);
+    KpMip *km = reinterpret_cast<KpMip *>(scratch);            // stage-1 records (scratch area: gone once stage 2 starts)
+    KpFreak *kf = reinterpret_cast<KpFreak *>(lds + kOffKf);   // stage-3 records (outside the scratch area)
     const bool one_batch = n_tile_kp <= kBatch;
+    // The binning pass recorded the smallest and largest ROI side of the tile: equal in the usual case.
+    const int tile_L = (int)a.tile_lmin[key];
+    const bool uniform = tile_L == (int)a.tile_lmax[key];
+
+    // Both stages' per-keypoint records from one binned record (ROI corner / side for the MIP; coordinates, scale
+    // index for FREAK).
+    auto make_records = [&](int b0, int nb) {
+        if (tid < nb) {
+            const SortedKp kp = tile_kps[b0 + tid];
+            const int x_i = (int)kp.x, y_i = (int)kp.y;  // :460 float -> int parameters
+            const int L = (int)(kp.packed & 0xff), half = (int)((kp.packed >> 8) & 0xff);
+            KpMip m;
+            m.g = kp.g;
+            m.roi_off = (uint16_t)((y_i - half - cy0) * kTileCW + (x_i - half - cx0));
+            m.L = (uint8_t)L;
+            m.pad = 0;
+            km[tid] = m;
+            KpFreak k;
+            k.kx = kp.x;
+            k.ky = kp.y;
+            k.g = kp.g;
+            k.idx = (int16_t)(kp.packed >> 16);
+            k.theta = 0;
+            kf[tid] = k;
+        }
+    };
+
+    // per-lane constants of the MIP sampling passes: where each sampled pixel goes, and (once the ROI side is known)
+    // the LDS byte offsets of its four source bytes relative to the ROI origin, frame base included.  Their loads are
+    // issued here, ahead of stage 0, so that the three global latencies overlap.
+    int pos[kMipIters], a0[kMipIters], a1[kMipIters], e0[kMipIters], e1[kMipIters];
+    int c0x[kMipIters], c1x[kMipIters], c0y[kMipIters], c1y[kMipIters];
+#pragma unroll
+    for (int u = 0; u < kMipIters; ++u) pos[u] = a.mip_pos[min(lane + 64 * u, a.mip_stride - 1)];
+    auto load_samples = [&](int L) {
+        const MipSample *tab = a.mip_samples + (int64_t)L * a.mip_stride;
+#pragma unroll
+        for (int u = 0; u < kMipIters; ++u) {
+            const MipSample sm = tab[min(lane + 64 * u, a.mip_stride - 1)];
+            const int frame = (lane + 64 * u) < a.mip_n_cur ? kOffCur : kOffPrev;
+            a0[u] = frame + sm.off00;
+            a1[u] = frame + sm.off10;
+            e0[u] = frame + sm.off01;
+            e1[u] = frame + sm.off11;
+            // The four bytes are fetched with four ds_read_u8.  Hide from the optimiser that e = a + 1 in most
+            // lanes: it would fuse the pairs into ds_read_u16 at odd addresses, which the LDS replays slowly.
+            asm volatile("" : "+v"(e0[u]), "+v"(e1[u]));
+            c0x[u] = sm.c0x;
+            c1x[u] = sm.c1x;
+            c0y[u] = sm.c0y;
+            c1y[u] = sm.c1y;
+        }
+    };
+    int have_L = -1;
+    if (uniform) {  // one ROI side in the whole tile (the usual case): its samples stay in registers
+        have_L = tile_L;
+        load_samples(tile_L);
+    }
 
     // ================= stage 0: gray tiles (tile + 8-px rim), 8 bytes per lane; all loads first, then the stores.
-    // The first batch's keypoint records ride along (both descriptor stages read them from LDS).
+    // The first batch's keypoint records ride along.
     {
         uint2 c[kGrayIters], p[kGrayIters];
 #pragma unroll
@@ -336,7 +399,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
             c[u] = load_px8(cur + ro, gx, W, row_ok, fast8);
             p[u] = load_px8(prev + ro, gx, W, row_ok, fast8);
         }
-        if (tid < min(kBatch, n_tile_kp)) s_kp[tid] = tile_kps[tid];
+        make_records(0, min(kBatch, n_tile_kp));
 #pragma unroll
         for (int u = 0; u < kGrayIters; ++u) {
             const int t = tid + u * kTileThreads;
@@ -351,33 +414,6 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
     // ================= stage 1: MIP
     {
         uint8_t *p19 = lds + kOffP19;
-        KpMip *km = reinterpret_cast<KpMip *>(scratch);
-        int *s_flags = reinterpret_cast<int *>(scratch + kBatch * sizeof(KpMip));  // [0] = mixed ROI sides in the batch
-        // per-lane constants of the sampling passes: where each sampled pixel goes, and (once the ROI side is known)
-        // the LDS byte offsets of its two source rows relative to the ROI origin, frame base included
-        int pos[kMipIters], a0[kMipIters], a1[kMipIters], e0[kMipIters], e1[kMipIters];
-        int c0x[kMipIters], c1x[kMipIters], c0y[kMipIters], c1y[kMipIters];
-#pragma unroll
-        for (int u = 0; u < kMipIters; ++u) pos[u] = a.mip_pos[min(lane + 64 * u, a.mip_stride - 1)];
-        auto load_samples = [&](int L) {
-            const MipSample *tab = a.mip_samples + (int64_t)L * a.mip_stride;
-#pragma unroll
-            for (int u = 0; u < kMipIters; ++u) {
-                const MipSample sm = tab[min(lane + 64 * u, a.mip_stride - 1)];
-                const int frame = (lane + 64 * u) < a.mip_n_cur ? kOffCur : kOffPrev;
-                a0[u] = frame + sm.off00;
-                a1[u] = frame + sm.off10;
-                e0[u] = frame + sm.off01;
-                e1[u] = frame + sm.off11;
-                // The four bytes are fetched with four ds_read_u8.  Hide from the optimiser that e = a + 1 in most
-                // lanes: it would fuse the pairs into ds_read_u16 at odd addresses, which the LDS replays slowly.
-                asm volatile("" : "+v"(e0[u]), "+v"(e1[u]));
-                c0x[u] = sm.c0x;
-                c1x[u] = sm.c1x;
-                c0y[u] = sm.c0y;
-                c1y[u] = sm.c1y;
-            }
-        };
         // per-lane constants of the bit pass: lane = 8*centre + offset (MoFREAKUtilities.cpp:56-70, 308-316)
         const int mc = lane >> 3, mi = lane & 7;
         const int mcx = (0xDDD99555u >> (4 * mc)) & 15, mcy = (0xD95D5D95u >> (4 * mc)) & 15;
@@ -385,33 +421,12 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
         const int base_c = (mcy - 1) * kPatch + (mcx - 1);
         const int base_p = kP19Pad + (mcy + mdy - 1) * kPatch + (mcx + mdx - 1);
         const int cw = base_c >> 2, cs = base_c & 3, pw = base_p >> 2, ps = base_p & 3;  // covering dword, byte shift
-        int have_L = -1;
         for (int b0 = 0; b0 < n_tile_kp; b0 += kBatch) {
             const int nb = min(kBatch, n_tile_kp - b0);
-            if (b0 > 0) {  // further batches of a crowded tile: fetch their records
+            if (b0 > 0) {  // further batches of a crowded tile: their records
                 __syncthreads();
-                if (tid < nb) s_kp[tid] = tile_kps[b0 + tid];
-            }
-            if (tid == 0) s_flags[0] = 0;
-            __syncthreads();  TILE_STAMP(1);
-            const int L0 = (int)ceilf(s_kp[0].size);
-            if (tid < nb) {
-                const SortedKp kp = s_kp[tid];
-                const int x_i = (int)kp.x, y_i = (int)kp.y;                    // :460 float -> int parameters
-                const int half = ((int)kp.size) / 2, L = (int)ceilf(kp.size);  // :293-295
-                KpMip m;
-                m.g = kp.g;
-                m.roi_off = (uint16_t)((y_i - half - cy0) * kTileCW + (x_i - half - cx0));
-                m.L = (uint8_t)L;
-                m.pad = 0;
-                km[tid] = m;
-                if (L != L0) s_flags[0] = 1;
-            }
-            __syncthreads();  TILE_STAMP(2);
-            const bool uniform = s_flags[0] == 0;
-            if (uniform && L0 != have_L) {  // one ROI side in the batch (the usual case): samples stay in registers
-                have_L = L0;
-                load_samples(L0);
+                make_records(b0, nb);
+                __syncthreads();
             }
             // Per wave, two keypoints at a time (their LDS reads are issued together, so one's latency hides under
             // the other's arithmetic): the sampled pixels of the two 19x19 resamples -> LDS, then -- same wave, so
@@ -615,25 +630,13 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
     // ================= stage 3: FREAK on the difference image
     {
         uint8_t *vv = scratch;                                             // [kBatch][kVStride] box means
-        KpFreak *kf = reinterpret_cast<KpFreak *>(scratch + kBatch * kVStride);
         for (int b0 = 0; b0 < n_tile_kp; b0 += kBatch) {
             const int nb = min(kBatch, n_tile_kp - b0);
-            if (!one_batch) {  // crowded tile: the records of this batch (a single batch still has them from stage 0)
-                __syncthreads();
-                if (tid < nb) s_kp[tid] = tile_kps[b0 + tid];
+            if (!one_batch) {  // crowded tile: the records of this batch (a single batch still has them from stage 0;
+                __syncthreads();  // km is rewritten too, harmlessly: the scratch area is free between batches)
+                make_records(b0, nb);
                 __syncthreads();
             }
-            if (tid < nb) {
-                const SortedKp kp = s_kp[tid];
-                KpFreak k;
-                k.kx = kp.x;
-                k.ky = kp.y;
-                k.g = kp.g;
-                k.idx = (int16_t)scale_index_scalar(&st, kp.size);
-                k.theta = 0;
-                kf[tid] = k;
-            }
-            __syncthreads();  TILE_STAMP(12);
             const int n_box = nb * kNbPoints;
             if (st.orientation_normalized) {
                 // F1: un-rotated box means; pattern points fetched for all of a thread's tasks before any is used
@@ -716,18 +719,26 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
             // F4: lane = descriptor bit
             {
                 const int pi = st.bit_pair_i[lane], pj = st.bit_pair_j[lane];
-                for (int kk = wave; kk < nb; kk += kTileWaves) {
-                    const uint8_t *v = vv + kk * kVStride;
-                    const int va = v[pi], vb = v[pj];
+                constexpr int kBitIters = (kBatch + kTileWaves - 1) / kTileWaves;
+                int va[kBitIters], vb[kBitIters];
+#pragma unroll
+                for (int u = 0; u < kBitIters; ++u) {  // clamped, unguarded: the byte pairs of all the wave's keypoints in flight
+                    const uint8_t *v = vv + min(wave + u * kTileWaves, nb - 1) * kVStride;
+                    va[u] = v[pi];
+                    vb[u] = v[pj];
+                }
+#pragma unroll
+                for (int u = 0; u < kBitIters; ++u) {
+                    const int kk = wave + u * kTileWaves;
                     bool bit;
                     if (st.bit_mode == MOFREAK_BITS_SSE)
-                        bit = va >= vb;
+                        bit = va[u] >= vb[u];
                     else if (st.bit_mode == MOFREAK_BITS_NATURAL)
-                        bit = va > vb;
+                        bit = va[u] > vb[u];
                     else
-                        bit = (int)(int8_t)va > (int)(int8_t)vb;
+                        bit = (int)(int8_t)va[u] > (int)(int8_t)vb[u];
                     const uint64_t app = __ballot(bit);
-                    if (lane == 0) s_bits[kk] = make_uint2((uint32_t)app, (uint32_t)(app >> 32));
+                    if (lane == 0 && kk < nb) s_bits[kk] = make_uint2((uint32_t)app, (uint32_t)(app >> 32));
                 }
             }
             __syncthreads();  TILE_STAMP(16);
@@ -757,6 +768,10 @@ int launch_bin(const BinArgs &a, void *stream)
     hipError_t e = hipMemsetAsync(a.tile_start, 0, (size_t)(a.n_keys + 1) * sizeof(int32_t), s);
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(a.tile_cursor, 0, (size_t)a.n_keys * sizeof(int32_t), s);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(a.tile_lmin, 0xff, (size_t)a.n_keys * sizeof(uint32_t), s);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(a.tile_lmax, 0, (size_t)a.n_keys * sizeof(uint32_t), s);
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(a.slow_count, 0, sizeof(int32_t), s);
     if (e != hipSuccess) return (int)e;
