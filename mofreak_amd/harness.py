@@ -76,19 +76,39 @@ class MoFREAKUtilities:
     # north-star spelling (BASELINE.json names these; the reference snapshot does not have them)
     computeMoFREAKFeatures = computeMoFREAKFromFile
 
-    def extract_rows(self, frames: np.ndarray) -> np.ndarray:
-        """Rows of one gray frame stack, in the reference's order (frames ascending, keypoints in input order)."""
+    def extract_rows(self, frames: np.ndarray, chunk_frames: int = 0) -> np.ndarray:
+        """Rows of one gray frame stack, in the reference's order (frames ascending, keypoints in input order).
+
+        chunk_frames > gap: a long stream is walked in chunks of that many frames, consecutive chunks overlapping
+        by `gap` frames (the reference keeps only a `gap`-deep frame queue, MoFREAKUtilities.cpp:391-399, 485-487),
+        so that device memory is bounded by the chunk, not by the stream."""
         T, H, W = frames.shape
         gap = self._ctx.params.gap_for_frame_difference
         if T <= gap:
             return np.zeros(0, api.ROW_DTYPE)
+        if chunk_frames and chunk_frames > gap and T > chunk_frames:
+            parts = []
+            for t0 in range(0, T - gap, chunk_frames - gap):
+                sub = frames[t0:t0 + chunk_frames]
+                rows = self._extract_rows_one(np.ascontiguousarray(sub), frame_offset=t0)
+                parts.append(rows)
+            return np.concatenate(parts) if parts else np.zeros(0, api.ROW_DTYPE)
+        return self._extract_rows_one(frames, 0)
+
+    def _extract_rows_one(self, frames: np.ndarray, frame_offset: int) -> np.ndarray:
+        T, H, W = frames.shape
+        gap = self._ctx.params.gap_for_frame_difference
         prov = self.keypoint_provider
         if getattr(prov, "shared", False):
-            return self._ctx.extract_stream_host(frames, prov(gap, W, H))
-        lists = [np.ascontiguousarray(prov(t, W, H), np.float32).reshape(-1, 3) for t in range(gap, T)]
-        offs = np.concatenate([[0], np.cumsum([len(k) for k in lists])]).astype(np.int64)
-        kps = np.concatenate(lists) if offs[-1] else np.zeros((0, 3), np.float32)
-        return self._ctx.extract_stream_host(frames, kps, kp_offsets=offs)
+            rows = self._ctx.extract_stream_host(frames, prov(gap, W, H))
+        else:
+            lists = [np.ascontiguousarray(prov(frame_offset + t, W, H), np.float32).reshape(-1, 3) for t in range(gap, T)]
+            offs = np.concatenate([[0], np.cumsum([len(k) for k in lists])]).astype(np.int64)
+            kps = np.concatenate(lists) if offs[-1] else np.zeros((0, 3), np.float32)
+            rows = self._ctx.extract_stream_host(frames, kps, kp_offsets=offs)
+        if frame_offset:
+            rows["frame_number"] += frame_offset
+        return rows
 
     def buildMoFREAKFeature(self, cur: np.ndarray, prev: np.ndarray, x: float, y: float, size: float):
         """One keypoint of one frame pair -> (appearance[8], motion[8]) or None if FREAK erases it."""

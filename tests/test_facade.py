@@ -137,3 +137,22 @@ def test_python_mirror_extracts_and_shards(native_lib, oracle, tmp_path):
     d, v = oracle.Freak().extract_pair(np.load(paths[0])[5], np.load(paths[0])[0], np.float32([[80, 64, 7.0]]))
     assert v[0] == 1 and np.array_equal(one[0], d[0, :8]) and np.array_equal(one[1], d[0, 8:])
     mf.close()
+
+
+@pytest.mark.gpu
+def test_long_stream_in_chunks_equals_one_pass(native_lib, oracle):
+    """BASELINE config 5 shape in miniature: a stream walked in overlapping chunks (5-frame halo) gives the rows of
+    one pass -- per-frame keypoint lists, so the provider's frame index has to survive the chunking too."""
+    W, H, T = 176, 144, 41
+    fr = synth.synth_stack(T, W, H, t0=3)
+    rng = np.random.default_rng(9)
+    per_frame = {t: synth.random_keypoints(rng, int(rng.integers(0, 60)), W, H, sizes=(7.0, 9.0, 12.0)) for t in range(T)}
+    mf = harness.MoFREAKUtilities(harness.TRECVID, device=0, keypoint_provider=lambda t, w, h: per_frame[t])
+    whole = mf.extract_rows(fr)
+    for chunk in (6, 7, 13, 40):
+        assert mf.extract_rows(fr, chunk_frames=chunk).tobytes() == whole.tobytes(), chunk
+    lists = [per_frame[t] for t in range(5, T)]
+    offs = np.concatenate([[0], np.cumsum([len(k) for k in lists])]).astype(np.int64)
+    want = oracle.Freak().extract_stream(fr, np.concatenate(lists), offs)
+    assert whole.tobytes() == want.tobytes() and len(whole) > 200
+    mf.close()
