@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
     // the LDS byte offsets of its four source bytes relative to the ROI origin, frame base included.  Their loads are
     // issued here, ahead of stage 0, so that the three global latencies overlap.
     int pos[kMipIters], a0[kMipIters], a1[kMipIters], e0[kMipIters], e1[kMipIters];
-    int c0x[kMipIters], c1x[kMipIters], c0y[kMipIters], c1y[kMipIters];
+    uint32_t cxp[kMipIters], cyp[kMipIters];  // the two 11-bit weights of an axis, packed as loaded (c0 | c1 << 16)
 #pragma unroll
     for (int u = 0; u < kMipIters; ++u) pos[u] = a.mip_pos[min(lane + 64 * u, a.mip_stride - 1)];
     auto load_samples = [&](int L) {
@@ -373,10 +373,8 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
             // The four bytes are fetched with four ds_read_u8.  Hide from the optimiser that e = a + 1 in most
             // lanes: it would fuse the pairs into ds_read_u16 at odd addresses, which the LDS replays slowly.
             asm volatile("" : "+v"(e0[u]), "+v"(e1[u]));
-            c0x[u] = sm.c0x;
-            c1x[u] = sm.c1x;
-            c0y[u] = sm.c0y;
-            c1y[u] = sm.c1y;
+            cxp[u] = (uint32_t)(uint16_t)sm.c0x | (uint32_t)(uint16_t)sm.c1x << 16;
+            cyp[u] = (uint32_t)(uint16_t)sm.c0y | (uint32_t)(uint16_t)sm.c1y << 16;
         }
     };
     int have_L = -1;
@@ -445,9 +443,11 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
                         uint8_t *dst = p19 + (h ? kk2 : kk) * (2 * kP19Pad);
 #pragma unroll
                         for (int u = 0; u < kMipIters; ++u) {
-                            const int t0 = __mul24((int)lds[a0[u] + mm.roi_off], c0x[u]) + __mul24((int)lds[e0[u] + mm.roi_off], c1x[u]);
-                            const int t1 = __mul24((int)lds[a1[u] + mm.roi_off], c0x[u]) + __mul24((int)lds[e1[u] + mm.roi_off], c1x[u]);
-                            const int px = ((__mul24(c0y[u], t0 >> 4) >> 16) + (__mul24(c1y[u], t1 >> 4) >> 16) + 2) >> 2;
+                            const int c0x = (int)(cxp[u] & 0xffffu), c1x = (int)(cxp[u] >> 16);
+                            const int c0y = (int)(cyp[u] & 0xffffu), c1y = (int)(cyp[u] >> 16);
+                            const int t0 = __mul24((int)lds[a0[u] + mm.roi_off], c0x) + __mul24((int)lds[e0[u] + mm.roi_off], c1x);
+                            const int t1 = __mul24((int)lds[a1[u] + mm.roi_off], c0x) + __mul24((int)lds[e1[u] + mm.roi_off], c1x);
+                            const int px = ((__mul24(c0y, t0 >> 4) >> 16) + (__mul24(c1y, t1 >> 4) >> 16) + 2) >> 2;
                             if (lane + 64 * u < a.mip_n) dst[pos[u]] = (uint8_t)px;
                         }
                     }
@@ -470,9 +470,11 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
 #pragma unroll
                         for (int u = 0; u < kMipIters; ++u) {
                             // every factor fits 24 bits: full-rate v_mul_i32_i24 / v_mad_i32_i24
-                            const int t0 = __mul24(s00[h][u], c0x[u]) + __mul24(s01[h][u], c1x[u]);
-                            const int t1 = __mul24(s10[h][u], c0x[u]) + __mul24(s11[h][u], c1x[u]);
-                            const int px = ((__mul24(c0y[u], t0 >> 4) >> 16) + (__mul24(c1y[u], t1 >> 4) >> 16) + 2) >> 2;
+                            const int c0x = (int)(cxp[u] & 0xffffu), c1x = (int)(cxp[u] >> 16);
+                            const int c0y = (int)(cyp[u] & 0xffffu), c1y = (int)(cyp[u] >> 16);
+                            const int t0 = __mul24(s00[h][u], c0x) + __mul24(s01[h][u], c1x);
+                            const int t1 = __mul24(s10[h][u], c0x) + __mul24(s11[h][u], c1x);
+                            const int px = ((__mul24(c0y, t0 >> 4) >> 16) + (__mul24(c1y, t1 >> 4) >> 16) + 2) >> 2;
                             if ((h == 0 || two) && lane + 64 * u < a.mip_n) dst[pos[u]] = (uint8_t)px;
                         }
                     }
