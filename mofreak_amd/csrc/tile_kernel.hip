@@ -277,6 +277,17 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs a)
         }                                                                           \
     } while (0)
 
+// The vertical step of the 8-bit bilinear resize, ((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2, with the
+// weights pre-shifted by 12: t < 2^20 and b << 12 <= 2^23 are 24-bit operands, and the high half of their 48-bit
+// product, (t & ~15) * (b << 12) >> 32, is (b * (t >> 4)) >> 16 exactly (all factors non-negative).
+__device__ __forceinline__ int resize_y(int t0, int t1, uint32_t b0s, uint32_t b1s)
+{
+    uint32_t p0, p1;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(p0) : "v"((uint32_t)t0 & ~15u), "v"(b0s));
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(p1) : "v"((uint32_t)t1 & ~15u), "v"(b1s));
+    return (int)((p0 + p1 + 2u) >> 2);
+}
+
 template <bool STAMPS>
 __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
 {
@@ -357,7 +368,8 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
     // the LDS byte offsets of its four source bytes relative to the ROI origin, frame base included.  Their loads are
     // issued here, ahead of stage 0, so that the three global latencies overlap.
     int pos[kMipIters], a0[kMipIters], a1[kMipIters], e0[kMipIters], e1[kMipIters];
-    uint32_t cxp[kMipIters], cyp[kMipIters];  // the two 11-bit weights of an axis, packed as loaded (c0 | c1 << 16)
+    uint32_t cxp[kMipIters];                   // the two 11-bit x weights, packed as loaded (c0 | c1 << 16)
+    uint32_t c0ys[kMipIters], c1ys[kMipIters];  // the y weights << 12: (w * (t >> 4)) >> 16 == mul_hi_u24(t & ~15, w << 12)
 #pragma unroll
     for (int u = 0; u < kMipIters; ++u) pos[u] = a.mip_pos[min(lane + 64 * u, a.mip_stride - 1)];
     auto load_samples = [&](int L) {
@@ -374,7 +386,8 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
             // lanes: it would fuse the pairs into ds_read_u16 at odd addresses, which the LDS replays slowly.
             asm volatile("" : "+v"(e0[u]), "+v"(e1[u]));
             cxp[u] = (uint32_t)(uint16_t)sm.c0x | (uint32_t)(uint16_t)sm.c1x << 16;
-            cyp[u] = (uint32_t)(uint16_t)sm.c0y | (uint32_t)(uint16_t)sm.c1y << 16;
+            c0ys[u] = (uint32_t)(uint16_t)sm.c0y << 12;
+            c1ys[u] = (uint32_t)(uint16_t)sm.c1y << 12;
         }
     };
     int have_L = -1;
@@ -444,10 +457,9 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
 #pragma unroll
                         for (int u = 0; u < kMipIters; ++u) {
                             const int c0x = (int)(cxp[u] & 0xffffu), c1x = (int)(cxp[u] >> 16);
-                            const int c0y = (int)(cyp[u] & 0xffffu), c1y = (int)(cyp[u] >> 16);
                             const int t0 = __mul24((int)lds[a0[u] + mm.roi_off], c0x) + __mul24((int)lds[e0[u] + mm.roi_off], c1x);
                             const int t1 = __mul24((int)lds[a1[u] + mm.roi_off], c0x) + __mul24((int)lds[e1[u] + mm.roi_off], c1x);
-                            const int px = ((__mul24(c0y, t0 >> 4) >> 16) + (__mul24(c1y, t1 >> 4) >> 16) + 2) >> 2;
+                            const int px = resize_y(t0, t1, c0ys[u], c1ys[u]);
                             if (lane + 64 * u < a.mip_n) dst[pos[u]] = (uint8_t)px;
                         }
                     }
@@ -471,10 +483,9 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
                         for (int u = 0; u < kMipIters; ++u) {
                             // every factor fits 24 bits: full-rate v_mul_i32_i24 / v_mad_i32_i24
                             const int c0x = (int)(cxp[u] & 0xffffu), c1x = (int)(cxp[u] >> 16);
-                            const int c0y = (int)(cyp[u] & 0xffffu), c1y = (int)(cyp[u] >> 16);
                             const int t0 = __mul24(s00[h][u], c0x) + __mul24(s01[h][u], c1x);
                             const int t1 = __mul24(s10[h][u], c0x) + __mul24(s11[h][u], c1x);
-                            const int px = ((__mul24(c0y, t0 >> 4) >> 16) + (__mul24(c1y, t1 >> 4) >> 16) + 2) >> 2;
+                            const int px = resize_y(t0, t1, c0ys[u], c1ys[u]);
                             if ((h == 0 || two) && lane + 64 * u < a.mip_n) dst[pos[u]] = (uint8_t)px;
                         }
                     }
