@@ -103,3 +103,35 @@ def random_keypoints(rng: np.random.Generator, n: int, W: int, H: int,
         kp[:, :2] = np.floor(kp[:, :2])
     kp[:, 2] = rng.choice(np.asarray(sizes, dtype=np.float32), n)
     return kp
+
+
+def moving_objects_stack(T: int, W: int, H: int, n_objects: int | None = None, seed: int = 7) -> np.ndarray:
+    """T gray frames of high-contrast rectangles and discs drifting over the textured background of synth_stack.
+
+    The smooth synthetic frames above have no frame difference large enough for a corner detector (|cur - prev|
+    peaks near 30); the detector row needs moving structure with real corners at several
+    scales.  Objects: about one per 80 x 80 px, sides 6..64 px, gray 0..255, speed up to 3 px/frame.
+    """
+    rng = np.random.default_rng(seed)
+    if n_objects is None:
+        n_objects = max(4, (W * H) // 6400)
+    kind = rng.integers(0, 2, n_objects)
+    cx, cy = rng.uniform(0, W, n_objects), rng.uniform(0, H, n_objects)
+    sx, sy = rng.uniform(6, 64, n_objects), rng.uniform(6, 64, n_objects)
+    vx, vy = rng.uniform(-3, 3, n_objects), rng.uniform(-3, 3, n_objects)
+    gray = rng.integers(0, 256, n_objects)
+    base = synth_stack(T, W, H)
+    yy, xx = np.mgrid[0:H, 0:W]
+    out = np.empty((T, H, W), np.uint8)
+    for t in range(T):
+        f = base[t].copy()
+        for k in range(n_objects):
+            x0, y0 = cx[k] + vx[k] * t, cy[k] + vy[k] * t
+            x0, y0 = x0 % W, y0 % H
+            if kind[k] == 0:
+                m = (np.abs(xx - x0) <= sx[k] / 2) & (np.abs(yy - y0) <= sy[k] / 2)
+            else:
+                m = ((xx - x0) / (sx[k] / 2)) ** 2 + ((yy - y0) / (sy[k] / 2)) ** 2 <= 1.0
+            f[m] = gray[k]
+        out[t] = f
+    return out

@@ -27,9 +27,8 @@ _lib = None
 
 
 def build():
-    src = os.path.join(ORACLE_DIR, "mofreak_oracle.c")
-    if (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(
-            os.path.getmtime(src), os.path.getmtime(os.path.join(ORACLE_DIR, "mofreak_oracle.h"))):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("mofreak_oracle.c", "mofreak_oracle.h", "brisk_oracle.c", "brisk_oracle.h")]
+    if (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
 
 
@@ -65,6 +64,29 @@ def lib():
     L.mo_bow_match.argtypes = [u8p, u8p, C.c_int, C.c_int]
     L.mo_bow_histogram.argtypes = [u8p, C.c_long, u8p, C.c_int, C.c_int, f32p]
     L.mo_format_row.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    # detector (brisk_oracle.h)
+    L.mo_brisk_create.restype = C.c_void_p
+    L.mo_brisk_create.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.mo_brisk_destroy.argtypes = [C.c_void_p]
+    L.mo_brisk_layers.argtypes = [C.c_void_p]
+    L.mo_brisk_layer_info.argtypes = [C.c_void_p, C.c_int, i32p, i32p, f32p, f32p]
+    L.mo_brisk_layer_image.restype = C.c_void_p
+    L.mo_brisk_layer_image.argtypes = [C.c_void_p, C.c_int]
+    L.mo_brisk_layer_scores.restype = C.c_void_p
+    L.mo_brisk_layer_scores.argtypes = [C.c_void_p, C.c_int]
+    L.mo_brisk_get_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.mo_brisk_layer_points.argtypes = [C.c_void_p, C.c_int, i32p, C.c_int]
+    L.mo_brisk_detect.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.mo_brisk_halfsample.argtypes = [u8p, C.c_int, C.c_int, u8p]
+    L.mo_brisk_twothirdsample.argtypes = [u8p, C.c_int, C.c_int, u8p]
+    L.mo_oast9_16_is_corner.argtypes = [u8p, C.c_int, C.c_int]
+    L.mo_oast9_16_score.argtypes = [u8p, C.c_int, C.c_int]
+    L.mo_agast5_8_score.argtypes = [u8p, C.c_int, C.c_int]
+    L.mo_oast9_16_detect.argtypes = [u8p, C.c_int, C.c_int, C.c_int, i32p, C.c_int]
+    L.mo_brisk_subpixel2d.restype = C.c_float
+    L.mo_brisk_subpixel2d.argtypes = [i32p, f32p, f32p]
+    L.mo_brisk_refine1d.restype = C.c_float
+    L.mo_brisk_refine1d.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, f32p]
     _lib = L
     return L
 
@@ -244,3 +266,110 @@ def format_rows(rows: np.ndarray) -> bytes:
         n = lib().mo_format_row(rows[i:i + 1].ctypes.data, buf, 512)
         out.append(buf.raw[:n])
     return b"".join(out)
+
+
+# ------------------------------------------------------------------ detector (oracle/brisk_oracle.c)
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("response", "<f4"), ("layer", "<i4")])
+
+
+class Brisk:
+    """BriskScaleSpace over one image: pyramid, per-layer OAST points, the score cache, getKeypoints."""
+
+    def __init__(self, img: np.ndarray, octaves: int = 3):
+        img = np.ascontiguousarray(img, np.uint8)
+        H, W = img.shape
+        self.h = lib().mo_brisk_create(_u8(img), W, W, H, octaves)
+        self.n_layers = lib().mo_brisk_layers(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.mo_brisk_destroy(self.h)
+            self.h = None
+
+    def layer_info(self, i):
+        w, h = C.c_int32(), C.c_int32()
+        sc, of = C.c_float(), C.c_float()
+        lib().mo_brisk_layer_info(self.h, i, C.byref(w), C.byref(h), C.byref(sc), C.byref(of))
+        return w.value, h.value, np.float32(sc.value), np.float32(of.value)
+
+    def _plane(self, fn, i):
+        w, h, _, _ = self.layer_info(i)
+        ptr = fn(self.h, i)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(h, w)).copy()
+
+    def layer_image(self, i):
+        return self._plane(lib().mo_brisk_layer_image, i)
+
+    def layer_scores(self, i):
+        return self._plane(lib().mo_brisk_layer_scores, i)
+
+    def get_keypoints(self, threshold: int = 30, cap: int = 1 << 20) -> np.ndarray:
+        out = np.zeros(cap, KEYPOINT_DTYPE)
+        n = lib().mo_brisk_get_keypoints(self.h, threshold, out.ctypes.data, cap)
+        assert n <= cap
+        return out[:n].copy()
+
+    def layer_points(self, i) -> np.ndarray:
+        n = lib().mo_brisk_layer_points(self.h, i, None, 0)
+        xy = np.zeros((max(n, 1), 2), np.int32)
+        lib().mo_brisk_layer_points(self.h, i, _i32(xy), n)
+        return xy[:n]
+
+
+def brisk_detect(img, threshold=30, octaves=3, cap=1 << 20) -> np.ndarray:
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    out = np.zeros(cap, KEYPOINT_DTYPE)
+    n = lib().mo_brisk_detect(_u8(img), W, W, H, threshold, octaves, out.ctypes.data, cap)
+    assert n <= cap
+    return out[:n].copy()
+
+
+def brisk_halfsample(src):
+    src = np.ascontiguousarray(src, np.uint8)
+    h, w = src.shape
+    dst = np.zeros((h // 2, w // 2), np.uint8)
+    lib().mo_brisk_halfsample(_u8(src), w, h, _u8(dst))
+    return dst
+
+
+def brisk_twothirdsample(src):
+    src = np.ascontiguousarray(src, np.uint8)
+    h, w = src.shape
+    dst = np.zeros((2 * (h // 3), 2 * (w // 3)), np.uint8)
+    lib().mo_brisk_twothirdsample(_u8(src), w, h, _u8(dst))
+    return dst
+
+
+def oast_score(img, x, y, bmin=0):
+    img = np.ascontiguousarray(img, np.uint8)
+    p = C.cast(img.ctypes.data + y * img.shape[1] + x, C.POINTER(C.c_uint8))
+    return lib().mo_oast9_16_score(p, img.shape[1], bmin)
+
+
+def agast58_score(img, x, y, bmin=0):
+    img = np.ascontiguousarray(img, np.uint8)
+    p = C.cast(img.ctypes.data + y * img.shape[1] + x, C.POINTER(C.c_uint8))
+    return lib().mo_agast5_8_score(p, img.shape[1], bmin)
+
+
+def oast_detect(img, b):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    n = lib().mo_oast9_16_detect(_u8(img), w, h, b, None, 0)
+    xy = np.zeros((max(n, 1), 2), np.int32)
+    lib().mo_oast9_16_detect(_u8(img), w, h, b, _i32(xy), n)
+    return xy[:n]
+
+
+def brisk_subpixel2d(s9):
+    s = np.ascontiguousarray(s9, np.int32)
+    dx, dy = C.c_float(), C.c_float()
+    m = lib().mo_brisk_subpixel2d(_i32(s), C.byref(dx), C.byref(dy))
+    return np.float32(m), np.float32(dx.value), np.float32(dy.value)
+
+
+def brisk_refine1d(variant, s_05, s0, s05):
+    mx = C.c_float()
+    r = lib().mo_brisk_refine1d(variant, float(np.float32(s_05)), float(np.float32(s0)), float(np.float32(s05)), C.byref(mx))
+    return np.float32(r), np.float32(mx.value)
