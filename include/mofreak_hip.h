@@ -182,6 +182,41 @@ int mofreak_extract_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W
 int mofreak_bgr_to_gray(mofreak_ctx *ctx, const uint8_t *bgr, int W, int H, int64_t row_stride, int64_t frame_stride,
                         int n_frames, uint8_t *gray_out, unsigned flags);
 
+/* ------------------------------------------------------------------ keypoint detector */
+/*
+ * BriskFeatureDetector(threshold, octaves).detect(|cur - prev|) for n_pairs frame pairs: what
+ * computeMoFREAKFromFile does at MoFREAKUtilities.cpp:413-423 before it describes the keypoints -- cv::absdiff, then
+ * BriskScaleSpace::constructPyramid + getKeypoints (brisk.cpp:549-704) over the OAST 9/16 corner detector
+ * (oast9_16.cc:46, oast9_16_nms.cc:42).  The reference uses threshold 30 and octaves 3 (MoFREAKUtilities.cpp:420,
+ * brisk.h:228).  prev == NULL: search cur itself (any gray image).
+ *
+ *   out_kps       x, y, size of every keypoint, pair after pair, inside a pair in the order of the reference's
+ *                 keypoint vector (layer by layer, raster order inside a layer) -- ready to be handed to
+ *                 mofreak_extract_pairs together with out_offsets
+ *   out_offsets   n_pairs + 1 CSR offsets into out_kps (same memory space as out_kps)
+ *   out_response  optional: cv::KeyPoint::response (the refined score); out_layer: optional cv::KeyPoint::octave
+ *                 as the reference fills it (the pyramid layer index)
+ *   n_out         total number of keypoints (host pointer).  More than `capacity`: MOFREAK_ERR_CAPACITY, nothing
+ *                 beyond capacity is written.  octaves: 0..4; W, H <= 65535.  Synchronises the stream.
+ */
+int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, int W, int H, int64_t row_stride,
+                         int64_t pair_stride, int n_pairs, int threshold, int octaves, mofreak_keypoint *out_kps,
+                         int64_t capacity, int64_t *out_offsets, float *out_response, int32_t *out_layer, int64_t *n_out,
+                         unsigned flags);
+/* Candidates per pair the detector reserves room for (default 131072); more corners than that in one pair's pyramid
+ * make mofreak_detect_pairs return MOFREAK_ERR_CAPACITY. */
+int mofreak_detect_set_capacity(mofreak_ctx *ctx, int candidates_per_pair);
+
+/* Components, for tests and for callers that want the pyramid: the layers of BriskScaleSpace::constructPyramid over
+ * one gray image (BriskLayer::halfsample / twothirdsample, brisk.cpp:1840-2065) and, with scores_out, the OAST 9/16
+ * corner score of every pixel of every layer (BriskLayer::getAgastScore(x, y, 1), :1685-1694; 0 inside the 3-pixel
+ * border).  Layers are written one after the other, w*h bytes each, rows packed; dims_out gets w, h per layer
+ * (2 * n_layers int32), scale_offset_out scale, offset per layer.  Any output may be NULL.  Returns the number of
+ * layers through n_layers_out. */
+int mofreak_brisk_pyramid(mofreak_ctx *ctx, const uint8_t *img, int W, int H, int64_t row_stride, int octaves,
+                          uint8_t *layers_out, uint8_t *scores_out, int32_t *dims_out, float *scale_offset_out,
+                          int *n_layers_out, unsigned flags);
+
 /* ------------------------------------------------------------------ bag-of-words assignment */
 /* BagOfWordsRepresentation::bruteForceMatch (BagOfWordsRepresentation.cpp:22-37, hammingDistance :39-72): for each of
  * n 16-byte descriptors the index of the nearest of n_codewords 16-byte codewords by bitwise Hamming distance, the

@@ -36,6 +36,7 @@ EXPORTS = [
     "mofreak_parse_rows", "mofreak_diff_integral", "mofreak_mip19", "mofreak_roi19", "mofreak_freak_info",
     "mofreak_theta_index", "mofreak_pattern_sizes", "mofreak_scale_index", "mofreak_table_pattern",
     "mofreak_table_orientation", "mofreak_table_bit_pairs", "mofreak_table_resize",
+    "mofreak_detect_pairs", "mofreak_detect_set_capacity", "mofreak_brisk_pyramid",
 ]
 
 
@@ -97,6 +98,9 @@ def load() -> C.CDLL:
     L.mofreak_bow_assign.argtypes = [vp, vp, vp, i64, vp, i32, vp, C.c_uint]
     L.mofreak_bow_histogram.argtypes = [vp, vp, vp, i64, vp, i32, vp, C.POINTER(C.c_int32), C.c_uint]
     L.mofreak_extract_pairs.argtypes = [vp, vp, vp, i32, i32, i64, i64, i32, vp, vp, i64, vp, vp, C.c_uint]
+    L.mofreak_detect_pairs.argtypes = [vp, vp, vp, i32, i32, i64, i64, i32, i32, i32, vp, i64, vp, vp, vp, C.POINTER(i64), C.c_uint]
+    L.mofreak_detect_set_capacity.argtypes = [vp, i32]
+    L.mofreak_brisk_pyramid.argtypes = [vp, vp, i32, i32, i64, i32, vp, vp, vp, vp, C.POINTER(C.c_int), C.c_uint]
     L.mofreak_compact_rows.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, i64, C.POINTER(i64), C.c_uint]
     L.mofreak_extract_stream.argtypes = [vp, vp, i32, i32, i32, vp, vp, i64, vp, i64, C.POINTER(i64), C.c_uint]
     L.mofreak_format_rows.argtypes = [vp, i64, vp, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -246,6 +250,60 @@ class Context:
         n, H, W, _ = bgr.shape
         out = np.empty((n, H, W), np.uint8)
         self.bgr_to_gray(bgr, W, H, n, out)
+        return out
+
+    # ---- keypoint detector
+    def detect_pairs(self, cur, prev, W, H, n_pairs, out_kps, out_offsets, threshold=30, octaves=3, out_response=None,
+                     out_layer=None, capacity=None, row_stride=None, pair_stride=None) -> int:
+        """Raw call (numpy = host, torch cuda tensors = device).  Returns the number of keypoints."""
+        host = _is_host(cur, prev, out_kps, out_offsets, out_response, out_layer)
+        row_stride = W if row_stride is None else row_stride
+        pair_stride = W * H if pair_stride is None else pair_stride
+        capacity = _count_keypoints(out_kps) if capacity is None else capacity
+        n = C.c_int64(0)
+        self._check(self._lib.mofreak_detect_pairs(self._h, _ptr(cur), _ptr(prev), W, H, row_stride, pair_stride, n_pairs, threshold,
+                                                   octaves, _ptr(out_kps), capacity, _ptr(out_offsets), _ptr(out_response),
+                                                   _ptr(out_layer), C.byref(n), MEM_HOST if host else MEM_DEVICE))
+        return n.value
+
+    def detect_pairs_host(self, cur: np.ndarray, prev, threshold=30, octaves=3, capacity=1 << 20):
+        """cur, prev: (n_pairs, H, W) u8 (prev None: search cur itself) -> (kps (n,3) f32, offsets (n_pairs+1,) i64,
+        response (n,) f32, layer (n,) i32) in the reference's keypoint order."""
+        cur = np.ascontiguousarray(cur, np.uint8)
+        if cur.ndim == 2:
+            cur = cur[None]
+        prev = None if prev is None else np.ascontiguousarray(prev, np.uint8).reshape(cur.shape)
+        n_pairs, H, W = cur.shape
+        kps = np.zeros((capacity, 3), np.float32)
+        offs = np.zeros(n_pairs + 1, np.int64)
+        resp = np.zeros(capacity, np.float32)
+        layer = np.zeros(capacity, np.int32)
+        n = self.detect_pairs(cur, prev, W, H, n_pairs, kps, offs, threshold, octaves, resp, layer, capacity=capacity)
+        return kps[:n].copy(), offs, resp[:n].copy(), layer[:n].copy()
+
+    def set_detect_capacity(self, candidates_per_pair: int):
+        self._check(self._lib.mofreak_detect_set_capacity(self._h, candidates_per_pair))
+
+    def brisk_pyramid_host(self, img: np.ndarray, octaves=3, scores=True):
+        """-> list of (layer image, score map or None, scale, offset) per pyramid layer."""
+        img = np.ascontiguousarray(img, np.uint8)
+        H, W = img.shape
+        dims = np.zeros(16, np.int32)
+        so = np.zeros(16, np.float32)
+        nl = C.c_int(0)
+        self._check(self._lib.mofreak_brisk_pyramid(self._h, _ptr(img), W, H, W, octaves, None, None, _ptr(dims), _ptr(so),
+                                                    C.byref(nl), MEM_HOST))
+        sizes = [int(dims[2 * i]) * int(dims[2 * i + 1]) for i in range(nl.value)]
+        layers = np.zeros(sum(sizes), np.uint8)
+        sc = np.zeros(sum(sizes), np.uint8) if scores else None
+        self._check(self._lib.mofreak_brisk_pyramid(self._h, _ptr(img), W, H, W, octaves, _ptr(layers), _ptr(sc), None, None, None,
+                                                    MEM_HOST))
+        out, o = [], 0
+        for i in range(nl.value):
+            w, h = int(dims[2 * i]), int(dims[2 * i + 1])
+            out.append((layers[o:o + sizes[i]].reshape(h, w), None if sc is None else sc[o:o + sizes[i]].reshape(h, w),
+                        np.float32(so[2 * i]), np.float32(so[2 * i + 1])))
+            o += sizes[i]
         return out
 
     # ---- bag-of-words assignment

@@ -8,7 +8,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmofreak_hip.so")
-SOURCES = ["kernels.hip", "tile_kernel.hip", "bow_kernel.hip", "capi.cpp", "tables.cpp", "format.cpp"]
+SOURCES = ["kernels.hip", "tile_kernel.hip", "bow_kernel.hip", "detect_kernel.hip", "capi.cpp", "tables.cpp", "format.cpp"]
 HEADERS = ["tables.h", "device_types.h", "device_helpers.h", os.path.join("..", "..", "include", "mofreak_hip.h")]
 # -ffp-contract=off / -fno-fast-math: a handful of float/double expressions restate reference
 # expressions whose rounding is part of the result.

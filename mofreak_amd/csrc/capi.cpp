@@ -39,6 +39,10 @@ struct mofreak_ctx {
     DeviceBuffer integral, band_totals, scratch_desc, scratch_valid, compact_offsets, stage[6], offsets_dev;
     DeviceBuffer kp_key, sorted_idx, slow_list, tile_start, tile_cursor, slow_count, tile_lmin, tile_lmax;  // keypoint binning
     DeviceBuffer bow_counts;
+    // keypoint detector workspace
+    DeviceBuffer det_img, det_score, det_touch, det_status, det_rows, det_cand_xy, det_cand_flag, det_cand_emit, det_cand_res, det_layer_start,
+        det_emit_count, det_emit_offsets, det_running, det_out_kps, det_out_offsets, det_out_resp, det_out_layer, det_planes_out;
+    int det_cand_cap = 131072;
     ThetaBound *d_theta = nullptr;
     unsigned long long *d_stamps = nullptr;  // MOFREAK_TILE_STAMPS=1: per-phase tick sums of the diagnostic tile kernel
     MipSample *d_mip_samples = nullptr;
@@ -563,6 +567,10 @@ void mofreak_destroy(mofreak_ctx *ctx)
     release(ctx->tile_lmax);
     release(ctx->slow_count);
     release(ctx->bow_counts);
+    for (DeviceBuffer *b : {&ctx->det_img, &ctx->det_score, &ctx->det_touch, &ctx->det_status, &ctx->det_rows, &ctx->det_cand_xy, &ctx->det_cand_flag,
+                            &ctx->det_cand_emit, &ctx->det_cand_res, &ctx->det_layer_start, &ctx->det_emit_count, &ctx->det_emit_offsets,
+                            &ctx->det_running, &ctx->det_out_kps, &ctx->det_out_offsets, &ctx->det_out_resp, &ctx->det_out_layer, &ctx->det_planes_out})
+        release(*b);
     release(ctx->integral);
     release(ctx->band_totals);
     release(ctx->scratch_desc);
@@ -1138,6 +1146,243 @@ int mofreak_table_resize(const mofreak_ctx *ctx, int L, int16_t out[2 * 19 * 4])
         out[4 * i + 2] = t[i].c0;
         out[4 * i + 3] = t[i].c1;
     }
+    return MOFREAK_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ keypoint detector
+namespace {
+
+// BriskScaleSpace(octaves) + the layer constructors (brisk.cpp:561-567, 1646-1674): sizes, scale and offset per layer
+int det_geometry(const mofreak_ctx *ctx, int W, int H, int octaves, DetGeom &g)
+{
+    if (octaves < 0 || octaves > kDetMaxLayers / 2) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "octaves must be in 0..4");
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return fail(ctx, MOFREAK_ERR_BAD_ARG, "W, H must be in 1..65535");
+    std::memset(&g, 0, sizeof(g));
+    g.n_layers = octaves == 0 ? 1 : 2 * octaves;
+    int64_t off = 0;
+    int rows = 0;
+    for (int i = 0; i < g.n_layers; ++i) {
+        DetLayer &L = g.L[i];
+        if (i == 0) {
+            L.w = W;
+            L.h = H;
+            L.scale = 1.0f;
+            L.offset = 0.0f;
+        } else if (i == 1) {
+            L.w = 2 * (g.L[0].w / 3);
+            L.h = 2 * (g.L[0].h / 3);
+            L.scale = (float)((double)g.L[0].scale * 1.5);
+            L.offset = (float)(0.5 * (double)L.scale - 0.5);
+        } else {
+            L.w = g.L[i - 2].w / 2;
+            L.h = g.L[i - 2].h / 2;
+            L.scale = g.L[i - 2].scale * 2;
+            L.offset = (float)(0.5 * (double)L.scale - 0.5);
+        }
+        L.off = off;
+        L.row_base = rows;
+        off += (((int64_t)L.w * L.h + 63) / 64) * 64;
+        rows += L.h;
+    }
+    g.plane_bytes = off + 64;
+    g.total_rows = rows;
+    return MOFREAK_OK;
+}
+
+int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
+{
+    int rc;
+    const size_t planes = (size_t)batch * g.plane_bytes, cands = (size_t)batch * ctx->det_cand_cap;
+    if ((rc = ensure(ctx, ctx->det_img, planes))) return rc;
+    if ((rc = ensure(ctx, ctx->det_score, planes))) return rc;
+    if ((rc = ensure(ctx, ctx->det_touch, planes))) return rc;
+    if ((rc = ensure(ctx, ctx->det_status, planes))) return rc;
+    if ((rc = ensure(ctx, ctx->det_rows, (size_t)batch * (g.total_rows + 1) * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->det_cand_xy, cands * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->det_cand_flag, cands))) return rc;
+    if ((rc = ensure(ctx, ctx->det_cand_emit, cands))) return rc;
+    if ((rc = ensure(ctx, ctx->det_cand_res, cands * sizeof(DetResult)))) return rc;
+    if ((rc = ensure(ctx, ctx->det_layer_start, (size_t)batch * (kDetMaxLayers + 1) * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->det_emit_count, (size_t)batch * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->det_emit_offsets, (size_t)(batch + 1) * sizeof(int64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->det_running, sizeof(int64_t)))) return rc;
+    a.g = g;
+    a.img = static_cast<uint8_t *>(ctx->det_img.ptr);
+    a.score = static_cast<uint8_t *>(ctx->det_score.ptr);
+    a.touch = static_cast<uint8_t *>(ctx->det_touch.ptr);
+    a.status = static_cast<uint8_t *>(ctx->det_status.ptr);
+    a.row_count = static_cast<int32_t *>(ctx->det_rows.ptr);
+    a.cand_cap = ctx->det_cand_cap;
+    a.cand_xy = static_cast<uint32_t *>(ctx->det_cand_xy.ptr);
+    a.cand_flag = static_cast<uint8_t *>(ctx->det_cand_flag.ptr);
+    a.cand_emit = static_cast<uint8_t *>(ctx->det_cand_emit.ptr);
+    a.cand_res = static_cast<DetResult *>(ctx->det_cand_res.ptr);
+    a.layer_start = static_cast<int32_t *>(ctx->det_layer_start.ptr);
+    a.emit_count = static_cast<int32_t *>(ctx->det_emit_count.ptr);
+    a.emit_offsets = static_cast<int64_t *>(ctx->det_emit_offsets.ptr);
+    a.status_word = ctx->d_status;
+    return MOFREAK_OK;
+}
+
+// pairs per batch: about 1 GiB of planes and candidate records
+int det_batch(const mofreak_ctx *ctx, const DetGeom &g, int n_pairs)
+{
+    const size_t per_pair = 4 * (size_t)g.plane_bytes + (size_t)ctx->det_cand_cap * (sizeof(uint32_t) + 2 + sizeof(DetResult));
+    const size_t b = std::max<size_t>(1, ((size_t)1 << 30) / per_pair);
+    return (int)std::min<size_t>({b, (size_t)std::max(n_pairs, 1), (size_t)16384});
+}
+
+}  // namespace
+
+extern "C" {
+
+int mofreak_detect_set_capacity(mofreak_ctx *ctx, int candidates_per_pair)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    if (candidates_per_pair < 256 || candidates_per_pair > (1 << 24)) return fail(ctx, MOFREAK_ERR_BAD_ARG, "candidates_per_pair must be in 256..2^24");
+    ctx->det_cand_cap = candidates_per_pair;
+    return MOFREAK_OK;
+}
+
+int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, int W, int H, int64_t row_stride, int64_t pair_stride,
+                         int n_pairs, int threshold, int octaves, mofreak_keypoint *out_kps, int64_t capacity, int64_t *out_offsets,
+                         float *out_response, int32_t *out_layer, int64_t *n_out, unsigned flags)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    if (n_out) *n_out = 0;
+    if (n_pairs < 0 || capacity < 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "n_pairs and capacity must not be negative");
+    if (threshold < 1 || threshold > 255) return fail(ctx, MOFREAK_ERR_BAD_ARG, "threshold must be in 1..255");
+    if (row_stride < W) return fail(ctx, MOFREAK_ERR_BAD_ARG, "row_stride < W");
+    if (n_pairs > 1 && pair_stride == 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "pair_stride is 0");
+    if (!out_offsets || (capacity > 0 && !out_kps) || (n_pairs > 0 && !cur)) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null pointer");
+    DetGeom g;
+    int rc = det_geometry(ctx, W, H, octaves, g);
+    if (rc) return rc;
+    NEED_DEVICE(ctx);
+    const bool host = (flags & MOFREAK_MEM_HOST) != 0;
+    const Geometry geo{W, H, row_stride, pair_stride};
+    const uint8_t *d_cur = cur, *d_prev = prev;
+    mofreak_keypoint *d_kps = out_kps;
+    int64_t *d_off = out_offsets;
+    float *d_resp = out_response;
+    int32_t *d_layer = out_layer;
+    if (host) {
+        if (n_pairs > 0) {
+            if ((rc = upload(ctx, ctx->stage[0], cur, frame_span(geo, n_pairs)))) return rc;
+            d_cur = static_cast<const uint8_t *>(ctx->stage[0].ptr);
+            if (prev) {
+                if ((rc = upload(ctx, ctx->stage[1], prev, frame_span(geo, n_pairs)))) return rc;
+                d_prev = static_cast<const uint8_t *>(ctx->stage[1].ptr);
+            }
+        }
+        if ((rc = ensure(ctx, ctx->det_out_kps, (size_t)capacity * sizeof(mofreak_keypoint)))) return rc;
+        if ((rc = ensure(ctx, ctx->det_out_offsets, (size_t)(n_pairs + 1) * sizeof(int64_t)))) return rc;
+        d_kps = static_cast<mofreak_keypoint *>(ctx->det_out_kps.ptr);
+        d_off = static_cast<int64_t *>(ctx->det_out_offsets.ptr);
+        if (out_response) {
+            if ((rc = ensure(ctx, ctx->det_out_resp, (size_t)capacity * sizeof(float)))) return rc;
+            d_resp = static_cast<float *>(ctx->det_out_resp.ptr);
+        }
+        if (out_layer) {
+            if ((rc = ensure(ctx, ctx->det_out_layer, (size_t)capacity * sizeof(int32_t)))) return rc;
+            d_layer = static_cast<int32_t *>(ctx->det_out_layer.ptr);
+        }
+    }
+    const int batch = det_batch(ctx, g, n_pairs);
+    DetArgs a{};
+    if ((rc = det_workspace(ctx, g, batch, a))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->det_running.ptr, 0, sizeof(int64_t), ctx->stream));
+    if (n_pairs == 0) HIP_TRY(ctx, hipMemsetAsync(d_off, 0, sizeof(int64_t), ctx->stream));
+    a.threshold = threshold;
+    a.safe_threshold = (int)(uint8_t)((float)threshold * 1.0f);  // safeThreshold_ = threshold_ * safetyFactor_ (brisk.cpp:58, 597)
+    a.out_kps = d_kps;
+    a.out_response = d_resp;
+    a.out_layer = d_layer;
+    a.out_capacity = capacity;
+    a.out_offsets = d_off;
+    for (int p0 = 0; p0 < n_pairs; p0 += batch) {
+        const int np = std::min(batch, n_pairs - p0);
+        a.n_pairs = np;
+        a.first_pair = p0;
+        a.f = FrameArgs{d_cur + (int64_t)p0 * pair_stride, d_prev ? d_prev + (int64_t)p0 * pair_stride : nullptr, W, H, row_stride, pair_stride};
+        HIP_TRY(ctx, hipMemsetAsync(a.row_count, 0, (size_t)np * (g.total_rows + 1) * sizeof(int32_t), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(a.touch, 0, (size_t)np * g.plane_bytes, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(a.status, 0, (size_t)np * g.plane_bytes, ctx->stream));
+        int e = launch_det_pyramid(a, ctx->stream);
+        if (!e) e = launch_det_scores(a, ctx->stream);
+        if (!e) e = launch_det_keypoints(a, static_cast<int64_t *>(ctx->det_running.ptr), ctx->stream);
+        if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("detector launch: ") + hipGetErrorString((hipError_t)e));
+    }
+    int64_t total = 0;
+    int32_t st = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->det_running.ptr, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&st, ctx->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_out) *n_out = total;
+    if (st & 4) return fail(ctx, MOFREAK_ERR_CAPACITY, "more corner candidates in one pair than the detector reserved (mofreak_detect_set_capacity)");
+    if (host) {
+        const int64_t n_copy = std::min(total, capacity);
+        HIP_TRY(ctx, hipMemcpy(out_offsets, d_off, (size_t)(n_pairs + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (n_copy) {
+            HIP_TRY(ctx, hipMemcpy(out_kps, d_kps, (size_t)n_copy * sizeof(mofreak_keypoint), hipMemcpyDeviceToHost));
+            if (out_response) HIP_TRY(ctx, hipMemcpy(out_response, d_resp, (size_t)n_copy * sizeof(float), hipMemcpyDeviceToHost));
+            if (out_layer) HIP_TRY(ctx, hipMemcpy(out_layer, d_layer, (size_t)n_copy * sizeof(int32_t), hipMemcpyDeviceToHost));
+        }
+    }
+    if ((st & 8) || total > capacity) return fail(ctx, MOFREAK_ERR_CAPACITY, "more keypoints than out_kps holds");
+    return MOFREAK_OK;
+}
+
+int mofreak_brisk_pyramid(mofreak_ctx *ctx, const uint8_t *img, int W, int H, int64_t row_stride, int octaves, uint8_t *layers_out,
+                          uint8_t *scores_out, int32_t *dims_out, float *scale_offset_out, int *n_layers_out, unsigned flags)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    if (!img) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null pointer");
+    if (row_stride < W) return fail(ctx, MOFREAK_ERR_BAD_ARG, "row_stride < W");
+    DetGeom g;
+    int rc = det_geometry(ctx, W, H, octaves, g);
+    if (rc) return rc;
+    if (n_layers_out) *n_layers_out = g.n_layers;
+    for (int i = 0; i < g.n_layers; ++i) {
+        if (dims_out) {
+            dims_out[2 * i] = g.L[i].w;
+            dims_out[2 * i + 1] = g.L[i].h;
+        }
+        if (scale_offset_out) {
+            scale_offset_out[2 * i] = g.L[i].scale;
+            scale_offset_out[2 * i + 1] = g.L[i].offset;
+        }
+    }
+    if (!layers_out && !scores_out) return MOFREAK_OK;
+    NEED_DEVICE(ctx);
+    const bool host = (flags & MOFREAK_MEM_HOST) != 0;
+    const Geometry geo{W, H, row_stride, 0};
+    const uint8_t *d_img = img;
+    if (host) {
+        if ((rc = upload(ctx, ctx->stage[0], img, frame_span(geo, 1)))) return rc;
+        d_img = static_cast<const uint8_t *>(ctx->stage[0].ptr);
+    }
+    DetArgs a{};
+    if ((rc = det_workspace(ctx, g, 1, a))) return rc;
+    a.n_pairs = 1;
+    a.threshold = a.safe_threshold = 255;
+    a.f = FrameArgs{d_img, nullptr, W, H, row_stride, 0};
+    HIP_TRY(ctx, hipMemsetAsync(a.row_count, 0, (size_t)(g.total_rows + 1) * sizeof(int32_t), ctx->stream));
+    int e = launch_det_pyramid(a, ctx->stream);
+    if (!e && scores_out) e = launch_det_scores(a, ctx->stream);
+    if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("detector launch: ") + hipGetErrorString((hipError_t)e));
+    const hipMemcpyKind kind = host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    size_t o = 0;
+    for (int i = 0; i < g.n_layers; ++i) {
+        const size_t n = (size_t)g.L[i].w * g.L[i].h;
+        if (n && layers_out) HIP_TRY(ctx, hipMemcpyAsync(layers_out + o, a.img + g.L[i].off, n, kind, ctx->stream));
+        if (n && scores_out) HIP_TRY(ctx, hipMemcpyAsync(scores_out + o, a.score + g.L[i].off, n, kind, ctx->stream));
+        o += n;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MOFREAK_OK;
 }
 

@@ -1,0 +1,1022 @@
+// Keypoint detector for gfx950: BRISK scale-space corners on the frame-difference image.
+//
+// Replaces, per frame pair, BriskFeatureDetector(30).detect(diff_img) (MoFREAKUtilities.cpp:420-423), i.e.
+// BriskScaleSpace::constructPyramid + getKeypoints (brisk.cpp:572-704) with the OAST 9/16 detector and the
+// AGAST 5/8 score behind them (oast9_16.cc:46, oast9_16_nms.cc:42, agast5_8_nms.cc:42).
+//
+// The reference walks its candidates one by one, asks for corner scores lazily and caches them; this design turns
+// that inside out so that every step is data parallel, and keeps the reference's results bit for bit:
+//
+//   pyramid     difference image, then the 2/3 and 1/2 resamplers as closed forms of their SSE sequences
+//               (every output byte depends on which part of the SIMD loop produced it: main blocks, the odd
+//               block, the scalar tail), one thread per output pixel
+//   scores      the corner score of EVERY pixel of every layer in one pass: the bisection around the decision
+//               tree evaluates "largest b for which some arc of 9 ring pixels is all brighter than c+b or all
+//               darker than c-b", which is max over arcs of the arc's smallest |difference|, minus one
+//   candidates  pixels with score >= threshold in raster order per layer (counted per row while scoring, scanned,
+//               scattered by one wave per row), classified by the strict part of isMax2D
+//   refinement  one thread per surviving candidate walks the layer above / below exactly as refine3D does, on
+//               the dense score maps
+//   ties        isMax2D breaks ties on the reference's RAW score cache, which holds a score only where one has
+//               been asked for before -- so the outcome depends on the processing order.  Reproduced exactly:
+//               refinement marks the cells it asks for in the layer above ("touch" map), a maximum that reaches
+//               its own 3x3 patch marks itself ("status" map), and a tie is decided from score * (detected |
+//               touched from below | inside the patch of a raster-earlier maximum).  Ties that could depend on
+//               each other are resolved in rounds by one workgroup per pair, layer by layer.
+//   emission    ordered compaction in (layer, raster) order -- the order of the reference's keypoint vector, which
+//               the rows of a .mofreak file inherit.
+//
+// Integer/byte work bound by LDS and VALU issue, no MFMA.  Floating point mirrors the reference's expressions
+// (float vs double literals) one operation at a time; compile with -ffp-contract=off.
+#include "device_helpers.h"
+
+namespace mofreak {
+namespace {
+
+constexpr int kDetThreads = 256;
+
+struct PairView {
+    const DetGeom *g;
+    const uint8_t *img;
+    const uint8_t *score;
+    uint8_t *touch;
+    uint8_t *status;
+};
+
+__device__ __forceinline__ PairView pair_view(const DetArgs &a, int p)
+{
+    PairView v;
+    v.g = &a.g;
+    const int64_t o = (int64_t)p * a.g.plane_bytes;
+    v.img = a.img + o;
+    v.score = a.score + o;
+    v.touch = a.touch + o;
+    v.status = a.status + o;
+    return v;
+}
+
+__device__ __forceinline__ int avg_u8(int a, int b) { return (a + b + 1) >> 1; }  // _mm_avg_epu8
+
+// ------------------------------------------------------------------ pyramid
+__global__ __launch_bounds__(kDetThreads) void det_diff_kernel(DetArgs a)
+{
+    const int p = blockIdx.z, y = blockIdx.y;
+    const int x0 = (blockIdx.x * kDetThreads + threadIdx.x) * 4;
+    const int W = a.g.L[0].w;
+    if (x0 >= W) return;
+    const uint8_t *c = a.f.cur + (int64_t)p * a.f.pair_stride + (int64_t)y * a.f.row_stride + x0;
+    const uint8_t *q = a.f.prev ? a.f.prev + (int64_t)p * a.f.pair_stride + (int64_t)y * a.f.row_stride + x0 : nullptr;
+    uint8_t *d = a.img + (int64_t)p * a.g.plane_bytes + a.g.L[0].off + (int64_t)y * W + x0;
+    const int n = min(4, W - x0);
+    for (int k = 0; k < n; ++k) {
+        const int u = c[k], v = q ? q[k] : 0;
+        d[k] = (uint8_t)(u > v ? u - v : v - u);  // cv::absdiff (MoFREAKUtilities.cpp:413-414)
+    }
+}
+
+// BriskLayer::halfsample (brisk.cpp:1840-1972), one output pixel per thread.
+__global__ __launch_bounds__(kDetThreads) void det_half_kernel(DetArgs a, int src_l, int dst_l)
+{
+    const DetLayer S = a.g.L[src_l], D = a.g.L[dst_l];
+    const int c = blockIdx.x * kDetThreads + threadIdx.x, r = blockIdx.y, p = blockIdx.z;
+    if (c >= D.w) return;
+    const uint8_t *u = a.img + (int64_t)p * a.g.plane_bytes + S.off + (int64_t)(2 * r) * S.w, *l = u + S.w;
+    const int hsize = S.w / 16, end = hsize / 2;
+    int out;
+    if (c < 16 * end) {  // pairs of 16-byte blocks: rounding average of the two vertical rounding averages
+        out = avg_u8(avg_u8(u[2 * c], l[2 * c]), avg_u8(u[2 * c + 1], l[2 * c + 1]));
+    } else if (c < 8 * hsize) {  // the odd block: truncating mean of the vertical averages (:1929-1933)
+        out = (avg_u8(u[2 * c], l[2 * c]) + avg_u8(u[2 * c + 1], l[2 * c + 1])) / 2;
+    } else {  // scalar tail (:1949-1956): columns k and k+1 behind the last whole block, not 2k and 2k+1
+        const int k = c - 8 * hsize, b = 16 * hsize;
+        out = (u[b + k] + u[b + k + 1] + l[b + k] + l[b + k + 1]) / 4;
+    }
+    a.img[(int64_t)p * a.g.plane_bytes + D.off + (int64_t)r * D.w + c] = (uint8_t)out;
+}
+
+// BriskLayer::twothirdsample (brisk.cpp:1974-2065), one output pixel per thread.
+__global__ __launch_bounds__(kDetThreads) void det_twothird_kernel(DetArgs a, int src_l, int dst_l)
+{
+    const DetLayer S = a.g.L[src_l], D = a.g.L[dst_l];
+    const int c = blockIdx.x * kDetThreads + threadIdx.x, r2 = blockIdx.y, p = blockIdx.z;
+    if (c >= D.w) return;
+    const int r = r2 >> 1;
+    const uint8_t *base = a.img + (int64_t)p * a.g.plane_bytes + S.off;
+    const uint8_t *mid = base + (int64_t)(3 * r + 1) * S.w;
+    const uint8_t *outer = (r2 & 1) ? mid + S.w : mid - S.w;  // third row for the lower output row, first for the upper
+    const int hsize = S.w / 15;
+    int out;
+    if (c < 10 * hsize) {
+        // shuffle masks of :1982-1984: outer column / "middle" column per output byte; the last pair reads 12, not 13
+        const int i = c / 10, m = c - 10 * i;
+        const int t2 = (int)((0xEC'B986'5320ull >> (4 * m)) & 15);  // {0,2,3,5,6,8,9,11,12,14}
+        const int t1 = (int)((0xCC'AA77'4411ull >> (4 * m)) & 15);  // {1,1,4,4,7,7,10,10,12,12}
+        const int x2 = 15 * i + t2, x1 = 15 * i + t1;
+        const int v2 = avg_u8(avg_u8(outer[x2], mid[x2]), outer[x2]);
+        const int v1 = avg_u8(avg_u8(outer[x1], mid[x1]), outer[x1]);
+        out = avg_u8(avg_u8(v2, v1), v2);
+    } else {  // scalar remainder (:2036-2052)
+        const int k = c - 10 * hsize, j = 15 * hsize + 3 * (k >> 1);
+        const int X2 = outer[j + 1], B2 = mid[j + 1];
+        const int X = (k & 1) ? outer[j + 2] : outer[j], B = (k & 1) ? mid[j + 2] : mid[j];
+        out = ((4 * X + 2 * (X2 + B) + B2) / 9) & 0xff;
+    }
+    a.img[(int64_t)p * a.g.plane_bytes + D.off + (int64_t)r2 * D.w + c] = (uint8_t)out;
+}
+
+// ------------------------------------------------------------------ dense corner scores
+// score = largest b in [1, 254] for which 9 contiguous ring pixels are all > c + b or all < c - b, 0 if none:
+// what OastDetector9_16::cornerScore's bisection converges to (oast9_16_nms.cc:42-2116), for any start value <= it.
+__device__ __forceinline__ int arc9_max_of_min(const int (&d)[16])
+{
+    int m3[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m3[k] = min(d[k], min(d[(k + 1) & 15], d[(k + 2) & 15]));
+    int best = -256;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) best = max(best, min(m3[k], min(m3[(k + 3) & 15], m3[(k + 6) & 15])));
+    return best;
+}
+
+constexpr int kScoreTileW = 64, kScoreTileH = 16, kScoreLdsW = 72;
+
+__global__ __launch_bounds__(kDetThreads) void det_score_kernel(DetArgs a, int layer)
+{
+    __shared__ uint8_t tile[(kScoreTileH + 6) * kScoreLdsW];
+    const DetLayer L = a.g.L[layer];
+    const int p = blockIdx.z, x0 = blockIdx.x * kScoreTileW, y0 = blockIdx.y * kScoreTileH;
+    const uint8_t *img = a.img + (int64_t)p * a.g.plane_bytes + L.off;
+    for (int t = threadIdx.x; t < (kScoreTileH + 6) * (kScoreTileW + 6); t += kDetThreads) {
+        const int r = t / (kScoreTileW + 6), c = t - r * (kScoreTileW + 6);
+        const int gx = x0 - 3 + c, gy = y0 - 3 + r;
+        tile[r * kScoreLdsW + c] = (gx >= 0 && gx < L.w && gy >= 0 && gy < L.h) ? img[(int64_t)gy * L.w + gx] : 0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint8_t *score = a.score + (int64_t)p * a.g.plane_bytes + L.off;
+    int32_t *row_count = a.row_count + (int64_t)p * (a.g.total_rows + 1) + L.row_base;
+#pragma unroll
+    for (int it = 0; it < kScoreTileH / 4; ++it) {
+        const int ry = wave + 4 * it, x = x0 + lane, y = y0 + ry;
+        int s = 0;
+        if (x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3) {
+            const uint8_t *t = tile + (ry + 3) * kScoreLdsW + lane + 3;
+            const int c = t[0];
+            int d[16];
+            // Bresenham circle of radius 3 in the order of OastDetector9_16::init_pattern (oast9_16.h:74-92)
+            d[0] = t[-3] - c;
+            d[1] = t[-kScoreLdsW - 3] - c;
+            d[2] = t[-2 * kScoreLdsW - 2] - c;
+            d[3] = t[-3 * kScoreLdsW - 1] - c;
+            d[4] = t[-3 * kScoreLdsW] - c;
+            d[5] = t[-3 * kScoreLdsW + 1] - c;
+            d[6] = t[-2 * kScoreLdsW + 2] - c;
+            d[7] = t[-kScoreLdsW + 3] - c;
+            d[8] = t[3] - c;
+            d[9] = t[kScoreLdsW + 3] - c;
+            d[10] = t[2 * kScoreLdsW + 2] - c;
+            d[11] = t[3 * kScoreLdsW + 1] - c;
+            d[12] = t[3 * kScoreLdsW] - c;
+            d[13] = t[3 * kScoreLdsW - 1] - c;
+            d[14] = t[2 * kScoreLdsW - 2] - c;
+            d[15] = t[kScoreLdsW - 3] - c;
+            const int vb = arc9_max_of_min(d);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) d[k] = -d[k];
+            const int vd = arc9_max_of_min(d);
+            s = max(max(vb, vd) - 1, 0);
+        }
+        if (x < L.w && y < L.h) score[(int64_t)y * L.w + x] = (uint8_t)s;
+        const unsigned long long hit = __ballot(s >= a.safe_threshold);
+        if (lane == 0 && hit && y < L.h) atomicAdd(&row_count[y], __popcll(hit));
+    }
+}
+
+// exclusive scan of the per-row detection counts of one pair (all layers); one workgroup per pair
+__global__ __launch_bounds__(kDetThreads) void det_scan_kernel(DetArgs a)
+{
+    __shared__ int part[kDetThreads];
+    const int p = blockIdx.x, n = a.g.total_rows;
+    int32_t *rc = a.row_count + (int64_t)p * (n + 1);
+    const int per = (n + kDetThreads - 1) / kDetThreads;
+    const int lo = min(threadIdx.x * per, n), hi = min(lo + per, n);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += rc[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < kDetThreads; o <<= 1) {
+        const int t = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+    for (int i = lo; i < hi; ++i) {
+        const int c = rc[i];
+        rc[i] = run;
+        run += c;
+    }
+    __syncthreads();
+    if (threadIdx.x == kDetThreads - 1) {
+        const int total = part[kDetThreads - 1];
+        rc[n] = total;
+        if (total > a.cand_cap) atomicOr(a.status_word, 4);
+    }
+    __syncthreads();
+    if (threadIdx.x <= a.g.n_layers) {
+        const int l = threadIdx.x;
+        const int v = l < a.g.n_layers ? rc[a.g.L[l].row_base] : rc[n];
+        a.layer_start[(int64_t)p * (kDetMaxLayers + 1) + l] = min(v, a.cand_cap);
+    }
+}
+
+// one wave per layer row: the row's detections in x order, and the strict part of isMax2D (brisk.cpp:838-872)
+__global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
+{
+    const int p = blockIdx.y, row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= a.g.total_rows) return;
+    int layer = 0;
+    while (layer + 1 < a.g.n_layers && row >= a.g.L[layer + 1].row_base) ++layer;
+    const DetLayer L = a.g.L[layer];
+    const int y = row - L.row_base;
+    if (y < 3 || y >= L.h - 3) return;
+    const int32_t *rc = a.row_count + (int64_t)p * (a.g.total_rows + 1);
+    int base = rc[row];
+    if (rc[row + 1] == base) return;
+    const int64_t plane = (int64_t)p * a.g.plane_bytes + L.off;
+    const uint8_t *sc = a.score + plane;
+    const int64_t cbase = (int64_t)p * a.cand_cap;
+    for (int x0 = 0; x0 < L.w; x0 += 64) {
+        const int x = x0 + lane;
+        const int s = x < L.w ? sc[(int64_t)y * L.w + x] : 0;
+        const bool hit = s >= a.safe_threshold;  // the score is zero outside the detector's 3-pixel border
+        const unsigned long long m = __ballot(hit);
+        if (hit) {
+            const int idx = base + __popcll(m & ((1ull << lane) - 1));
+            if (idx < a.cand_cap) {
+                const uint8_t *q = sc + (int64_t)y * L.w + x;
+                int hi = 0, eq = 0;
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        if (dx == 0 && dy == 0) continue;
+                        const int v = q[dy * L.w + dx];
+                        hi |= v > s;
+                        eq |= v == s;
+                    }
+                const uint8_t flag = hi ? kDetNotMax : (eq ? kDetTie : kDetMax);
+                a.cand_xy[cbase + idx] = (uint32_t)x | ((uint32_t)y << 16);
+                a.cand_flag[cbase + idx] = flag;
+                a.cand_emit[cbase + idx] = 0;
+                if (flag == kDetTie) a.status[plane + (int64_t)y * L.w + x] = kStPending;
+            }
+        }
+        base += __popcll(m);
+    }
+}
+
+// ------------------------------------------------------------------ refinement (thread per maximum)
+// BriskLayer::getAgastScore(int, int, 1) (brisk.cpp:1685-1694) on the dense map.  MARK: record that the reference
+// would have asked for (and therefore cached) this cell -- only cells of the layer ABOVE the walker matter later.
+template <bool MARK>
+__device__ __forceinline__ int score_at(const PairView &v, int layer, int x, int y)
+{
+    const DetLayer &L = v.g->L[layer];
+    if (x < 3 || y < 3 || x >= L.w - 3 || y >= L.h - 3) return 0;
+    const int64_t o = L.off + (int64_t)y * L.w + x;
+    if (MARK) v.touch[o] = 1;
+    return v.score[o];
+}
+
+// getAgastScore(float, float, 1, scale = 1) (:1705-1720): bilinear, returned through uint8_t
+template <bool MARK>
+__device__ __forceinline__ int score_f(const PairView &v, int layer, float xf, float yf)
+{
+    const int x = (int)xf;
+    const float rx1 = xf - (float)x;
+    const float rx = 1.0f - rx1;
+    const int y = (int)yf;
+    const float ry1 = yf - (float)y;
+    const float ry = 1.0f - ry1;
+    const float s00 = (float)score_at<MARK>(v, layer, x, y);
+    const float s10 = (float)score_at<MARK>(v, layer, x + 1, y);
+    const float s01 = (float)score_at<MARK>(v, layer, x, y + 1);
+    const float s11 = (float)score_at<MARK>(v, layer, x + 1, y + 1);
+    const float r = rx * ry * s00 + rx1 * ry * s10 + rx * ry1 * s01 + rx1 * ry1 * s11;
+    return (int)r & 0xff;
+}
+
+// AgastDetector5_8::cornerScore from b = 0 (agast5_8_nms.cc:42; brisk.cpp:1696-1703): 5 contiguous of the 8 neighbours
+__device__ int score_5_8(const PairView &v, int x, int y)
+{
+    const DetLayer &L = v.g->L[0];
+    if (x < 2 || y < 2 || x >= L.w - 2 || y >= L.h - 2) return 0;
+    const uint8_t *t = v.img + L.off + (int64_t)y * L.w + x;
+    const int c = t[0], w = L.w;
+    int d[8];
+    d[0] = t[-1] - c;  // init_pattern order (agast5_8.h:66-76)
+    d[1] = t[-w - 1] - c;
+    d[2] = t[-w] - c;
+    d[3] = t[-w + 1] - c;
+    d[4] = t[1] - c;
+    d[5] = t[w + 1] - c;
+    d[6] = t[w] - c;
+    d[7] = t[w - 1] - c;
+    int vb = -256, vd = -256;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int mn = d[k], mx = d[k];
+#pragma unroll
+        for (int j = 1; j < 5; ++j) {
+            mn = min(mn, d[(k + j) & 7]);
+            mx = max(mx, d[(k + j) & 7]);
+        }
+        vb = max(vb, mn);
+        vd = max(vd, -mx);
+    }
+    return max(max(vb, vd) - 1, 0);
+}
+
+// BriskScaleSpace::subpixel2D (brisk.cpp:1535-1644); s = s_0_0, s_0_1, s_0_2, s_1_0, ... (first index x)
+__device__ float subpixel2d(const int (&s)[9], float &delta_x, float &delta_y)
+{
+    const int s_0_0 = s[0], s_0_1 = s[1], s_0_2 = s[2], s_1_0 = s[3], s_1_1 = s[4], s_1_2 = s[5], s_2_0 = s[6], s_2_1 = s[7],
+              s_2_2 = s[8];
+    const int tmp1 = s_0_0 + s_0_2 - 2 * s_1_1 + s_2_0 + s_2_2;
+    const int coeff1 = 3 * (tmp1 + s_0_1 - ((s_1_0 + s_1_2) * 2) + s_2_1);
+    const int coeff2 = 3 * (tmp1 - ((s_0_1 + s_2_1) * 2) + s_1_0 + s_1_2);
+    const int tmp2 = s_0_2 - s_2_0;
+    const int tmp3 = (s_0_0 + tmp2 - s_2_2);
+    const int tmp4 = tmp3 - 2 * tmp2;
+    const int coeff3 = -3 * (tmp3 + s_0_1 - s_2_1);
+    const int coeff4 = -3 * (tmp4 + s_1_0 - s_1_2);
+    const int coeff5 = (s_0_0 - s_0_2 - s_2_0 + s_2_2) * 4;
+    const int coeff6 = (-(s_0_0 + s_0_2 - ((s_1_0 + s_0_1 + s_1_2 + s_2_1) * 2) - 5 * s_1_1 + s_2_0 + s_2_2)) * 2;
+    const int H_det = 4 * coeff1 * coeff2 - coeff5 * coeff5;
+    if (H_det == 0) {
+        delta_x = 0.0f;
+        delta_y = 0.0f;
+        return (float)((double)(float)coeff6 / 18.0);
+    }
+    if (!(H_det > 0 && coeff1 < 0)) {  // the maximum is at one of the four patch corners
+        int tmp_max = coeff3 + coeff4 + coeff5;
+        delta_x = 1.0f;
+        delta_y = 1.0f;
+        int tmp = -coeff3 + coeff4 - coeff5;
+        if (tmp > tmp_max) {
+            tmp_max = tmp;
+            delta_x = -1.0f;
+            delta_y = 1.0f;
+        }
+        tmp = coeff3 - coeff4 - coeff5;
+        if (tmp > tmp_max) {
+            tmp_max = tmp;
+            delta_x = 1.0f;
+            delta_y = -1.0f;
+        }
+        tmp = -coeff3 - coeff4 + coeff5;
+        if (tmp > tmp_max) {
+            tmp_max = tmp;
+            delta_x = -1.0f;
+            delta_y = -1.0f;
+        }
+        return (float)((double)(float)(tmp_max + coeff1 + coeff2 + coeff6) / 18.0);
+    }
+    const float dx = (float)(2 * coeff2 * coeff3 - coeff4 * coeff5) / (float)(-H_det);
+    const float dy = (float)(2 * coeff1 * coeff4 - coeff3 * coeff5) / (float)(-H_det);
+    bool tx = false, tx_ = false, ty = false, ty_ = false;
+    if ((double)dx > 1.0)
+        tx = true;
+    else if ((double)dx < -1.0)
+        tx_ = true;
+    if ((double)dy > 1.0) ty = true;
+    if ((double)dy < -1.0) ty_ = true;
+    const float c1 = (float)coeff1, c2 = (float)coeff2, c3 = (float)coeff3, c4 = (float)coeff4, c5 = (float)coeff5, c6 = (float)coeff6;
+    if (tx || tx_ || ty || ty_) {
+        float dx1 = 0.0f, dx2 = 0.0f, dy1 = 0.0f, dy2 = 0.0f;
+        if (tx) {
+            dx1 = 1.0f;
+            dy1 = -(float)(coeff4 + coeff5) / (float)(2 * coeff2);
+            if ((double)dy1 > 1.0) dy1 = 1.0f; else if ((double)dy1 < -1.0) dy1 = -1.0f;
+        } else if (tx_) {
+            dx1 = -1.0f;
+            dy1 = -(float)(coeff4 - coeff5) / (float)(2 * coeff2);
+            if ((double)dy1 > 1.0) dy1 = 1.0f; else if ((double)dy1 < -1.0) dy1 = -1.0f;
+        }
+        if (ty) {
+            dy2 = 1.0f;
+            dx2 = -(float)(coeff3 + coeff5) / (float)(2 * coeff1);
+            if ((double)dx2 > 1.0) dx2 = 1.0f; else if ((double)dx2 < -1.0) dx2 = -1.0f;
+        } else if (ty_) {
+            dy2 = -1.0f;
+            dx2 = -(float)(coeff3 - coeff5) / (float)(2 * coeff1);
+            if ((double)dx2 > 1.0) dx2 = 1.0f; else if ((double)dx2 < -1.0) dx2 = -1.0f;
+        }
+        const float max1 = (float)((double)(c1 * dx1 * dx1 + c2 * dy1 * dy1 + c3 * dx1 + c4 * dy1 + c5 * dx1 * dy1 + c6) / 18.0);
+        const float max2 = (float)((double)(c1 * dx2 * dx2 + c2 * dy2 * dy2 + c3 * dx2 + c4 * dy2 + c5 * dx2 * dy2 + c6) / 18.0);
+        if (max1 > max2) {
+            delta_x = dx1;
+            delta_y = dx1;  // sic (:1629)
+            return max1;
+        }
+        delta_x = dx2;
+        delta_y = dx2;  // sic (:1634)
+        return max2;
+    }
+    delta_x = dx;
+    delta_y = dy;
+    return (float)((double)(c1 * dx * dx + c2 * dy * dy + c3 * dx + c4 * dy + c5 * dx * dy + c6) / 18.0);
+}
+
+// refine1D (variant 0, :1418), refine1D_1 (1, :1459), refine1D_2 (2, :1499)
+__device__ float refine1d(int variant, float s_05, float s0, float s05, float &max)
+{
+    const int i_05 = (int)(1024.0 * (double)s_05 + 0.5);
+    const int i0 = (int)(1024.0 * (double)s0 + 0.5);
+    const int i05 = (int)(1024.0 * (double)s05 + 0.5);
+    int qa, qb, qc;
+    double lo_d, hi_d;
+    if (variant == 0) {
+        qa = 16 * i_05 - 24 * i0 + 8 * i05;
+        qb = -40 * i_05 + 54 * i0 - 14 * i05;
+        qc = +24 * i_05 - 27 * i0 + 6 * i05;
+        lo_d = 0.75;
+        hi_d = 1.5;
+    } else if (variant == 1) {
+        qa = 9 * i_05 - 18 * i0 + 9 * i05;
+        qb = -21 * i_05 + 36 * i0 - 15 * i05;
+        qc = +12 * i_05 - 16 * i0 + 6 * i05;
+        lo_d = 0.6666666666666666666666666667;
+        hi_d = 1.33333333333333333333333333;
+    } else {
+        qa = 2 * i_05 - 4 * i0 + 2 * i05;
+        qb = -5 * i_05 + 8 * i0 - 3 * i05;
+        qc = +3 * i_05 - 3 * i0 + 1 * i05;
+        lo_d = 0.7;
+        hi_d = 1.5;
+    }
+    if (qa >= 0) {  // second derivative must be negative
+        if (s0 >= s_05 && s0 >= s05) {
+            max = s0;
+            return 1.0f;
+        }
+        if (s_05 >= s0 && s_05 >= s05) {
+            max = s_05;
+            return (float)lo_d;
+        }
+        if (s05 >= s0 && s05 >= s_05) {
+            max = s05;
+            return (float)(variant == 1 ? 1.3333333333333333333333333333 : 1.5);
+        }
+    }
+    float ret_val = -(float)qb / (float)(2 * qa);
+    if ((double)ret_val < lo_d)
+        ret_val = (float)lo_d;
+    else if ((double)ret_val > hi_d)
+        ret_val = (float)hi_d;
+    float m = (float)qc + (float)qa * ret_val * ret_val + (float)qb * ret_val;
+    if (variant == 2)
+        m = m / 1024.0f;
+    else
+        m = (float)((double)m / (variant == 0 ? 3072.0 : 2048.0));
+    max = m;
+    return ret_val;
+}
+
+template <bool MARK>
+__device__ float patch_subpixel(const PairView &v, int layer, int x, int y, float &dx, float &dy)
+{
+    int s[9];
+    s[0] = score_at<MARK>(v, layer, x - 1, y - 1);
+    s[1] = score_at<MARK>(v, layer, x - 1, y);
+    s[2] = score_at<MARK>(v, layer, x - 1, y + 1);
+    s[3] = score_at<MARK>(v, layer, x, y - 1);
+    s[4] = score_at<MARK>(v, layer, x, y);
+    s[5] = score_at<MARK>(v, layer, x, y + 1);
+    s[6] = score_at<MARK>(v, layer, x + 1, y - 1);
+    s[7] = score_at<MARK>(v, layer, x + 1, y);
+    s[8] = score_at<MARK>(v, layer, x + 1, y + 1);
+    return subpixel2d(s, dx, dy);
+}
+
+// getScoreMaxAbove (ABOVE, brisk.cpp:1106-1249) / getScoreMaxBelow (:1251-1416)
+template <bool ABOVE>
+__device__ float neighbour_layer_max(const PairView &v, int layer, int x_layer, int y_layer, int threshold, bool &ismax, float &dx, float &dy)
+{
+    ismax = false;
+    const int nl = ABOVE ? layer + 1 : layer - 1;
+    const bool octave = (layer & 1) == 0;
+    float x_1, x1, y_1, y1;
+    if (ABOVE) {
+        if (octave) {  // double division (:1123-1126)
+            x_1 = (float)((double)(float)(4 * x_layer - 1 - 2) / 6.0);
+            x1 = (float)((double)(float)(4 * x_layer - 1 + 2) / 6.0);
+            y_1 = (float)((double)(float)(4 * y_layer - 1 - 2) / 6.0);
+            y1 = (float)((double)(float)(4 * y_layer - 1 + 2) / 6.0);
+        } else {  // float division (:1130-1133)
+            x_1 = (float)(6 * x_layer - 1 - 3) / 8.0f;
+            x1 = (float)(6 * x_layer - 1 + 3) / 8.0f;
+            y_1 = (float)(6 * y_layer - 1 - 3) / 8.0f;
+            y1 = (float)(6 * y_layer - 1 + 3) / 8.0f;
+        }
+    } else {
+        if (octave) {
+            x_1 = (float)((double)(float)(8 * x_layer + 1 - 4) / 6.0);
+            x1 = (float)((double)(float)(8 * x_layer + 1 + 4) / 6.0);
+            y_1 = (float)((double)(float)(8 * y_layer + 1 - 4) / 6.0);
+            y1 = (float)((double)(float)(8 * y_layer + 1 + 4) / 6.0);
+        } else {
+            x_1 = (float)((double)(float)(6 * x_layer + 1 - 3) / 4.0);
+            x1 = (float)((double)(float)(6 * x_layer + 1 + 3) / 4.0);
+            y_1 = (float)((double)(float)(6 * y_layer + 1 - 3) / 4.0);
+            y1 = (float)((double)(float)(6 * y_layer + 1 + 3) / 4.0);
+        }
+    }
+    const float thr = (float)threshold;
+    const int xa = (int)(x_1 + 1), xb = (int)x1, ya = (int)(y_1 + 1), yb = (int)y1;
+
+    // first row
+    int max_x = xa, max_y = ya;
+    float tmp_max;
+    float max = (float)score_f<ABOVE>(v, nl, x_1, y_1);
+    if (max > thr) return 0;
+    for (int x = xa; x <= xb; x++) {
+        tmp_max = (float)score_f<ABOVE>(v, nl, (float)x, y_1);
+        if (tmp_max > thr) return 0;
+        if (tmp_max > max) {
+            max = tmp_max;
+            max_x = x;
+        }
+    }
+    tmp_max = (float)score_f<ABOVE>(v, nl, x1, y_1);
+    if (tmp_max > thr) return 0;
+    if (tmp_max > max) {
+        max = tmp_max;
+        max_x = xb;
+    }
+    // middle rows
+    for (int y = ya; y <= yb; y++) {
+        tmp_max = (float)score_f<ABOVE>(v, nl, x_1, (float)y);
+        if (tmp_max > thr) return 0;
+        if (tmp_max > max) {
+            max = tmp_max;
+            max_x = xa;
+            max_y = y;
+        }
+        for (int x = xa; x <= xb; x++) {
+            tmp_max = (float)score_at<ABOVE>(v, nl, x, y);
+            if (tmp_max > thr) return 0;
+            if (!ABOVE && tmp_max == max) {  // :1321-1344 (below only)
+                const int t1 = 2 * (score_at<false>(v, nl, x - 1, y) + score_at<false>(v, nl, x + 1, y) + score_at<false>(v, nl, x, y + 1) +
+                                    score_at<false>(v, nl, x, y - 1)) +
+                               (score_at<false>(v, nl, x + 1, y + 1) + score_at<false>(v, nl, x - 1, y + 1) +
+                                score_at<false>(v, nl, x + 1, y - 1) + score_at<false>(v, nl, x - 1, y - 1));
+                const int t2 = 2 * (score_at<false>(v, nl, max_x - 1, max_y) + score_at<false>(v, nl, max_x + 1, max_y) +
+                                    score_at<false>(v, nl, max_x, max_y + 1) + score_at<false>(v, nl, max_x, max_y - 1)) +
+                               (score_at<false>(v, nl, max_x + 1, max_y + 1) + score_at<false>(v, nl, max_x - 1, max_y + 1) +
+                                score_at<false>(v, nl, max_x + 1, max_y - 1) + score_at<false>(v, nl, max_x - 1, max_y - 1));
+                if (t1 > t2) {
+                    max_x = x;
+                    max_y = y;
+                }
+            }
+            if (tmp_max > max) {
+                max = tmp_max;
+                max_x = x;
+                max_y = y;
+            }
+        }
+        tmp_max = (float)score_f<ABOVE>(v, nl, x1, (float)y);
+        if (tmp_max > thr) return 0;
+        if (tmp_max > max) {
+            max = tmp_max;
+            max_x = xb;
+            max_y = y;
+        }
+    }
+    // bottom row: no early exit
+    tmp_max = (float)score_f<ABOVE>(v, nl, x_1, y1);
+    if (tmp_max > max) {
+        max = tmp_max;
+        max_x = xa;
+        max_y = yb;
+    }
+    for (int x = xa; x <= xb; x++) {
+        tmp_max = (float)score_f<ABOVE>(v, nl, (float)x, y1);
+        if (tmp_max > max) {
+            max = tmp_max;
+            max_x = x;
+            max_y = yb;
+        }
+    }
+    tmp_max = (float)score_f<ABOVE>(v, nl, x1, y1);
+    if (tmp_max > max) {
+        max = tmp_max;
+        max_x = xb;
+        max_y = yb;
+    }
+
+    float dx_1, dy_1;
+    const float refined_max = patch_subpixel<ABOVE>(v, nl, max_x, max_y, dx_1, dy_1);
+    const float real_x = (float)max_x + dx_1;
+    const float real_y = (float)max_y + dy_1;
+    bool returnrefined = true;
+    if (ABOVE) {
+        if (octave) {  // float arithmetic (:1228-1229)
+            dx = (real_x * 6.0f + 1.0f) / 4.0f - (float)x_layer;
+            dy = (real_y * 6.0f + 1.0f) / 4.0f - (float)y_layer;
+        } else {  // double arithmetic (:1232-1233)
+            dx = (float)(((double)real_x * 8.0 + 1.0) / 6.0 - (double)(float)x_layer);
+            dy = (float)(((double)real_y * 8.0 + 1.0) / 6.0 - (double)(float)y_layer);
+        }
+    } else {
+        if (octave) {
+            dx = (float)(((double)real_x * 6.0 + 1.0) / 8.0 - (double)(float)x_layer);
+            dy = (float)(((double)real_y * 6.0 + 1.0) / 8.0 - (double)(float)y_layer);
+        } else {
+            dx = (float)(((double)real_x * 4.0 - 1.0) / 6.0 - (double)(float)x_layer);
+            dy = (float)(((double)real_y * 4.0 - 1.0) / 6.0 - (double)(float)y_layer);
+        }
+    }
+    if (dx > 1.0f) { dx = 1.0f; returnrefined = false; }
+    if (dx < -1.0f) { dx = -1.0f; returnrefined = false; }
+    if (dy > 1.0f) { dy = 1.0f; returnrefined = false; }
+    if (dy < -1.0f) { dy = -1.0f; returnrefined = false; }
+    ismax = true;
+    if (returnrefined) return refined_max < max ? max : refined_max;  // std::max(refined_max, max)
+    return max;
+}
+
+struct Refined {
+    bool emit, reached;  // reached: the walk got as far as the 3x3 patch on its own layer (those cells are cached from then on)
+    DetResult r;
+};
+
+// What getKeypoints does with one 2-D maximum (brisk.cpp:609-702), refine3D included (:937-1103).
+__device__ Refined refine_maximum(const PairView &v, int layer, int px, int py, int threshold)
+{
+    const float basicSize = 12.0f;
+    const DetGeom &g = *v.g;
+    const DetLayer &L = g.L[layer];
+    Refined out;
+    out.emit = false;
+    out.reached = false;
+    out.r = DetResult{0.f, 0.f, 0.f, 0.f};
+    float delta_x_layer, delta_y_layer;
+    if (g.n_layers == 1) {  // :609-638
+        const float peak = patch_subpixel<false>(v, 0, px, py, delta_x_layer, delta_y_layer);
+        out.reached = true;
+        out.emit = true;
+        out.r = DetResult{(float)px + delta_x_layer, (float)py + delta_y_layer, basicSize, peak};
+        return out;
+    }
+    const int center = score_at<false>(v, layer, px, py);
+    bool ismax;
+    if (layer == g.n_layers - 1) {  // :644-679
+        float dx, dy;
+        (void)neighbour_layer_max<false>(v, layer, px, py, center, ismax, dx, dy);
+        if (!ismax) return out;
+        const float peak = patch_subpixel<false>(v, layer, px, py, delta_x_layer, delta_y_layer);
+        out.reached = true;
+        out.emit = true;
+        out.r = DetResult{((float)px + delta_x_layer) * L.scale + L.offset, ((float)py + delta_y_layer) * L.scale + L.offset, basicSize * L.scale, peak};
+        return out;
+    }
+    // refine3D
+    float delta_x_above, delta_y_above, delta_x_below, delta_y_below;
+    const float max_above = neighbour_layer_max<true>(v, layer, px, py, center, ismax, delta_x_above, delta_y_above);
+    if (!ismax) return out;
+    float best, scale, x, y;
+    if ((layer & 1) == 0) {  // octave
+        float max_below_float;
+        if (layer == 0) {  // guess the missing layer below with the 5/8 mask (:959-989)
+            int s[9];
+            int mb;
+            s[0] = score_5_8(v, px - 1, py - 1);
+            mb = s[0];
+            s[3] = score_5_8(v, px, py - 1);
+            mb = max(mb, s[3]);
+            s[6] = score_5_8(v, px + 1, py - 1);
+            mb = max(mb, s[6]);
+            s[7] = score_5_8(v, px + 1, py);
+            mb = max(mb, s[7]);
+            s[4] = score_5_8(v, px, py);
+            mb = max(mb, s[4]);
+            s[1] = score_5_8(v, px - 1, py);
+            mb = max(mb, s[1]);
+            s[2] = score_5_8(v, px - 1, py + 1);
+            mb = max(mb, s[2]);
+            s[5] = score_5_8(v, px, py + 1);
+            mb = max(mb, s[5]);
+            s[8] = score_5_8(v, px + 1, py + 1);
+            mb = max(mb, s[8]);
+            (void)subpixel2d(s, delta_x_below, delta_y_below);
+            max_below_float = (float)mb;
+        } else {
+            max_below_float = neighbour_layer_max<false>(v, layer, px, py, center, ismax, delta_x_below, delta_y_below);
+            if (!ismax) return out;
+        }
+        const float max_layer = patch_subpixel<false>(v, layer, px, py, delta_x_layer, delta_y_layer);
+        out.reached = true;
+        const float s0 = ((float)center < max_layer) ? max_layer : (float)center;
+        scale = refine1d(layer == 0 ? 2 : 0, max_below_float, s0, max_above, best);
+        if ((double)scale > 1.0) {
+            const float r0 = (float)((1.5 - (double)scale) / .5);
+            const float r1 = (float)(1.0 - (double)r0);
+            x = (r0 * delta_x_layer + r1 * delta_x_above + (float)px) * L.scale + L.offset;
+            y = (r0 * delta_y_layer + r1 * delta_y_above + (float)py) * L.scale + L.offset;
+        } else if (layer == 0) {
+            const float r0 = (float)(((double)scale - 0.5) / 0.5);
+            const float r_1 = (float)(1.0 - (double)r0);
+            x = r0 * delta_x_layer + r_1 * delta_x_below + (float)px;
+            y = r0 * delta_y_layer + r_1 * delta_y_below + (float)py;
+        } else {
+            const float r0 = (float)(((double)scale - 0.75) / 0.25);
+            const float r_1 = (float)(1.0 - (double)r0);
+            x = (r0 * delta_x_layer + r_1 * delta_x_below + (float)px) * L.scale + L.offset;
+            y = (r0 * delta_y_layer + r_1 * delta_y_below + (float)py) * L.scale + L.offset;
+        }
+    } else {  // intra
+        const float max_below = neighbour_layer_max<false>(v, layer, px, py, center, ismax, delta_x_below, delta_y_below);
+        if (!ismax) return out;
+        const float max_layer = patch_subpixel<false>(v, layer, px, py, delta_x_layer, delta_y_layer);
+        out.reached = true;
+        const float s0 = ((float)center < max_layer) ? max_layer : (float)center;
+        scale = refine1d(1, max_below, s0, max_above, best);
+        if ((double)scale > 1.0) {
+            const float r0 = (float)(4.0 - (double)scale * 3.0);
+            const float r1 = (float)(1.0 - (double)r0);
+            x = (r0 * delta_x_layer + r1 * delta_x_above + (float)px) * L.scale + L.offset;
+            y = (r0 * delta_y_layer + r1 * delta_y_above + (float)py) * L.scale + L.offset;
+        } else {
+            const float r0 = (float)((double)scale * 3.0 - 2.0);
+            const float r_1 = (float)(1.0 - (double)r0);
+            x = (r0 * delta_x_layer + r_1 * delta_x_below + (float)px) * L.scale + L.offset;
+            y = (r0 * delta_y_layer + r_1 * delta_y_below + (float)py) * L.scale + L.offset;
+        }
+    }
+    scale *= L.scale;
+    if (best > (float)threshold) {  // :698
+        out.emit = true;
+        out.r = DetResult{x, y, basicSize * scale, best};
+    }
+    return out;
+}
+
+__device__ __forceinline__ int layer_of(const int32_t *layer_start, int n_layers, int i)
+{
+    int l = 0;
+    while (l + 1 < n_layers && i >= layer_start[l + 1]) ++l;
+    return l;
+}
+
+__device__ void finish_candidate(const DetArgs &a, const PairView &v, int p, int i, int layer, int x, int y)
+{
+    const Refined r = refine_maximum(v, layer, x, y, a.threshold);
+    const int64_t ci = (int64_t)p * a.cand_cap + i;
+    a.cand_emit[ci] = r.emit ? 1 : 0;
+    a.cand_res[ci] = r.r;
+    const DetLayer &L = a.g.L[layer];
+    v.status[L.off + (int64_t)y * L.w + x] = r.reached ? kStReached : kStDone;
+}
+
+// maxima without ties: independent of everything else
+__global__ __launch_bounds__(kDetThreads) void det_refine_kernel(DetArgs a)
+{
+    const int p = blockIdx.y, i = blockIdx.x * kDetThreads + threadIdx.x;
+    const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
+    if (i >= ls[a.g.n_layers]) return;
+    const int64_t ci = (int64_t)p * a.cand_cap + i;
+    if (a.cand_flag[ci] != kDetMax) return;
+    const uint32_t xy = a.cand_xy[ci];
+    const PairView v = pair_view(a, p);
+    finish_candidate(a, v, p, i, layer_of(ls, a.g.n_layers, i), (int)(xy & 0xffff), (int)(xy >> 16));
+}
+
+// ---- ties
+constexpr uint8_t kDetTieReady = 3;
+
+// The reference's score cache cell at q = (qx, qy) as candidate (px, py) would find it (see the header comment).
+__device__ int raw_score(const PairView &v, const DetLayer &L, int safe_threshold, int qx, int qy, int px, int py)
+{
+    if (qx < 3 || qy < 3 || qx >= L.w - 3 || qy >= L.h - 3) return 0;
+    const int64_t o = L.off + (int64_t)qy * L.w + qx;
+    const int s = v.score[o];
+    if (s == 0 || s >= safe_threshold || v.touch[o]) return s;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int mx = qx + dx, my = qy + dy;
+            if (my > py || (my == py && mx >= px)) continue;  // only maxima processed before this candidate
+            if (mx < 0 || my < 0 || mx >= L.w || my >= L.h) continue;
+            if (v.status[L.off + (int64_t)my * L.w + mx] == kStReached) return s;
+        }
+    return 0;
+}
+
+// the smoothing part of isMax2D (brisk.cpp:874-933) on the emulated cache
+__device__ bool tie_is_max(const PairView &v, const DetLayer &L, int safe_threshold, int px, int py)
+{
+    int r[5][5];
+    for (int dy = -2; dy <= 2; ++dy)
+        for (int dx = -2; dx <= 2; ++dx) r[dy + 2][dx + 2] = raw_score(v, L, safe_threshold, px + dx, py + dy, px, py);
+    const int center = r[2][2];
+    auto smooth = [&](int cx, int cy) {  // 1 2 1 / 2 4 2 / 1 2 1 around (cx, cy) in window coordinates
+        return r[cy - 1][cx - 1] + 2 * r[cy - 1][cx] + r[cy - 1][cx + 1] + 2 * r[cy][cx - 1] + 4 * r[cy][cx] + 2 * r[cy][cx + 1] + r[cy + 1][cx - 1] +
+               2 * r[cy + 1][cx] + r[cy + 1][cx + 1];
+    };
+    const int smoothedcenter = smooth(2, 2);
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            if (dx == 0 && dy == 0) continue;
+            if (r[2 + dy][2 + dx] != center) continue;
+            if (smooth(2 + dx, 2 + dy) > smoothedcenter) return false;
+        }
+    return true;
+}
+
+// one workgroup per pair: layer by layer, rounds of mutually independent ties
+__global__ __launch_bounds__(kDetThreads) void det_tie_kernel(DetArgs a)
+{
+    __shared__ int remaining;
+    const int p = blockIdx.x;
+    const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
+    const PairView v = pair_view(a, p);
+    const int64_t cb = (int64_t)p * a.cand_cap;
+    for (int layer = 0; layer < a.g.n_layers; ++layer) {
+        const DetLayer L = a.g.L[layer];
+        const int lo = ls[layer], hi = ls[layer + 1];
+        for (;;) {
+            if (threadIdx.x == 0) remaining = 0;
+            __syncthreads();
+            // phase 1: a tie is ready when no undecided tie that precedes it could still change the cells it reads
+            for (int i = lo + threadIdx.x; i < hi; i += kDetThreads) {
+                if (a.cand_flag[cb + i] != kDetTie) continue;
+                const uint32_t xy = a.cand_xy[cb + i];
+                const int px = (int)(xy & 0xffff), py = (int)(xy >> 16);
+                bool ready = true;
+                for (int dy = -3; dy <= 0 && ready; ++dy)
+                    for (int dx = -3; dx <= 3; ++dx) {
+                        if (dy == 0 && dx >= 0) break;
+                        const int mx = px + dx, my = py + dy;
+                        if (mx < 0 || my < 0 || mx >= L.w) continue;
+                        if (v.status[L.off + (int64_t)my * L.w + mx] == kStPending) {
+                            ready = false;
+                            break;
+                        }
+                    }
+                if (ready)
+                    a.cand_flag[cb + i] = kDetTieReady;
+                else
+                    atomicAdd(&remaining, 1);
+            }
+            __threadfence_block();
+            __syncthreads();
+            // phase 2: decide the ready ones
+            for (int i = lo + threadIdx.x; i < hi; i += kDetThreads) {
+                if (a.cand_flag[cb + i] != kDetTieReady) continue;
+                const uint32_t xy = a.cand_xy[cb + i];
+                const int px = (int)(xy & 0xffff), py = (int)(xy >> 16);
+                if (tie_is_max(v, L, a.safe_threshold, px, py)) {
+                    a.cand_flag[cb + i] = kDetMax;
+                    finish_candidate(a, v, p, i, layer, px, py);
+                } else {
+                    a.cand_flag[cb + i] = kDetNotMax;
+                    v.status[L.off + (int64_t)py * L.w + px] = kStDone;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (remaining == 0) break;
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------ ordered emission
+__global__ __launch_bounds__(kDetThreads) void det_emit_count_kernel(DetArgs a)
+{
+    __shared__ int total;
+    const int p = blockIdx.x;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    const int n = a.layer_start[(int64_t)p * (kDetMaxLayers + 1) + a.g.n_layers];
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += kDetThreads) c += a.cand_emit[(int64_t)p * a.cand_cap + i];
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&total, c);
+    __syncthreads();
+    if (threadIdx.x == 0) a.emit_count[p] = total;
+}
+
+// one workgroup: CSR offsets of the batch's pairs, continuing the running total of the call
+__global__ __launch_bounds__(kDetThreads) void det_emit_scan_kernel(DetArgs a, int64_t *running)
+{
+    __shared__ long long part[kDetThreads];
+    const int n = a.n_pairs;
+    const int per = (n + kDetThreads - 1) / kDetThreads;
+    const int lo = min(threadIdx.x * per, n), hi = min(lo + per, n);
+    long long sum = 0;
+    for (int i = lo; i < hi; ++i) sum += a.emit_count[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < kDetThreads; o <<= 1) {
+        const long long t = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    const long long base = *running;
+    long long run = base + part[threadIdx.x] - sum;
+    for (int i = lo; i < hi; ++i) {
+        a.emit_offsets[i] = run;
+        a.out_offsets[a.first_pair + i] = run;
+        run += a.emit_count[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == kDetThreads - 1) {
+        const long long end = base + part[kDetThreads - 1];
+        a.emit_offsets[n] = end;
+        a.out_offsets[a.first_pair + n] = end;
+        *running = end;
+        if (end > a.out_capacity) atomicOr(a.status_word, 8);
+    }
+}
+
+__global__ __launch_bounds__(kDetThreads) void det_emit_scatter_kernel(DetArgs a)
+{
+    __shared__ int wave_cnt[4];
+    const int p = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
+    const int n = ls[a.g.n_layers];
+    long long run = a.emit_offsets[p];
+    for (int i0 = 0; i0 < n; i0 += kDetThreads) {
+        const int i = i0 + threadIdx.x;
+        const int64_t ci = (int64_t)p * a.cand_cap + i;
+        const bool e = i < n && a.cand_emit[ci];
+        const unsigned long long m = __ballot(e);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, all = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) before += wave_cnt[w];
+            all += wave_cnt[w];
+        }
+        if (e) {
+            const long long o = run + before + __popcll(m & ((1ull << lane) - 1));
+            if (o < a.out_capacity) {
+                const DetResult r = a.cand_res[ci];
+                a.out_kps[o] = mofreak_keypoint{r.x, r.y, r.size};
+                if (a.out_response) a.out_response[o] = r.response;
+                if (a.out_layer) a.out_layer[o] = layer_of(ls, a.g.n_layers, i);
+            }
+        }
+        run += all;
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+int launch_det_pyramid(const DetArgs &a, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const DetGeom &g = a.g;
+    hipLaunchKernelGGL(det_diff_kernel, dim3((g.L[0].w + 4 * kDetThreads - 1) / (4 * kDetThreads), g.L[0].h, a.n_pairs), dim3(kDetThreads), 0, s, a);
+    // BriskScaleSpace::constructPyramid (brisk.cpp:572-588): layer 1 = 2/3 of layer 0, layer i >= 2 = half of layer i-2
+    for (int l = 1; l < g.n_layers; ++l) {
+        const dim3 grid((g.L[l].w + kDetThreads - 1) / kDetThreads, g.L[l].h, a.n_pairs);
+        if (grid.x == 0 || grid.y == 0) continue;
+        if (l == 1)
+            hipLaunchKernelGGL(det_twothird_kernel, grid, dim3(kDetThreads), 0, s, a, 0, 1);
+        else
+            hipLaunchKernelGGL(det_half_kernel, grid, dim3(kDetThreads), 0, s, a, l - 2, l);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_det_scores(const DetArgs &a, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int l = 0; l < a.g.n_layers; ++l) {
+        const dim3 grid((a.g.L[l].w + kScoreTileW - 1) / kScoreTileW, (a.g.L[l].h + kScoreTileH - 1) / kScoreTileH, a.n_pairs);
+        if (grid.x == 0 || grid.y == 0) continue;
+        hipLaunchKernelGGL(det_score_kernel, grid, dim3(kDetThreads), 0, s, a, l);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_det_keypoints(const DetArgs &a, int64_t *running, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(det_scan_kernel, dim3(a.n_pairs), dim3(kDetThreads), 0, s, a);
+    hipLaunchKernelGGL(det_candidates_kernel, dim3((a.g.total_rows + 3) / 4, a.n_pairs), dim3(kDetThreads), 0, s, a);
+    hipLaunchKernelGGL(det_refine_kernel, dim3((a.cand_cap + kDetThreads - 1) / kDetThreads, a.n_pairs), dim3(kDetThreads), 0, s, a);
+    hipLaunchKernelGGL(det_tie_kernel, dim3(a.n_pairs), dim3(kDetThreads), 0, s, a);
+    hipLaunchKernelGGL(det_emit_count_kernel, dim3(a.n_pairs), dim3(kDetThreads), 0, s, a);
+    hipLaunchKernelGGL(det_emit_scan_kernel, dim3(1), dim3(kDetThreads), 0, s, a, running);
+    hipLaunchKernelGGL(det_emit_scatter_kernel, dim3(a.n_pairs), dim3(kDetThreads), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mofreak

@@ -145,6 +145,51 @@ struct CompactArgs {
 
 constexpr int kCompactItemsPerBlock = 1024;
 
+// ---- keypoint detector (detect_kernel.hip): BRISK scale space over |cur - prev|
+constexpr int kDetMaxLayers = 8;
+struct DetLayer {
+    int32_t w, h;
+    int64_t off;       // byte offset of the layer inside one pair's plane
+    float scale, offset;
+    int32_t row_base;  // index of the layer's first row in the pair's concatenated row list
+    int32_t pad;
+};
+struct DetGeom {
+    int32_t n_layers, total_rows;
+    int64_t plane_bytes;  // one pair, all layers
+    DetLayer L[kDetMaxLayers];
+};
+// candidate flags
+enum : uint8_t { kDetNotMax = 0, kDetMax = 1, kDetTie = 2 };
+// status-map values (one byte per pixel, written only by the thread that owns that candidate)
+enum : uint8_t { kStNone = 0, kStPending = 1, kStReached = 2, kStDone = 3 };
+struct DetResult {
+    float x, y, size, response;
+};
+struct DetArgs {
+    DetGeom g;
+    FrameArgs f;  // cur / prev of the batch's first pair (prev == nullptr: cur already is the image to search)
+    int32_t n_pairs;
+    int32_t threshold, safe_threshold;
+    uint8_t *img, *score, *touch, *status;  // [n_pairs][plane_bytes]
+    int32_t *row_count;                     // [n_pairs][total_rows + 1]: counts, then exclusive offsets
+    int32_t cand_cap;                       // per pair
+    uint32_t *cand_xy;                      // [n_pairs][cand_cap]  x | y << 16
+    uint8_t *cand_flag;                     // [n_pairs][cand_cap]
+    uint8_t *cand_emit;                     // [n_pairs][cand_cap]
+    DetResult *cand_res;                    // [n_pairs][cand_cap]
+    int32_t *layer_start;                   // [n_pairs][kDetMaxLayers + 1]
+    int32_t *emit_count;                    // [n_pairs]
+    int64_t *emit_offsets;                  // [n_pairs + 1], relative to out_base
+    mofreak_keypoint *out_kps;              // whole-call outputs
+    float *out_response;                    // optional
+    int32_t *out_layer;                     // optional
+    int64_t out_capacity, out_base;
+    int64_t *out_offsets;                   // whole-call CSR offsets; this batch fills [first_pair .. first_pair + n_pairs]
+    int64_t first_pair;
+    int32_t *status_word;                   // bit 2: more candidates than cand_cap; bit 3: more keypoints than out_capacity
+};
+
 // launchers (kernels.hip); all asynchronous on `stream`, return a hipError_t value as int
 int launch_integral(const IntegralArgs &a, void *stream);
 int launch_describe(const DescribeArgs &a, int n_blocks, void *stream);
@@ -159,5 +204,8 @@ int launch_bow_assign(const uint8_t *desc, const uint8_t *valid, int64_t n, cons
                       int32_t *out_index, unsigned int *counts, int n_cus, void *stream);
 int launch_bow_normalize(const unsigned int *counts, int n_codewords, float *hist, int32_t *success, void *stream);
 int launch_unpack_integral(const int32_t *src, int pitch, int W, int H, int n_pairs, int32_t *dst, void *stream);
+int launch_det_pyramid(const DetArgs &a, void *stream);   // difference image + the resampled layers
+int launch_det_scores(const DetArgs &a, void *stream);    // dense corner scores + per-row detection counts
+int launch_det_keypoints(const DetArgs &a, int64_t *running, void *stream);  // candidates, maxima, refinement, ordered emission
 
 }  // namespace mofreak

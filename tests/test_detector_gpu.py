@@ -1,0 +1,150 @@
+"""Parity of the HIP keypoint detector (mofreak_amd/csrc/detect_kernel.hip) with the CPU oracle
+(oracle/brisk_oracle.c): pyramid bytes, dense corner scores, and the keypoint list -- coordinates, size, response,
+layer AND order, all bit-exact -- through the C ABI."""
+import numpy as np
+import pytest
+
+import mofreak_amd as M
+import oracle_lib as O
+from mofreak_amd import synth
+from test_brisk_oracle import C16, _score_maxmin
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(native_lib):
+    c = M.Context(0)
+    yield c
+    c.close()
+
+
+def _oracle_keypoints(img, threshold=30, octaves=3):
+    k = O.brisk_detect(img, threshold, octaves)
+    return (np.stack([k["x"], k["y"], k["size"]], 1).astype(np.float32).reshape(-1, 3), k["response"].copy(), k["layer"].copy())
+
+
+def _assert_same_keypoints(got, want, what=""):
+    gk, gr, gl = got
+    wk, wr, wl = want
+    assert len(gk) == len(wk), f"{what}: {len(gk)} keypoints, oracle {len(wk)}"
+    assert np.array_equal(gl, wl), what
+    assert gk.tobytes() == wk.tobytes(), f"{what}: first difference at {np.nonzero((gk != wk).any(1))[0][:5]}"
+    assert gr.tobytes() == wr.tobytes(), what
+
+
+def _quantised_noise(seed, h, w, levels=4, block=3):
+    """Blocky few-level noise: plenty of equal corner scores next to each other, i.e. isMax2D ties."""
+    rng = np.random.default_rng(seed)
+    small = rng.integers(0, levels, ((h + block - 1) // block, (w + block - 1) // block)) * (255 // (levels - 1))
+    return np.kron(small, np.ones((block, block), np.int64))[:h, :w].astype(np.uint8)
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (212, 160), (100, 70), (53, 47), (640, 360), (1920, 1080)])
+def test_pyramid_and_scores_match_the_oracle(ctx, w, h):
+    img = np.random.default_rng(w + h).integers(0, 256, (h, w), dtype=np.uint8)
+    img[h // 4:h // 2, w // 4:w // 2] = 230
+    got = ctx.brisk_pyramid_host(img, 3)
+    b = O.Brisk(img, 3)
+    assert len(got) == b.n_layers == 6
+    for i, (layer, score, scale, offset) in enumerate(got):
+        lw, lh, ls, lo = b.layer_info(i)
+        assert layer.shape == (lh, lw) and scale == ls and offset == lo
+        assert np.array_equal(layer, b.layer_image(i)), f"layer {i}"
+        if lw >= 7 and lh >= 7:
+            assert np.array_equal(score, _score_maxmin(layer, C16, 9).astype(np.uint8)), f"scores of layer {i}"
+    # spot-check the dense scores against the oracle's bisection (what the reference computes lazily)
+    layer, score = got[0][0], got[0][1]
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        x, y = int(rng.integers(3, w - 3)), int(rng.integers(3, h - 3))
+        assert score[y, x] == O.oast_score(layer, x, y, 0)
+
+
+def test_keypoints_of_moving_objects_match_the_oracle(ctx):
+    fr = synth.moving_objects_stack(9, 320, 240)
+    cur, prev = fr[5:], fr[:4]
+    kps, offs, resp, layer = ctx.detect_pairs_host(cur, prev)
+    assert offs[0] == 0 and offs[-1] == len(kps) and len(kps) > 400
+    for p in range(4):
+        want = _oracle_keypoints(O.absdiff(cur[p], prev[p]))
+        s = slice(offs[p], offs[p + 1])
+        _assert_same_keypoints((kps[s], resp[s], layer[s]), want, f"pair {p}")
+        assert set(np.unique(want[2])) == set(range(6))
+
+
+@pytest.mark.parametrize("octaves", [0, 1, 2, 3, 4])
+def test_every_pyramid_depth(ctx, octaves):
+    fr = synth.moving_objects_stack(6, 400, 300, seed=3)
+    d = O.absdiff(fr[5], fr[0])
+    kps, offs, resp, layer = ctx.detect_pairs_host(d, None, 30, octaves)
+    want = _oracle_keypoints(d, 30, octaves)
+    _assert_same_keypoints((kps, resp, layer), want, f"octaves {octaves}")
+    assert len(kps) > 50
+
+
+@pytest.mark.parametrize("seed,levels,block,thr", [(1, 4, 3, 30), (2, 3, 2, 30), (3, 2, 4, 20), (4, 6, 5, 40), (5, 4, 1, 30)])
+def test_ties_are_broken_like_the_sequential_reference(ctx, seed, levels, block, thr):
+    """Equal neighbouring scores: the outcome depends on which score-cache cells the reference has filled by the time
+    it reaches a candidate.  The oracle replays that order; the device reproduces it from its touch/status maps."""
+    img = _quantised_noise(seed, 180, 240, levels, block)
+    b = O.Brisk(img, 3)
+    want_all = b.get_keypoints(thr)
+    # make sure this input really exercises ties on several layers
+    ties = 0
+    for i in range(b.n_layers):
+        sc = b.layer_scores(i).astype(np.int32)
+        pts = b.layer_points(i)
+        for x, y in pts:
+            nb = sc[y - 1:y + 2, x - 1:x + 2].copy()
+            c = nb[1, 1]
+            nb[1, 1] = -1
+            ties += int((nb.max() == c))
+    assert ties > 20
+    kps, offs, resp, layer = ctx.detect_pairs_host(img, None, thr, 3)
+    _assert_same_keypoints((kps, resp, layer), _oracle_keypoints(img, thr, 3), f"seed {seed}")
+    assert len(want_all) == len(kps)
+
+
+def test_full_hd_pair_and_capacity_errors(ctx):
+    fr = synth.moving_objects_stack(6, 1920, 1080)
+    d = O.absdiff(fr[5], fr[0])
+    kps, offs, resp, layer = ctx.detect_pairs_host(fr[5], fr[0])
+    _assert_same_keypoints((kps, resp, layer), _oracle_keypoints(d), "1080p")
+    assert len(kps) > 3000
+    with pytest.raises(M.MoFREAKError) as e:
+        ctx.detect_pairs_host(fr[5], fr[0], capacity=100)
+    assert e.value.code == M.api.ERR_CAPACITY
+    ctx.set_detect_capacity(256)
+    with pytest.raises(M.MoFREAKError) as e:
+        ctx.detect_pairs_host(fr[5], fr[0])
+    assert e.value.code == M.api.ERR_CAPACITY
+    ctx.set_detect_capacity(131072)
+    again = ctx.detect_pairs_host(fr[5], fr[0])
+    assert again[0].tobytes() == kps.tobytes()
+
+
+def test_detect_then_describe_gives_the_reference_rows(ctx, oracle):
+    """The two halves of computeMoFREAKFromFile's loop body together: detector output feeds the descriptor path through
+    CSR offsets; rows equal the oracle's for the oracle's own keypoints."""
+    fr = synth.moving_objects_stack(11, 352, 288, seed=11)
+    T = len(fr)
+    cur, prev = fr[5:], fr[:T - 5]
+    kps, offs, _, _ = ctx.detect_pairs_host(cur, prev)
+    rows = ctx.extract_stream_host(fr, kps, kp_offsets=offs)
+    lists = [_oracle_keypoints(O.absdiff(cur[p], prev[p]))[0] for p in range(T - 5)]
+    woffs = np.concatenate([[0], np.cumsum([len(k) for k in lists])]).astype(np.int64)
+    assert np.array_equal(offs, woffs)
+    want = oracle.Freak().extract_stream(fr, np.concatenate(lists), woffs)
+    assert rows.tobytes() == want.tobytes() and len(rows) > 300
+    # keypoints near the border are detected but erased by FREAK's border rule: fewer rows than keypoints
+    assert len(rows) < len(kps)
+
+
+def test_empty_and_flat_inputs(ctx):
+    flat = np.full((2, 120, 160), 77, np.uint8)
+    kps, offs, _, _ = ctx.detect_pairs_host(flat, flat)
+    assert len(kps) == 0 and np.array_equal(offs, [0, 0, 0])
+    tiny = np.random.default_rng(0).integers(0, 256, (1, 20, 24), dtype=np.uint8)
+    kps, offs, resp, layer = ctx.detect_pairs_host(tiny, None)
+    _assert_same_keypoints((kps, resp, layer), _oracle_keypoints(tiny[0]), "tiny")
