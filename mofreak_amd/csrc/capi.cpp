@@ -41,7 +41,7 @@ struct mofreak_ctx {
     DeviceBuffer bow_counts;
     // keypoint detector workspace
     DeviceBuffer det_img, det_score, det_touch, det_status, det_rows, det_cand_xy, det_cand_flag, det_cand_emit, det_cand_res, det_layer_start,
-        det_emit_count, det_emit_offsets, det_running, det_out_kps, det_out_offsets, det_out_resp, det_out_layer, det_planes_out;
+        det_emit_count, det_tie_waiting, det_geom, det_emit_offsets, det_running, det_out_kps, det_out_offsets, det_out_resp, det_out_layer, det_planes_out;
     int det_cand_cap = 131072;
     ThetaBound *d_theta = nullptr;
     unsigned long long *d_stamps = nullptr;  // MOFREAK_TILE_STAMPS=1: per-phase tick sums of the diagnostic tile kernel
@@ -568,7 +568,7 @@ void mofreak_destroy(mofreak_ctx *ctx)
     release(ctx->slow_count);
     release(ctx->bow_counts);
     for (DeviceBuffer *b : {&ctx->det_img, &ctx->det_score, &ctx->det_touch, &ctx->det_status, &ctx->det_rows, &ctx->det_cand_xy, &ctx->det_cand_flag,
-                            &ctx->det_cand_emit, &ctx->det_cand_res, &ctx->det_layer_start, &ctx->det_emit_count, &ctx->det_emit_offsets,
+                            &ctx->det_cand_emit, &ctx->det_cand_res, &ctx->det_layer_start, &ctx->det_emit_count, &ctx->det_tie_waiting, &ctx->det_geom, &ctx->det_emit_offsets,
                             &ctx->det_running, &ctx->det_out_kps, &ctx->det_out_offsets, &ctx->det_out_resp, &ctx->det_out_layer, &ctx->det_planes_out})
         release(*b);
     release(ctx->integral);
@@ -1207,8 +1207,11 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     if ((rc = ensure(ctx, ctx->det_layer_start, (size_t)batch * (kDetMaxLayers + 1) * sizeof(int32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_emit_count, (size_t)batch * sizeof(int32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_emit_offsets, (size_t)(batch + 1) * sizeof(int64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->det_tie_waiting, (size_t)batch * kDetMaxLayers * 2 * sizeof(int32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_running, sizeof(int64_t)))) return rc;
     a.g = g;
+    if ((rc = upload(ctx, ctx->det_geom, &a.g, sizeof(DetGeom)))) return rc;  // a.g lives in the caller's frame until it synchronises
+    a.dg = static_cast<const DetGeom *>(ctx->det_geom.ptr);
     a.img = static_cast<uint8_t *>(ctx->det_img.ptr);
     a.score = static_cast<uint8_t *>(ctx->det_score.ptr);
     a.touch = static_cast<uint8_t *>(ctx->det_touch.ptr);
@@ -1222,6 +1225,7 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     a.layer_start = static_cast<int32_t *>(ctx->det_layer_start.ptr);
     a.emit_count = static_cast<int32_t *>(ctx->det_emit_count.ptr);
     a.emit_offsets = static_cast<int64_t *>(ctx->det_emit_offsets.ptr);
+    a.tie_waiting = static_cast<int32_t *>(ctx->det_tie_waiting.ptr);
     a.status_word = ctx->d_status;
     return MOFREAK_OK;
 }
@@ -1311,6 +1315,7 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
         HIP_TRY(ctx, hipMemsetAsync(a.row_count, 0, (size_t)np * (g.total_rows + 1) * sizeof(int32_t), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(a.touch, 0, (size_t)np * g.plane_bytes, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(a.status, 0, (size_t)np * g.plane_bytes, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(a.tie_waiting, 0, (size_t)np * kDetMaxLayers * 2 * sizeof(int32_t), ctx->stream));
         int e = launch_det_pyramid(a, ctx->stream);
         if (!e) e = launch_det_scores(a, ctx->stream);
         if (!e) e = launch_det_keypoints(a, static_cast<int64_t *>(ctx->det_running.ptr), ctx->stream);

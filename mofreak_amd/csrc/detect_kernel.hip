@@ -34,6 +34,7 @@ namespace mofreak {
 namespace {
 
 constexpr int kDetThreads = 256;
+constexpr int kDetTieRounds = 2;  // global rounds of tie decisions per layer before the per-pair loop takes the rest
 
 struct PairView {
     const DetGeom *g;
@@ -46,8 +47,8 @@ struct PairView {
 __device__ __forceinline__ PairView pair_view(const DetArgs &a, int p)
 {
     PairView v;
-    v.g = &a.g;
-    const int64_t o = (int64_t)p * a.g.plane_bytes;
+    v.g = a.dg;
+    const int64_t o = (int64_t)p * a.dg->plane_bytes;
     v.img = a.img + o;
     v.score = a.score + o;
     v.touch = a.touch + o;
@@ -62,11 +63,11 @@ __global__ __launch_bounds__(kDetThreads) void det_diff_kernel(DetArgs a)
 {
     const int p = blockIdx.z, y = blockIdx.y;
     const int x0 = (blockIdx.x * kDetThreads + threadIdx.x) * 4;
-    const int W = a.g.L[0].w;
+    const int W = a.dg->L[0].w;
     if (x0 >= W) return;
     const uint8_t *c = a.f.cur + (int64_t)p * a.f.pair_stride + (int64_t)y * a.f.row_stride + x0;
     const uint8_t *q = a.f.prev ? a.f.prev + (int64_t)p * a.f.pair_stride + (int64_t)y * a.f.row_stride + x0 : nullptr;
-    uint8_t *d = a.img + (int64_t)p * a.g.plane_bytes + a.g.L[0].off + (int64_t)y * W + x0;
+    uint8_t *d = a.img + (int64_t)p * a.dg->plane_bytes + a.dg->L[0].off + (int64_t)y * W + x0;
     const int n = min(4, W - x0);
     for (int k = 0; k < n; ++k) {
         const int u = c[k], v = q ? q[k] : 0;
@@ -77,10 +78,10 @@ __global__ __launch_bounds__(kDetThreads) void det_diff_kernel(DetArgs a)
 // BriskLayer::halfsample (brisk.cpp:1840-1972), one output pixel per thread.
 __global__ __launch_bounds__(kDetThreads) void det_half_kernel(DetArgs a, int src_l, int dst_l)
 {
-    const DetLayer S = a.g.L[src_l], D = a.g.L[dst_l];
+    const DetLayer S = a.dg->L[src_l], D = a.dg->L[dst_l];
     const int c = blockIdx.x * kDetThreads + threadIdx.x, r = blockIdx.y, p = blockIdx.z;
     if (c >= D.w) return;
-    const uint8_t *u = a.img + (int64_t)p * a.g.plane_bytes + S.off + (int64_t)(2 * r) * S.w, *l = u + S.w;
+    const uint8_t *u = a.img + (int64_t)p * a.dg->plane_bytes + S.off + (int64_t)(2 * r) * S.w, *l = u + S.w;
     const int hsize = S.w / 16, end = hsize / 2;
     int out;
     if (c < 16 * end) {  // pairs of 16-byte blocks: rounding average of the two vertical rounding averages
@@ -91,17 +92,17 @@ __global__ __launch_bounds__(kDetThreads) void det_half_kernel(DetArgs a, int sr
         const int k = c - 8 * hsize, b = 16 * hsize;
         out = (u[b + k] + u[b + k + 1] + l[b + k] + l[b + k + 1]) / 4;
     }
-    a.img[(int64_t)p * a.g.plane_bytes + D.off + (int64_t)r * D.w + c] = (uint8_t)out;
+    a.img[(int64_t)p * a.dg->plane_bytes + D.off + (int64_t)r * D.w + c] = (uint8_t)out;
 }
 
 // BriskLayer::twothirdsample (brisk.cpp:1974-2065), one output pixel per thread.
 __global__ __launch_bounds__(kDetThreads) void det_twothird_kernel(DetArgs a, int src_l, int dst_l)
 {
-    const DetLayer S = a.g.L[src_l], D = a.g.L[dst_l];
+    const DetLayer S = a.dg->L[src_l], D = a.dg->L[dst_l];
     const int c = blockIdx.x * kDetThreads + threadIdx.x, r2 = blockIdx.y, p = blockIdx.z;
     if (c >= D.w) return;
     const int r = r2 >> 1;
-    const uint8_t *base = a.img + (int64_t)p * a.g.plane_bytes + S.off;
+    const uint8_t *base = a.img + (int64_t)p * a.dg->plane_bytes + S.off;
     const uint8_t *mid = base + (int64_t)(3 * r + 1) * S.w;
     const uint8_t *outer = (r2 & 1) ? mid + S.w : mid - S.w;  // third row for the lower output row, first for the upper
     const int hsize = S.w / 15;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(kDetThreads) void det_twothird_kernel(DetArgs a, in
         const int X = (k & 1) ? outer[j + 2] : outer[j], B = (k & 1) ? mid[j + 2] : mid[j];
         out = ((4 * X + 2 * (X2 + B) + B2) / 9) & 0xff;
     }
-    a.img[(int64_t)p * a.g.plane_bytes + D.off + (int64_t)r2 * D.w + c] = (uint8_t)out;
+    a.img[(int64_t)p * a.dg->plane_bytes + D.off + (int64_t)r2 * D.w + c] = (uint8_t)out;
 }
 
 // ------------------------------------------------------------------ dense corner scores
@@ -143,9 +144,9 @@ constexpr int kScoreTileW = 64, kScoreTileH = 16, kScoreLdsW = 72;
 __global__ __launch_bounds__(kDetThreads) void det_score_kernel(DetArgs a, int layer)
 {
     __shared__ uint8_t tile[(kScoreTileH + 6) * kScoreLdsW];
-    const DetLayer L = a.g.L[layer];
+    const DetLayer L = a.dg->L[layer];
     const int p = blockIdx.z, x0 = blockIdx.x * kScoreTileW, y0 = blockIdx.y * kScoreTileH;
-    const uint8_t *img = a.img + (int64_t)p * a.g.plane_bytes + L.off;
+    const uint8_t *img = a.img + (int64_t)p * a.dg->plane_bytes + L.off;
     for (int t = threadIdx.x; t < (kScoreTileH + 6) * (kScoreTileW + 6); t += kDetThreads) {
         const int r = t / (kScoreTileW + 6), c = t - r * (kScoreTileW + 6);
         const int gx = x0 - 3 + c, gy = y0 - 3 + r;
@@ -153,8 +154,8 @@ __global__ __launch_bounds__(kDetThreads) void det_score_kernel(DetArgs a, int l
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint8_t *score = a.score + (int64_t)p * a.g.plane_bytes + L.off;
-    int32_t *row_count = a.row_count + (int64_t)p * (a.g.total_rows + 1) + L.row_base;
+    uint8_t *score = a.score + (int64_t)p * a.dg->plane_bytes + L.off;
+    int32_t *row_count = a.row_count + (int64_t)p * (a.dg->total_rows + 1) + L.row_base;
 #pragma unroll
     for (int it = 0; it < kScoreTileH / 4; ++it) {
         const int ry = wave + 4 * it, x = x0 + lane, y = y0 + ry;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(kDetThreads) void det_score_kernel(DetArgs a, int l
 __global__ __launch_bounds__(kDetThreads) void det_scan_kernel(DetArgs a)
 {
     __shared__ int part[kDetThreads];
-    const int p = blockIdx.x, n = a.g.total_rows;
+    const int p = blockIdx.x, n = a.dg->total_rows;
     int32_t *rc = a.row_count + (int64_t)p * (n + 1);
     const int per = (n + kDetThreads - 1) / kDetThreads;
     const int lo = min(threadIdx.x * per, n), hi = min(lo + per, n);
@@ -223,9 +224,9 @@ __global__ __launch_bounds__(kDetThreads) void det_scan_kernel(DetArgs a)
         if (total > a.cand_cap) atomicOr(a.status_word, 4);
     }
     __syncthreads();
-    if (threadIdx.x <= a.g.n_layers) {
+    if (threadIdx.x <= a.dg->n_layers) {
         const int l = threadIdx.x;
-        const int v = l < a.g.n_layers ? rc[a.g.L[l].row_base] : rc[n];
+        const int v = l < a.dg->n_layers ? rc[a.dg->L[l].row_base] : rc[n];
         a.layer_start[(int64_t)p * (kDetMaxLayers + 1) + l] = min(v, a.cand_cap);
     }
 }
@@ -234,16 +235,16 @@ __global__ __launch_bounds__(kDetThreads) void det_scan_kernel(DetArgs a)
 __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
 {
     const int p = blockIdx.y, row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= a.g.total_rows) return;
+    if (row >= a.dg->total_rows) return;
     int layer = 0;
-    while (layer + 1 < a.g.n_layers && row >= a.g.L[layer + 1].row_base) ++layer;
-    const DetLayer L = a.g.L[layer];
+    while (layer + 1 < a.dg->n_layers && row >= a.dg->L[layer + 1].row_base) ++layer;
+    const DetLayer L = a.dg->L[layer];
     const int y = row - L.row_base;
     if (y < 3 || y >= L.h - 3) return;
-    const int32_t *rc = a.row_count + (int64_t)p * (a.g.total_rows + 1);
+    const int32_t *rc = a.row_count + (int64_t)p * (a.dg->total_rows + 1);
     int base = rc[row];
     if (rc[row + 1] == base) return;
-    const int64_t plane = (int64_t)p * a.g.plane_bytes + L.off;
+    const int64_t plane = (int64_t)p * a.dg->plane_bytes + L.off;
     const uint8_t *sc = a.score + plane;
     const int64_t cbase = (int64_t)p * a.cand_cap;
     for (int x0 = 0; x0 < L.w; x0 += 64) {
@@ -283,32 +284,53 @@ template <bool MARK>
 __device__ __forceinline__ int score_at(const PairView &v, int layer, int x, int y)
 {
     const DetLayer &L = v.g->L[layer];
-    if (x < 3 || y < 3 || x >= L.w - 3 || y >= L.h - 3) return 0;
-    const int64_t o = L.off + (int64_t)y * L.w + x;
-    if (MARK) v.touch[o] = 1;
-    return v.score[o];
+    const bool in = x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3;
+    const int64_t o = L.off + (in ? (int64_t)y * L.w + x : 0);  // unconditional load: independent loads overlap
+    const int s = v.score[o];
+    if (MARK && in) v.touch[o] = 1;
+    return in ? s : 0;
 }
 
-// getAgastScore(float, float, 1, scale = 1) (:1705-1720): bilinear, returned through uint8_t
-template <bool MARK>
-__device__ __forceinline__ int score_f(const PairView &v, int layer, float xf, float yf)
+// The part of a neighbouring layer's score map one refinement walk can reach -- at most 5 x 5 cells from the corner
+// ((int)x_1, (int)y_1) of getScoreMaxAbove/Below's sampling square, patch and tie rings included -- fetched with 36
+// independent loads into the thread's own 36 bytes of LDS.  The walk itself is a chain of data-dependent early
+// exits: on global memory every step would pay a full memory latency.
+constexpr int kWinSide = 6, kWinStride = 36;  // bytes per thread (9 dwords: neighbouring threads hit different banks)
+struct Window {
+    uint8_t *cells;
+    int ox, oy, layer;
+};
+
+__device__ __forceinline__ void window_load(const PairView &v, Window &w)
 {
-    const int x = (int)xf;
-    const float rx1 = xf - (float)x;
-    const float rx = 1.0f - rx1;
-    const int y = (int)yf;
-    const float ry1 = yf - (float)y;
-    const float ry = 1.0f - ry1;
-    const float s00 = (float)score_at<MARK>(v, layer, x, y);
-    const float s10 = (float)score_at<MARK>(v, layer, x + 1, y);
-    const float s01 = (float)score_at<MARK>(v, layer, x, y + 1);
-    const float s11 = (float)score_at<MARK>(v, layer, x + 1, y + 1);
-    const float r = rx * ry * s00 + rx1 * ry * s10 + rx * ry1 * s01 + rx1 * ry1 * s11;
-    return (int)r & 0xff;
+    const DetLayer &L = v.g->L[w.layer];
+    uint8_t tmp[kWinSide * kWinSide];
+#pragma unroll
+    for (int k = 0; k < kWinSide * kWinSide; ++k) {
+        const int x = w.ox + k % kWinSide, y = w.oy + k / kWinSide;
+        const bool in = x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3;
+        const uint8_t s = v.score[L.off + (in ? (int64_t)y * L.w + x : 0)];
+        tmp[k] = in ? s : (uint8_t)0;
+    }
+#pragma unroll
+    for (int k = 0; k < kWinSide * kWinSide; k += 4)
+        *reinterpret_cast<uint32_t *>(w.cells + k) = (uint32_t)tmp[k] | (uint32_t)tmp[k + 1] << 8 | (uint32_t)tmp[k + 2] << 16 | (uint32_t)tmp[k + 3] << 24;
+}
+
+template <bool MARK>
+__device__ __forceinline__ int window_at(const PairView &v, const Window &w, int x, int y)
+{
+    const int ix = x - w.ox, iy = y - w.oy;
+    if ((unsigned)ix >= (unsigned)kWinSide || (unsigned)iy >= (unsigned)kWinSide) return score_at<MARK>(v, w.layer, x, y);  // not expected
+    if (MARK) {
+        const DetLayer &L = v.g->L[w.layer];
+        if (x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3) v.touch[L.off + (int64_t)y * L.w + x] = 1;
+    }
+    return w.cells[iy * kWinSide + ix];
 }
 
 // AgastDetector5_8::cornerScore from b = 0 (agast5_8_nms.cc:42; brisk.cpp:1696-1703): 5 contiguous of the 8 neighbours
-__device__ int score_5_8(const PairView &v, int x, int y)
+__device__ __forceinline__ int score_5_8(const PairView &v, int x, int y)
 {
     const DetLayer &L = v.g->L[0];
     if (x < 2 || y < 2 || x >= L.w - 2 || y >= L.h - 2) return 0;
@@ -339,7 +361,7 @@ __device__ int score_5_8(const PairView &v, int x, int y)
 }
 
 // BriskScaleSpace::subpixel2D (brisk.cpp:1535-1644); s = s_0_0, s_0_1, s_0_2, s_1_0, ... (first index x)
-__device__ float subpixel2d(const int (&s)[9], float &delta_x, float &delta_y)
+__device__ __forceinline__ float subpixel2d(const int (&s)[9], float &delta_x, float &delta_y)
 {
     const int s_0_0 = s[0], s_0_1 = s[1], s_0_2 = s[2], s_1_0 = s[3], s_1_1 = s[4], s_1_2 = s[5], s_2_0 = s[6], s_2_1 = s[7],
               s_2_2 = s[8];
@@ -430,7 +452,7 @@ __device__ float subpixel2d(const int (&s)[9], float &delta_x, float &delta_y)
 }
 
 // refine1D (variant 0, :1418), refine1D_1 (1, :1459), refine1D_2 (2, :1499)
-__device__ float refine1d(int variant, float s_05, float s0, float s05, float &max)
+__device__ __forceinline__ float refine1d(int variant, float s_05, float s0, float s05, float &max)
 {
     const int i_05 = (int)(1024.0 * (double)s_05 + 0.5);
     const int i0 = (int)(1024.0 * (double)s0 + 0.5);
@@ -485,7 +507,7 @@ __device__ float refine1d(int variant, float s_05, float s0, float s05, float &m
 }
 
 template <bool MARK>
-__device__ float patch_subpixel(const PairView &v, int layer, int x, int y, float &dx, float &dy)
+__device__ __forceinline__ float patch_subpixel(const PairView &v, int layer, int x, int y, float &dx, float &dy)
 {
     int s[9];
     s[0] = score_at<MARK>(v, layer, x - 1, y - 1);
@@ -502,7 +524,8 @@ __device__ float patch_subpixel(const PairView &v, int layer, int x, int y, floa
 
 // getScoreMaxAbove (ABOVE, brisk.cpp:1106-1249) / getScoreMaxBelow (:1251-1416)
 template <bool ABOVE>
-__device__ float neighbour_layer_max(const PairView &v, int layer, int x_layer, int y_layer, int threshold, bool &ismax, float &dx, float &dy)
+__device__ __forceinline__ float neighbour_layer_max(const PairView &v, uint8_t *lds_cells, int layer, int x_layer, int y_layer, int threshold, bool &ismax, float &dx,
+                                     float &dy)
 {
     ismax = false;
     const int nl = ABOVE ? layer + 1 : layer - 1;
@@ -535,21 +558,36 @@ __device__ float neighbour_layer_max(const PairView &v, int layer, int x_layer, 
     }
     const float thr = (float)threshold;
     const int xa = (int)(x_1 + 1), xb = (int)x1, ya = (int)(y_1 + 1), yb = (int)y1;
+    Window win{lds_cells, (int)x_1, (int)y_1, nl};
+    window_load(v, win);
+    auto S = [&](int x, int y) { return window_at<ABOVE>(v, win, x, y); };  // getAgastScore(int, int, 1)
+    auto Q = [&](int x, int y) { return window_at<false>(v, win, x, y); };  // same, for the layer below (no bookkeeping)
+    auto F = [&](float xf, float yf) {                                      // getAgastScore(float, float, 1): bilinear through uint8_t
+        const int x = (int)xf;
+        const float rx1 = xf - (float)x;
+        const float rx = 1.0f - rx1;
+        const int y = (int)yf;
+        const float ry1 = yf - (float)y;
+        const float ry = 1.0f - ry1;
+        const float s00 = (float)S(x, y), s10 = (float)S(x + 1, y), s01 = (float)S(x, y + 1), s11 = (float)S(x + 1, y + 1);
+        const float r = rx * ry * s00 + rx1 * ry * s10 + rx * ry1 * s01 + rx1 * ry1 * s11;
+        return (int)r & 0xff;
+    };
 
     // first row
     int max_x = xa, max_y = ya;
     float tmp_max;
-    float max = (float)score_f<ABOVE>(v, nl, x_1, y_1);
+    float max = (float)F(x_1, y_1);
     if (max > thr) return 0;
     for (int x = xa; x <= xb; x++) {
-        tmp_max = (float)score_f<ABOVE>(v, nl, (float)x, y_1);
+        tmp_max = (float)F((float)x, y_1);
         if (tmp_max > thr) return 0;
         if (tmp_max > max) {
             max = tmp_max;
             max_x = x;
         }
     }
-    tmp_max = (float)score_f<ABOVE>(v, nl, x1, y_1);
+    tmp_max = (float)F(x1, y_1);
     if (tmp_max > thr) return 0;
     if (tmp_max > max) {
         max = tmp_max;
@@ -557,7 +595,7 @@ __device__ float neighbour_layer_max(const PairView &v, int layer, int x_layer, 
     }
     // middle rows
     for (int y = ya; y <= yb; y++) {
-        tmp_max = (float)score_f<ABOVE>(v, nl, x_1, (float)y);
+        tmp_max = (float)F(x_1, (float)y);
         if (tmp_max > thr) return 0;
         if (tmp_max > max) {
             max = tmp_max;
@@ -565,17 +603,17 @@ __device__ float neighbour_layer_max(const PairView &v, int layer, int x_layer, 
             max_y = y;
         }
         for (int x = xa; x <= xb; x++) {
-            tmp_max = (float)score_at<ABOVE>(v, nl, x, y);
+            tmp_max = (float)S(x, y);
             if (tmp_max > thr) return 0;
             if (!ABOVE && tmp_max == max) {  // :1321-1344 (below only)
-                const int t1 = 2 * (score_at<false>(v, nl, x - 1, y) + score_at<false>(v, nl, x + 1, y) + score_at<false>(v, nl, x, y + 1) +
-                                    score_at<false>(v, nl, x, y - 1)) +
-                               (score_at<false>(v, nl, x + 1, y + 1) + score_at<false>(v, nl, x - 1, y + 1) +
-                                score_at<false>(v, nl, x + 1, y - 1) + score_at<false>(v, nl, x - 1, y - 1));
-                const int t2 = 2 * (score_at<false>(v, nl, max_x - 1, max_y) + score_at<false>(v, nl, max_x + 1, max_y) +
-                                    score_at<false>(v, nl, max_x, max_y + 1) + score_at<false>(v, nl, max_x, max_y - 1)) +
-                               (score_at<false>(v, nl, max_x + 1, max_y + 1) + score_at<false>(v, nl, max_x - 1, max_y + 1) +
-                                score_at<false>(v, nl, max_x + 1, max_y - 1) + score_at<false>(v, nl, max_x - 1, max_y - 1));
+                const int t1 = 2 * (Q(x - 1, y) + Q(x + 1, y) + Q(x, y + 1) +
+                                    Q(x, y - 1)) +
+                               (Q(x + 1, y + 1) + Q(x - 1, y + 1) +
+                                Q(x + 1, y - 1) + Q(x - 1, y - 1));
+                const int t2 = 2 * (Q(max_x - 1, max_y) + Q(max_x + 1, max_y) +
+                                    Q(max_x, max_y + 1) + Q(max_x, max_y - 1)) +
+                               (Q(max_x + 1, max_y + 1) + Q(max_x - 1, max_y + 1) +
+                                Q(max_x + 1, max_y - 1) + Q(max_x - 1, max_y - 1));
                 if (t1 > t2) {
                     max_x = x;
                     max_y = y;
@@ -587,7 +625,7 @@ __device__ float neighbour_layer_max(const PairView &v, int layer, int x_layer, 
                 max_y = y;
             }
         }
-        tmp_max = (float)score_f<ABOVE>(v, nl, x1, (float)y);
+        tmp_max = (float)F(x1, (float)y);
         if (tmp_max > thr) return 0;
         if (tmp_max > max) {
             max = tmp_max;
@@ -596,21 +634,21 @@ __device__ float neighbour_layer_max(const PairView &v, int layer, int x_layer, 
         }
     }
     // bottom row: no early exit
-    tmp_max = (float)score_f<ABOVE>(v, nl, x_1, y1);
+    tmp_max = (float)F(x_1, y1);
     if (tmp_max > max) {
         max = tmp_max;
         max_x = xa;
         max_y = yb;
     }
     for (int x = xa; x <= xb; x++) {
-        tmp_max = (float)score_f<ABOVE>(v, nl, (float)x, y1);
+        tmp_max = (float)F((float)x, y1);
         if (tmp_max > max) {
             max = tmp_max;
             max_x = x;
             max_y = yb;
         }
     }
-    tmp_max = (float)score_f<ABOVE>(v, nl, x1, y1);
+    tmp_max = (float)F(x1, y1);
     if (tmp_max > max) {
         max = tmp_max;
         max_x = xb;
@@ -618,7 +656,10 @@ __device__ float neighbour_layer_max(const PairView &v, int layer, int x_layer, 
     }
 
     float dx_1, dy_1;
-    const float refined_max = patch_subpixel<ABOVE>(v, nl, max_x, max_y, dx_1, dy_1);
+    int patch[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) patch[k] = S(max_x + k / 3 - 1, max_y + k % 3 - 1);  // s_0_0, s_0_1, s_0_2, s_1_0, ... (first index x)
+    const float refined_max = subpixel2d(patch, dx_1, dy_1);
     const float real_x = (float)max_x + dx_1;
     const float real_y = (float)max_y + dy_1;
     bool returnrefined = true;
@@ -654,8 +695,10 @@ struct Refined {
 };
 
 // What getKeypoints does with one 2-D maximum (brisk.cpp:609-702), refine3D included (:937-1103).
-__device__ Refined refine_maximum(const PairView &v, int layer, int px, int py, int threshold)
+__device__ __forceinline__ Refined refine_maximum(const PairView &v, uint8_t *lds_cells, int layer, int px, int py, int threshold)
 {
+    // One walk above, one below, one own patch -- in the reference's order (above, below, patch), each at a single
+    // call site so that everything inlines and no argument goes through the stack.
     const float basicSize = 12.0f;
     const DetGeom &g = *v.g;
     const DetLayer &L = g.L[layer];
@@ -663,98 +706,66 @@ __device__ Refined refine_maximum(const PairView &v, int layer, int px, int py, 
     out.emit = false;
     out.reached = false;
     out.r = DetResult{0.f, 0.f, 0.f, 0.f};
-    float delta_x_layer, delta_y_layer;
-    if (g.n_layers == 1) {  // :609-638
-        const float peak = patch_subpixel<false>(v, 0, px, py, delta_x_layer, delta_y_layer);
-        out.reached = true;
-        out.emit = true;
-        out.r = DetResult{(float)px + delta_x_layer, (float)py + delta_y_layer, basicSize, peak};
-        return out;
-    }
+    const bool single = g.n_layers == 1, last = layer == g.n_layers - 1, octave = (layer & 1) == 0;
     const int center = score_at<false>(v, layer, px, py);
-    bool ismax;
-    if (layer == g.n_layers - 1) {  // :644-679
-        float dx, dy;
-        (void)neighbour_layer_max<false>(v, layer, px, py, center, ismax, dx, dy);
+    bool ismax = true;
+    float max_above = 0.f, max_below = 0.f;
+    float delta_x_above = 0.f, delta_y_above = 0.f, delta_x_below = 0.f, delta_y_below = 0.f, delta_x_layer, delta_y_layer;
+    if (!last) {  // refine3D: getScoreMaxAbove first (:945-950)
+        max_above = neighbour_layer_max<true>(v, lds_cells, layer, px, py, center, ismax, delta_x_above, delta_y_above);
         if (!ismax) return out;
-        const float peak = patch_subpixel<false>(v, layer, px, py, delta_x_layer, delta_y_layer);
-        out.reached = true;
+    }
+    if (layer > 0) {  // getScoreMaxBelow: the last layer (:651-657), octaves above 0 (:991-996), intra layers (:1049-1053)
+        max_below = neighbour_layer_max<false>(v, lds_cells, layer, px, py, center, ismax, delta_x_below, delta_y_below);
+        if (!ismax) return out;
+    } else if (!single) {  // layer 0: guess the missing layer below with the 5/8 mask (:959-989)
+        int s[9];
+        int mb = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            s[k] = score_5_8(v, px + k / 3 - 1, py + k % 3 - 1);
+            mb = max(mb, s[k]);
+        }
+        (void)subpixel2d(s, delta_x_below, delta_y_below);
+        max_below = (float)mb;
+    }
+    const float max_layer = patch_subpixel<false>(v, layer, px, py, delta_x_layer, delta_y_layer);
+    out.reached = true;
+    if (single) {  // :609-638
         out.emit = true;
-        out.r = DetResult{((float)px + delta_x_layer) * L.scale + L.offset, ((float)py + delta_y_layer) * L.scale + L.offset, basicSize * L.scale, peak};
+        out.r = DetResult{(float)px + delta_x_layer, (float)py + delta_y_layer, basicSize, max_layer};
         return out;
     }
-    // refine3D
-    float delta_x_above, delta_y_above, delta_x_below, delta_y_below;
-    const float max_above = neighbour_layer_max<true>(v, layer, px, py, center, ismax, delta_x_above, delta_y_above);
-    if (!ismax) return out;
-    float best, scale, x, y;
-    if ((layer & 1) == 0) {  // octave
-        float max_below_float;
-        if (layer == 0) {  // guess the missing layer below with the 5/8 mask (:959-989)
-            int s[9];
-            int mb;
-            s[0] = score_5_8(v, px - 1, py - 1);
-            mb = s[0];
-            s[3] = score_5_8(v, px, py - 1);
-            mb = max(mb, s[3]);
-            s[6] = score_5_8(v, px + 1, py - 1);
-            mb = max(mb, s[6]);
-            s[7] = score_5_8(v, px + 1, py);
-            mb = max(mb, s[7]);
-            s[4] = score_5_8(v, px, py);
-            mb = max(mb, s[4]);
-            s[1] = score_5_8(v, px - 1, py);
-            mb = max(mb, s[1]);
-            s[2] = score_5_8(v, px - 1, py + 1);
-            mb = max(mb, s[2]);
-            s[5] = score_5_8(v, px, py + 1);
-            mb = max(mb, s[5]);
-            s[8] = score_5_8(v, px + 1, py + 1);
-            mb = max(mb, s[8]);
-            (void)subpixel2d(s, delta_x_below, delta_y_below);
-            max_below_float = (float)mb;
-        } else {
-            max_below_float = neighbour_layer_max<false>(v, layer, px, py, center, ismax, delta_x_below, delta_y_below);
-            if (!ismax) return out;
-        }
-        const float max_layer = patch_subpixel<false>(v, layer, px, py, delta_x_layer, delta_y_layer);
-        out.reached = true;
-        const float s0 = ((float)center < max_layer) ? max_layer : (float)center;
-        scale = refine1d(layer == 0 ? 2 : 0, max_below_float, s0, max_above, best);
-        if ((double)scale > 1.0) {
-            const float r0 = (float)((1.5 - (double)scale) / .5);
-            const float r1 = (float)(1.0 - (double)r0);
-            x = (r0 * delta_x_layer + r1 * delta_x_above + (float)px) * L.scale + L.offset;
-            y = (r0 * delta_y_layer + r1 * delta_y_above + (float)py) * L.scale + L.offset;
-        } else if (layer == 0) {
-            const float r0 = (float)(((double)scale - 0.5) / 0.5);
-            const float r_1 = (float)(1.0 - (double)r0);
-            x = r0 * delta_x_layer + r_1 * delta_x_below + (float)px;
-            y = r0 * delta_y_layer + r_1 * delta_y_below + (float)py;
-        } else {
-            const float r0 = (float)(((double)scale - 0.75) / 0.25);
-            const float r_1 = (float)(1.0 - (double)r0);
-            x = (r0 * delta_x_layer + r_1 * delta_x_below + (float)px) * L.scale + L.offset;
-            y = (r0 * delta_y_layer + r_1 * delta_y_below + (float)py) * L.scale + L.offset;
-        }
-    } else {  // intra
-        const float max_below = neighbour_layer_max<false>(v, layer, px, py, center, ismax, delta_x_below, delta_y_below);
-        if (!ismax) return out;
-        const float max_layer = patch_subpixel<false>(v, layer, px, py, delta_x_layer, delta_y_layer);
-        out.reached = true;
-        const float s0 = ((float)center < max_layer) ? max_layer : (float)center;
-        scale = refine1d(1, max_below, s0, max_above, best);
-        if ((double)scale > 1.0) {
-            const float r0 = (float)(4.0 - (double)scale * 3.0);
-            const float r1 = (float)(1.0 - (double)r0);
-            x = (r0 * delta_x_layer + r1 * delta_x_above + (float)px) * L.scale + L.offset;
-            y = (r0 * delta_y_layer + r1 * delta_y_above + (float)py) * L.scale + L.offset;
-        } else {
-            const float r0 = (float)((double)scale * 3.0 - 2.0);
-            const float r_1 = (float)(1.0 - (double)r0);
-            x = (r0 * delta_x_layer + r_1 * delta_x_below + (float)px) * L.scale + L.offset;
-            y = (r0 * delta_y_layer + r_1 * delta_y_below + (float)py) * L.scale + L.offset;
-        }
+    if (last) {  // :659-678
+        out.emit = true;
+        out.r = DetResult{((float)px + delta_x_layer) * L.scale + L.offset, ((float)py + delta_y_layer) * L.scale + L.offset, basicSize * L.scale,
+                          max_layer};
+        return out;
+    }
+    const float s0 = ((float)center < max_layer) ? max_layer : (float)center;  // std::max(float(center), max_layer)
+    float best;
+    float scale = refine1d(octave ? (layer == 0 ? 2 : 0) : 1, max_below, s0, max_above, best);
+    float r0, r1;
+    bool up;
+    if (octave) {
+        up = (double)scale > 1.0;
+        if (up)
+            r0 = (float)((1.5 - (double)scale) / .5);  // :1019
+        else if (layer == 0)
+            r0 = (float)(((double)scale - 0.5) / 0.5);  // :1029
+        else
+            r0 = (float)(((double)scale - 0.75) / 0.25);  // :1036
+    } else {
+        up = (double)scale > 1.0;
+        r0 = up ? (float)(4.0 - (double)scale * 3.0) : (float)((double)scale * 3.0 - 2.0);  // :1076, :1085
+    }
+    r1 = (float)(1.0 - (double)r0);
+    const float ox = up ? delta_x_above : delta_x_below, oy = up ? delta_y_above : delta_y_below;
+    float x = r0 * delta_x_layer + r1 * ox + (float)px;
+    float y = r0 * delta_y_layer + r1 * oy + (float)py;
+    if (up || layer != 0) {  // layer 0 interpolating towards the guessed layer below stays in image coordinates (:1031-1032)
+        x = x * L.scale + L.offset;
+        y = y * L.scale + L.offset;
     }
     scale *= L.scale;
     if (best > (float)threshold) {  // :698
@@ -771,125 +782,193 @@ __device__ __forceinline__ int layer_of(const int32_t *layer_start, int n_layers
     return l;
 }
 
-__device__ void finish_candidate(const DetArgs &a, const PairView &v, int p, int i, int layer, int x, int y)
+__device__ __forceinline__ void finish_candidate(const DetArgs &a, const PairView &v, uint8_t *lds_cells, int p, int i, int layer, int x, int y)
 {
-    const Refined r = refine_maximum(v, layer, x, y, a.threshold);
+    const Refined r = refine_maximum(v, lds_cells, layer, x, y, a.threshold);
     const int64_t ci = (int64_t)p * a.cand_cap + i;
     a.cand_emit[ci] = r.emit ? 1 : 0;
     a.cand_res[ci] = r.r;
-    const DetLayer &L = a.g.L[layer];
+    const DetLayer &L = a.dg->L[layer];
     v.status[L.off + (int64_t)y * L.w + x] = r.reached ? kStReached : kStDone;
 }
 
 // maxima without ties: independent of everything else
 __global__ __launch_bounds__(kDetThreads) void det_refine_kernel(DetArgs a)
 {
+    __shared__ __attribute__((aligned(4))) uint8_t windows[kDetThreads * kWinStride];
     const int p = blockIdx.y, i = blockIdx.x * kDetThreads + threadIdx.x;
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
-    if (i >= ls[a.g.n_layers]) return;
+    if (i >= ls[a.dg->n_layers]) return;
     const int64_t ci = (int64_t)p * a.cand_cap + i;
     if (a.cand_flag[ci] != kDetMax) return;
     const uint32_t xy = a.cand_xy[ci];
     const PairView v = pair_view(a, p);
-    finish_candidate(a, v, p, i, layer_of(ls, a.g.n_layers, i), (int)(xy & 0xffff), (int)(xy >> 16));
+    finish_candidate(a, v, windows + threadIdx.x * kWinStride, p, i, layer_of(ls, a.dg->n_layers, i), (int)(xy & 0xffff), (int)(xy >> 16));
 }
 
 // ---- ties
 constexpr uint8_t kDetTieReady = 3;
 
-// The reference's score cache cell at q = (qx, qy) as candidate (px, py) would find it (see the header comment).
-__device__ int raw_score(const PairView &v, const DetLayer &L, int safe_threshold, int qx, int qy, int px, int py)
+// The smoothing part of isMax2D (brisk.cpp:874-933) on the reference's score cache as candidate (px, py) would find
+// it (see the header comment): a cell holds its score if it is a detected corner, if the layer below asked for it,
+// or if it lies in the 3x3 patch of a maximum that was processed earlier (raster order) and got as far as its patch;
+// otherwise it still holds zero.  All loads are issued up front (they are independent); the logic runs on registers.
+__device__ __forceinline__ bool tie_is_max(const PairView &v, const DetLayer &L, int safe_threshold, int px, int py)
 {
-    if (qx < 3 || qy < 3 || qx >= L.w - 3 || qy >= L.h - 3) return 0;
-    const int64_t o = L.off + (int64_t)qy * L.w + qx;
-    const int s = v.score[o];
-    if (s == 0 || s >= safe_threshold || v.touch[o]) return s;
-    for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int mx = qx + dx, my = qy + dy;
-            if (my > py || (my == py && mx >= px)) continue;  // only maxima processed before this candidate
-            if (mx < 0 || my < 0 || mx >= L.w || my >= L.h) continue;
-            if (v.status[L.off + (int64_t)my * L.w + mx] == kStReached) return s;
+    uint8_t st[7][7];
+    int sc[5][5];
+    uint8_t tc[5][5];
+#pragma unroll
+    for (int dy = -3; dy <= 3; ++dy)
+#pragma unroll
+        for (int dx = -3; dx <= 3; ++dx) {
+            const int mx = px + dx, my = py + dy;
+            const bool in = mx >= 0 && my >= 0 && mx < L.w && my < L.h;
+            const uint8_t s = v.status[L.off + (int64_t)(in ? my : py) * L.w + (in ? mx : px)];
+            st[dy + 3][dx + 3] = (in && (dy < 0 || (dy == 0 && dx < 0))) ? s : (uint8_t)kStNone;  // only maxima processed before
         }
-    return 0;
-}
-
-// the smoothing part of isMax2D (brisk.cpp:874-933) on the emulated cache
-__device__ bool tie_is_max(const PairView &v, const DetLayer &L, int safe_threshold, int px, int py)
-{
-    int r[5][5];
+#pragma unroll
     for (int dy = -2; dy <= 2; ++dy)
-        for (int dx = -2; dx <= 2; ++dx) r[dy + 2][dx + 2] = raw_score(v, L, safe_threshold, px + dx, py + dy, px, py);
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int qx = px + dx, qy = py + dy;
+            const bool in = qx >= 3 && qy >= 3 && qx < L.w - 3 && qy < L.h - 3;
+            const int64_t o = L.off + (int64_t)(in ? qy : py) * L.w + (in ? qx : px);
+            sc[dy + 2][dx + 2] = in ? (int)v.score[o] : 0;
+            tc[dy + 2][dx + 2] = in ? v.touch[o] : (uint8_t)0;
+        }
+    int r[5][5];
+#pragma unroll
+    for (int y = 0; y < 5; ++y)
+#pragma unroll
+        for (int x = 0; x < 5; ++x) {
+            const int s = sc[y][x];
+            bool filled = s >= safe_threshold || tc[y][x] != 0;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) filled |= st[y + dy][x + dx] == kStReached;  // window (y+dy, x+dx) = cell + (dx-1, dy-1)
+            r[y][x] = filled ? s : 0;
+        }
     const int center = r[2][2];
     auto smooth = [&](int cx, int cy) {  // 1 2 1 / 2 4 2 / 1 2 1 around (cx, cy) in window coordinates
         return r[cy - 1][cx - 1] + 2 * r[cy - 1][cx] + r[cy - 1][cx + 1] + 2 * r[cy][cx - 1] + 4 * r[cy][cx] + 2 * r[cy][cx + 1] + r[cy + 1][cx - 1] +
                2 * r[cy + 1][cx] + r[cy + 1][cx + 1];
     };
     const int smoothedcenter = smooth(2, 2);
+    bool is_max = true;
+#pragma unroll
     for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
             if (dx == 0 && dy == 0) continue;
-            if (r[2 + dy][2 + dx] != center) continue;
-            if (smooth(2 + dx, 2 + dy) > smoothedcenter) return false;
+            if (r[2 + dy][2 + dx] == center && smooth(2 + dx, 2 + dy) > smoothedcenter) is_max = false;
+        }
+    return is_max;
+}
+
+// A tie is ready when no undecided tie that precedes it in raster order could still change a cell it reads: such a
+// tie matters only through cells of its 3x3 patch that lie in this candidate's 5x5 window AND whose cached value
+// is not settled already (settled: score 0, a detected corner, or asked for from the layer below).
+__device__ __forceinline__ bool tie_ready(const PairView &v, const DetLayer &L, int safe_threshold, int px, int py)
+{
+    for (int dy = -3; dy <= 0; ++dy)
+        for (int dx = -3; dx <= 3; ++dx) {
+            if (dy == 0 && dx >= 0) break;
+            const int mx = px + dx, my = py + dy;
+            if (mx < 0 || my < 0 || mx >= L.w) continue;
+            if (v.status[L.off + (int64_t)my * L.w + mx] != kStPending) continue;
+            for (int qy = max(my - 1, py - 2); qy <= min(my + 1, py + 2); ++qy)
+                for (int qx = max(mx - 1, px - 2); qx <= min(mx + 1, px + 2); ++qx) {
+                    if (qx < 3 || qy < 3 || qx >= L.w - 3 || qy >= L.h - 3) continue;
+                    const int64_t o = L.off + (int64_t)qy * L.w + qx;
+                    const int sc = v.score[o];
+                    if (sc != 0 && sc < safe_threshold && !v.touch[o]) return false;
+                }
         }
     return true;
 }
 
-// one workgroup per pair: layer by layer, rounds of mutually independent ties
-__global__ __launch_bounds__(kDetThreads) void det_tie_kernel(DetArgs a)
+__device__ __forceinline__ void tie_decide(const DetArgs &a, const PairView &v, uint8_t *lds_cells, const DetLayer &L, int p, int i, int layer, int px, int py)
+{
+    const int64_t ci = (int64_t)p * a.cand_cap + i;
+    if (tie_is_max(v, L, a.safe_threshold, px, py)) {
+        a.cand_flag[ci] = kDetMax;
+        finish_candidate(a, v, lds_cells, p, i, layer, px, py);
+    } else {
+        a.cand_flag[ci] = kDetNotMax;
+        v.status[L.off + (int64_t)py * L.w + px] = kStDone;
+    }
+}
+
+// Ties of one layer, all pairs at once, in rounds of mutually independent ones: `ready` marks them (and counts the
+// ones that have to wait), `decide` settles the marked ones.  Two launches, because a tie must not see a neighbour
+// half-way through its decision.
+__global__ __launch_bounds__(kDetThreads) void det_tie_ready_kernel(DetArgs a, int layer, int32_t *waiting)
+{
+    const int p = blockIdx.y;
+    const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
+    const int i = ls[layer] + blockIdx.x * kDetThreads + threadIdx.x;
+    if (i >= ls[layer + 1]) return;
+    const int64_t ci = (int64_t)p * a.cand_cap + i;
+    if (a.cand_flag[ci] != kDetTie) return;
+    const uint32_t xy = a.cand_xy[ci];
+    const PairView v = pair_view(a, p);
+    if (tie_ready(v, a.dg->L[layer], a.safe_threshold, (int)(xy & 0xffff), (int)(xy >> 16)))
+        a.cand_flag[ci] = kDetTieReady;
+    else
+        atomicAdd(&waiting[p], 1);
+}
+
+__global__ __launch_bounds__(kDetThreads) void det_tie_decide_kernel(DetArgs a, int layer)
+{
+    __shared__ __attribute__((aligned(4))) uint8_t windows[kDetThreads * kWinStride];
+    const int p = blockIdx.y;
+    const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
+    const int i = ls[layer] + blockIdx.x * kDetThreads + threadIdx.x;
+    if (i >= ls[layer + 1]) return;
+    const int64_t ci = (int64_t)p * a.cand_cap + i;
+    if (a.cand_flag[ci] != kDetTieReady) return;
+    const uint32_t xy = a.cand_xy[ci];
+    const PairView v = pair_view(a, p);
+    tie_decide(a, v, windows + threadIdx.x * kWinStride, a.dg->L[layer], p, i, layer, (int)(xy & 0xffff), (int)(xy >> 16));
+}
+
+// Whatever the global rounds left waiting (chains of ties that depend on each other): one workgroup per pair loops
+// until the layer is settled.  Pairs with nothing waiting leave at once.
+__global__ __launch_bounds__(kDetThreads) void det_tie_residual_kernel(DetArgs a, int layer, const int32_t *waiting)
 {
     __shared__ int remaining;
+    __shared__ __attribute__((aligned(4))) uint8_t windows[kDetThreads * kWinStride];
     const int p = blockIdx.x;
+    if (waiting[p] == 0) return;
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
     const PairView v = pair_view(a, p);
     const int64_t cb = (int64_t)p * a.cand_cap;
-    for (int layer = 0; layer < a.g.n_layers; ++layer) {
-        const DetLayer L = a.g.L[layer];
-        const int lo = ls[layer], hi = ls[layer + 1];
-        for (;;) {
-            if (threadIdx.x == 0) remaining = 0;
-            __syncthreads();
-            // phase 1: a tie is ready when no undecided tie that precedes it could still change the cells it reads
-            for (int i = lo + threadIdx.x; i < hi; i += kDetThreads) {
-                if (a.cand_flag[cb + i] != kDetTie) continue;
-                const uint32_t xy = a.cand_xy[cb + i];
-                const int px = (int)(xy & 0xffff), py = (int)(xy >> 16);
-                bool ready = true;
-                for (int dy = -3; dy <= 0 && ready; ++dy)
-                    for (int dx = -3; dx <= 3; ++dx) {
-                        if (dy == 0 && dx >= 0) break;
-                        const int mx = px + dx, my = py + dy;
-                        if (mx < 0 || my < 0 || mx >= L.w) continue;
-                        if (v.status[L.off + (int64_t)my * L.w + mx] == kStPending) {
-                            ready = false;
-                            break;
-                        }
-                    }
-                if (ready)
-                    a.cand_flag[cb + i] = kDetTieReady;
-                else
-                    atomicAdd(&remaining, 1);
-            }
-            __threadfence_block();
-            __syncthreads();
-            // phase 2: decide the ready ones
-            for (int i = lo + threadIdx.x; i < hi; i += kDetThreads) {
-                if (a.cand_flag[cb + i] != kDetTieReady) continue;
-                const uint32_t xy = a.cand_xy[cb + i];
-                const int px = (int)(xy & 0xffff), py = (int)(xy >> 16);
-                if (tie_is_max(v, L, a.safe_threshold, px, py)) {
-                    a.cand_flag[cb + i] = kDetMax;
-                    finish_candidate(a, v, p, i, layer, px, py);
-                } else {
-                    a.cand_flag[cb + i] = kDetNotMax;
-                    v.status[L.off + (int64_t)py * L.w + px] = kStDone;
-                }
-            }
-            __threadfence_block();
-            __syncthreads();
-            if (remaining == 0) break;
-            __syncthreads();
+    const DetLayer L = a.dg->L[layer];
+    const int lo = ls[layer], hi = ls[layer + 1];
+    for (;;) {
+        if (threadIdx.x == 0) remaining = 0;
+        __syncthreads();
+        for (int i = lo + threadIdx.x; i < hi; i += kDetThreads) {
+            if (a.cand_flag[cb + i] != kDetTie) continue;
+            const uint32_t xy = a.cand_xy[cb + i];
+            if (tie_ready(v, L, a.safe_threshold, (int)(xy & 0xffff), (int)(xy >> 16)))
+                a.cand_flag[cb + i] = kDetTieReady;
+            else
+                atomicAdd(&remaining, 1);
         }
+        __threadfence_block();
+        __syncthreads();
+        for (int i = lo + threadIdx.x; i < hi; i += kDetThreads) {
+            if (a.cand_flag[cb + i] != kDetTieReady) continue;
+            const uint32_t xy = a.cand_xy[cb + i];
+            tie_decide(a, v, windows + threadIdx.x * kWinStride, L, p, i, layer, (int)(xy & 0xffff), (int)(xy >> 16));
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (remaining == 0) break;
+        __syncthreads();
     }
 }
 
@@ -900,7 +979,7 @@ __global__ __launch_bounds__(kDetThreads) void det_emit_count_kernel(DetArgs a)
     const int p = blockIdx.x;
     if (threadIdx.x == 0) total = 0;
     __syncthreads();
-    const int n = a.layer_start[(int64_t)p * (kDetMaxLayers + 1) + a.g.n_layers];
+    const int n = a.layer_start[(int64_t)p * (kDetMaxLayers + 1) + a.dg->n_layers];
     int c = 0;
     for (int i = threadIdx.x; i < n; i += kDetThreads) c += a.cand_emit[(int64_t)p * a.cand_cap + i];
     c = wave_sum(c);
@@ -948,7 +1027,7 @@ __global__ __launch_bounds__(kDetThreads) void det_emit_scatter_kernel(DetArgs a
     __shared__ int wave_cnt[4];
     const int p = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
-    const int n = ls[a.g.n_layers];
+    const int n = ls[a.dg->n_layers];
     long long run = a.emit_offsets[p];
     for (int i0 = 0; i0 < n; i0 += kDetThreads) {
         const int i = i0 + threadIdx.x;
@@ -968,7 +1047,7 @@ __global__ __launch_bounds__(kDetThreads) void det_emit_scatter_kernel(DetArgs a
                 const DetResult r = a.cand_res[ci];
                 a.out_kps[o] = mofreak_keypoint{r.x, r.y, r.size};
                 if (a.out_response) a.out_response[o] = r.response;
-                if (a.out_layer) a.out_layer[o] = layer_of(ls, a.g.n_layers, i);
+                if (a.out_layer) a.out_layer[o] = layer_of(ls, a.dg->n_layers, i);
             }
         }
         run += all;
@@ -1012,7 +1091,16 @@ int launch_det_keypoints(const DetArgs &a, int64_t *running, void *stream)
     hipLaunchKernelGGL(det_scan_kernel, dim3(a.n_pairs), dim3(kDetThreads), 0, s, a);
     hipLaunchKernelGGL(det_candidates_kernel, dim3((a.g.total_rows + 3) / 4, a.n_pairs), dim3(kDetThreads), 0, s, a);
     hipLaunchKernelGGL(det_refine_kernel, dim3((a.cand_cap + kDetThreads - 1) / kDetThreads, a.n_pairs), dim3(kDetThreads), 0, s, a);
-    hipLaunchKernelGGL(det_tie_kernel, dim3(a.n_pairs), dim3(kDetThreads), 0, s, a);
+    // ties: layer by layer (a layer's ties read what the maxima of the layer below asked for in it)
+    const dim3 cgrid((a.cand_cap + kDetThreads - 1) / kDetThreads, a.n_pairs);
+    for (int l = 0; l < a.g.n_layers; ++l) {
+        for (int round = 0; round < kDetTieRounds; ++round) {
+            hipLaunchKernelGGL(det_tie_ready_kernel, cgrid, dim3(kDetThreads), 0, s, a, l, a.tie_waiting + (int64_t)(l * kDetTieRounds + round) * a.n_pairs);
+            hipLaunchKernelGGL(det_tie_decide_kernel, cgrid, dim3(kDetThreads), 0, s, a, l);
+        }
+        hipLaunchKernelGGL(det_tie_residual_kernel, dim3(a.n_pairs), dim3(kDetThreads), 0, s, a, l,
+                           a.tie_waiting + (int64_t)(l * kDetTieRounds + kDetTieRounds - 1) * a.n_pairs);
+    }
     hipLaunchKernelGGL(det_emit_count_kernel, dim3(a.n_pairs), dim3(kDetThreads), 0, s, a);
     hipLaunchKernelGGL(det_emit_scan_kernel, dim3(1), dim3(kDetThreads), 0, s, a, running);
     hipLaunchKernelGGL(det_emit_scatter_kernel, dim3(a.n_pairs), dim3(kDetThreads), 0, s, a);

@@ -167,7 +167,8 @@ struct DetResult {
     float x, y, size, response;
 };
 struct DetArgs {
-    DetGeom g;
+    DetGeom g;          // host copy for the launchers; device code reads *dg (indexing a by-value kernel argument with a
+    const DetGeom *dg;  // per-thread layer number would spill the whole argument block to scratch)
     FrameArgs f;  // cur / prev of the batch's first pair (prev == nullptr: cur already is the image to search)
     int32_t n_pairs;
     int32_t threshold, safe_threshold;
@@ -180,6 +181,7 @@ struct DetArgs {
     DetResult *cand_res;                    // [n_pairs][cand_cap]
     int32_t *layer_start;                   // [n_pairs][kDetMaxLayers + 1]
     int32_t *emit_count;                    // [n_pairs]
+    int32_t *tie_waiting;                   // [kDetMaxLayers * 2][n_pairs], zeroed per batch: ties a global round left waiting
     int64_t *emit_offsets;                  // [n_pairs + 1], relative to out_base
     mofreak_keypoint *out_kps;              // whole-call outputs
     float *out_response;                    // optional
