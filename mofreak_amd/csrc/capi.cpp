@@ -40,7 +40,7 @@ struct mofreak_ctx {
     DeviceBuffer kp_key, sorted_idx, slow_list, tile_start, tile_cursor, slow_count, tile_lmin, tile_lmax;  // keypoint binning
     DeviceBuffer bow_counts;
     // keypoint detector workspace
-    DeviceBuffer det_img, det_score, det_touch, det_status, det_rows, det_cand_xy, det_cand_flag, det_cand_emit, det_cand_res, det_layer_start,
+    DeviceBuffer det_img, det_score, det_touch, det_status, det_rows, det_cand_xy, det_cand_flag, det_cand_emit, det_cand_spec, det_cand_asked, det_cand_win, det_cand_res, det_layer_start,
         det_emit_count, det_tie_waiting, det_geom, det_emit_offsets, det_running, det_out_kps, det_out_offsets, det_out_resp, det_out_layer, det_planes_out;
     int det_cand_cap = 131072;
     ThetaBound *d_theta = nullptr;
@@ -568,7 +568,7 @@ void mofreak_destroy(mofreak_ctx *ctx)
     release(ctx->slow_count);
     release(ctx->bow_counts);
     for (DeviceBuffer *b : {&ctx->det_img, &ctx->det_score, &ctx->det_touch, &ctx->det_status, &ctx->det_rows, &ctx->det_cand_xy, &ctx->det_cand_flag,
-                            &ctx->det_cand_emit, &ctx->det_cand_res, &ctx->det_layer_start, &ctx->det_emit_count, &ctx->det_tie_waiting, &ctx->det_geom, &ctx->det_emit_offsets,
+                            &ctx->det_cand_emit, &ctx->det_cand_spec, &ctx->det_cand_asked, &ctx->det_cand_win, &ctx->det_cand_res, &ctx->det_layer_start, &ctx->det_emit_count, &ctx->det_tie_waiting, &ctx->det_geom, &ctx->det_emit_offsets,
                             &ctx->det_running, &ctx->det_out_kps, &ctx->det_out_offsets, &ctx->det_out_resp, &ctx->det_out_layer, &ctx->det_planes_out})
         release(*b);
     release(ctx->integral);
@@ -1203,6 +1203,9 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     if ((rc = ensure(ctx, ctx->det_cand_xy, cands * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_cand_flag, cands))) return rc;
     if ((rc = ensure(ctx, ctx->det_cand_emit, cands))) return rc;
+    if ((rc = ensure(ctx, ctx->det_cand_spec, cands))) return rc;
+    if ((rc = ensure(ctx, ctx->det_cand_asked, cands * sizeof(unsigned long long)))) return rc;
+    if ((rc = ensure(ctx, ctx->det_cand_win, cands * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_cand_res, cands * sizeof(DetResult)))) return rc;
     if ((rc = ensure(ctx, ctx->det_layer_start, (size_t)batch * (kDetMaxLayers + 1) * sizeof(int32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_emit_count, (size_t)batch * sizeof(int32_t)))) return rc;
@@ -1221,6 +1224,9 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     a.cand_xy = static_cast<uint32_t *>(ctx->det_cand_xy.ptr);
     a.cand_flag = static_cast<uint8_t *>(ctx->det_cand_flag.ptr);
     a.cand_emit = static_cast<uint8_t *>(ctx->det_cand_emit.ptr);
+    a.cand_spec = static_cast<uint8_t *>(ctx->det_cand_spec.ptr);
+    a.cand_asked = static_cast<unsigned long long *>(ctx->det_cand_asked.ptr);
+    a.cand_win = static_cast<uint32_t *>(ctx->det_cand_win.ptr);
     a.cand_res = static_cast<DetResult *>(ctx->det_cand_res.ptr);
     a.layer_start = static_cast<int32_t *>(ctx->det_layer_start.ptr);
     a.emit_count = static_cast<int32_t *>(ctx->det_emit_count.ptr);
@@ -1233,7 +1239,7 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
 // pairs per batch: about 1 GiB of planes and candidate records
 int det_batch(const mofreak_ctx *ctx, const DetGeom &g, int n_pairs)
 {
-    const size_t per_pair = 4 * (size_t)g.plane_bytes + (size_t)ctx->det_cand_cap * (sizeof(uint32_t) + 2 + sizeof(DetResult));
+    const size_t per_pair = 4 * (size_t)g.plane_bytes + (size_t)ctx->det_cand_cap * (sizeof(uint32_t) + 3 + 12 + sizeof(DetResult));
     const size_t b = std::max<size_t>(1, ((size_t)1 << 30) / per_pair);
     return (int)std::min<size_t>({b, (size_t)std::max(n_pairs, 1), (size_t)16384});
 }
@@ -1327,6 +1333,7 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
     HIP_TRY(ctx, hipMemcpyAsync(&st, ctx->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (n_out) *n_out = total;
+    if (st & 16) return fail(ctx, MOFREAK_ERR_HIP, "detector: a refinement walk left its staged window (internal error)");
     if (st & 4) return fail(ctx, MOFREAK_ERR_CAPACITY, "more corner candidates in one pair than the detector reserved (mofreak_detect_set_capacity)");
     if (host) {
         const int64_t n_copy = std::min(total, capacity);

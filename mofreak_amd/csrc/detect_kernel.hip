@@ -287,18 +287,19 @@ __device__ __forceinline__ int score_at(const PairView &v, int layer, int x, int
     const bool in = x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3;
     const int64_t o = L.off + (in ? (int64_t)y * L.w + x : 0);  // unconditional load: independent loads overlap
     const int s = v.score[o];
-    if (MARK && in) v.touch[o] = 1;
     return in ? s : 0;
 }
 
 // The part of a neighbouring layer's score map one refinement walk can reach -- at most 5 x 5 cells from the corner
-// ((int)x_1, (int)y_1) of getScoreMaxAbove/Below's sampling square, patch and tie rings included -- fetched with 36
+// ((int)x_1 - 1, (int)y_1 - 1) of getScoreMaxAbove/Below's sampling square, patch and tie rings included -- fetched with 36
 // independent loads into the thread's own 36 bytes of LDS.  The walk itself is a chain of data-dependent early
 // exits: on global memory every step would pay a full memory latency.
 constexpr int kWinSide = 6, kWinStride = 36;  // bytes per thread (9 dwords: neighbouring threads hit different banks)
 struct Window {
     uint8_t *cells;
     int ox, oy, layer;
+    unsigned long long asked;  // bit iy * kWinSide + ix: the walk asked for this cell (and the cell is inside the scored region)
+    bool escaped;              // the walk left the window (cannot happen by construction; reported if it does)
 };
 
 __device__ __forceinline__ void window_load(const PairView &v, Window &w)
@@ -318,15 +319,29 @@ __device__ __forceinline__ void window_load(const PairView &v, Window &w)
 }
 
 template <bool MARK>
-__device__ __forceinline__ int window_at(const PairView &v, const Window &w, int x, int y)
+__device__ __forceinline__ int window_at(const PairView &v, Window &w, int x, int y)
 {
     const int ix = x - w.ox, iy = y - w.oy;
-    if ((unsigned)ix >= (unsigned)kWinSide || (unsigned)iy >= (unsigned)kWinSide) return score_at<MARK>(v, w.layer, x, y);  // not expected
+    if ((unsigned)ix >= (unsigned)kWinSide || (unsigned)iy >= (unsigned)kWinSide) {
+        w.escaped = true;
+        return score_at<false>(v, w.layer, x, y);
+    }
     if (MARK) {
         const DetLayer &L = v.g->L[w.layer];
-        if (x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3) v.touch[L.off + (int64_t)y * L.w + x] = 1;
+        if (x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3) w.asked |= 1ull << (iy * kWinSide + ix);
     }
     return w.cells[iy * kWinSide + ix];
+}
+
+// The cells a walk asked for in the layer above become "cached" there -- once the walker is known to be a maximum.
+__device__ __forceinline__ void apply_asked(const PairView &v, int layer_above, int ox, int oy, unsigned long long asked)
+{
+    const DetLayer &L = v.g->L[layer_above];
+    while (asked) {
+        const int k = __ffsll((long long)asked) - 1;
+        asked &= asked - 1;
+        v.touch[L.off + (int64_t)(oy + k / kWinSide) * L.w + ox + k % kWinSide] = 1;
+    }
 }
 
 // AgastDetector5_8::cornerScore from b = 0 (agast5_8_nms.cc:42; brisk.cpp:1696-1703): 5 contiguous of the 8 neighbours
@@ -524,8 +539,8 @@ __device__ __forceinline__ float patch_subpixel(const PairView &v, int layer, in
 
 // getScoreMaxAbove (ABOVE, brisk.cpp:1106-1249) / getScoreMaxBelow (:1251-1416)
 template <bool ABOVE>
-__device__ __forceinline__ float neighbour_layer_max(const PairView &v, uint8_t *lds_cells, int layer, int x_layer, int y_layer, int threshold, bool &ismax, float &dx,
-                                     float &dy)
+__device__ __forceinline__ float neighbour_layer_max(const PairView &v, Window &win, int layer, int x_layer, int y_layer, int threshold, bool &ismax, float &dx,
+                                                     float &dy)
 {
     ismax = false;
     const int nl = ABOVE ? layer + 1 : layer - 1;
@@ -558,7 +573,10 @@ __device__ __forceinline__ float neighbour_layer_max(const PairView &v, uint8_t 
     }
     const float thr = (float)threshold;
     const int xa = (int)(x_1 + 1), xb = (int)x1, ya = (int)(y_1 + 1), yb = (int)y1;
-    Window win{lds_cells, (int)x_1, (int)y_1, nl};
+    win.ox = (int)x_1 - 1;  // the walk reaches from (int)x_1 - 1 (patch around max_x = (int)x1 when that equals (int)x_1)
+    win.oy = (int)y_1 - 1;  // to (int)x1 + 1 <= (int)x_1 + 3: five cells; the window holds six
+    win.layer = nl;
+    win.asked = 0;
     window_load(v, win);
     auto S = [&](int x, int y) { return window_at<ABOVE>(v, win, x, y); };  // getAgastScore(int, int, 1)
     auto Q = [&](int x, int y) { return window_at<false>(v, win, x, y); };  // same, for the layer below (no bookkeeping)
@@ -691,7 +709,10 @@ __device__ __forceinline__ float neighbour_layer_max(const PairView &v, uint8_t 
 
 struct Refined {
     bool emit, reached;  // reached: the walk got as far as the 3x3 patch on its own layer (those cells are cached from then on)
+    bool escaped;
     DetResult r;
+    unsigned long long asked;  // cells of the layer above the walk asked for, relative to (ox, oy)
+    int ox, oy;
 };
 
 // What getKeypoints does with one 2-D maximum (brisk.cpp:609-702), refine3D included (:937-1103).
@@ -706,17 +727,28 @@ __device__ __forceinline__ Refined refine_maximum(const PairView &v, uint8_t *ld
     out.emit = false;
     out.reached = false;
     out.r = DetResult{0.f, 0.f, 0.f, 0.f};
+    out.asked = 0;
+    out.ox = out.oy = 0;
+    out.escaped = false;
+    Window win;
+    win.cells = lds_cells;
+    win.escaped = false;
     const bool single = g.n_layers == 1, last = layer == g.n_layers - 1, octave = (layer & 1) == 0;
     const int center = score_at<false>(v, layer, px, py);
     bool ismax = true;
     float max_above = 0.f, max_below = 0.f;
     float delta_x_above = 0.f, delta_y_above = 0.f, delta_x_below = 0.f, delta_y_below = 0.f, delta_x_layer, delta_y_layer;
     if (!last) {  // refine3D: getScoreMaxAbove first (:945-950)
-        max_above = neighbour_layer_max<true>(v, lds_cells, layer, px, py, center, ismax, delta_x_above, delta_y_above);
+        max_above = neighbour_layer_max<true>(v, win, layer, px, py, center, ismax, delta_x_above, delta_y_above);
+        out.asked = win.asked;
+        out.ox = win.ox;
+        out.oy = win.oy;
+        out.escaped = win.escaped;
         if (!ismax) return out;
     }
     if (layer > 0) {  // getScoreMaxBelow: the last layer (:651-657), octaves above 0 (:991-996), intra layers (:1049-1053)
-        max_below = neighbour_layer_max<false>(v, lds_cells, layer, px, py, center, ismax, delta_x_below, delta_y_below);
+        max_below = neighbour_layer_max<false>(v, win, layer, px, py, center, ismax, delta_x_below, delta_y_below);
+        out.escaped |= win.escaped;
         if (!ismax) return out;
     } else if (!single) {  // layer 0: guess the missing layer below with the 5/8 mask (:959-989)
         int s[9];
@@ -782,17 +814,33 @@ __device__ __forceinline__ int layer_of(const int32_t *layer_start, int n_layers
     return l;
 }
 
+// cand_emit bits
+constexpr uint8_t kEmit = 1, kReached = 2;
+
+// Refinement of candidate i.  It reads nothing but the dense score maps, so it does not depend on whether the
+// candidate's tie (if it has one) is already decided: SPECULATIVE runs it ahead of the decision and parks what the
+// decision will publish -- result, "reached its patch", and the cells it asked for in the layer above.
+template <bool SPECULATIVE>
 __device__ __forceinline__ void finish_candidate(const DetArgs &a, const PairView &v, uint8_t *lds_cells, int p, int i, int layer, int x, int y)
 {
     const Refined r = refine_maximum(v, lds_cells, layer, x, y, a.threshold);
     const int64_t ci = (int64_t)p * a.cand_cap + i;
-    a.cand_emit[ci] = r.emit ? 1 : 0;
     a.cand_res[ci] = r.r;
-    const DetLayer &L = a.dg->L[layer];
-    v.status[L.off + (int64_t)y * L.w + x] = r.reached ? kStReached : kStDone;
+    if (r.escaped) atomicOr(a.status_word, 16);
+    if (SPECULATIVE) {
+        a.cand_emit[ci] = 0;
+        a.cand_spec[ci] = (uint8_t)((r.emit ? kEmit : 0) | (r.reached ? kReached : 0));
+        a.cand_asked[ci] = r.asked;
+        a.cand_win[ci] = (uint32_t)r.ox | (uint32_t)r.oy << 16;
+    } else {
+        a.cand_emit[ci] = r.emit ? 1 : 0;
+        const DetLayer &L = a.dg->L[layer];
+        v.status[L.off + (int64_t)y * L.w + x] = r.reached ? kStReached : kStDone;
+        if (r.asked) apply_asked(v, layer + 1, r.ox, r.oy, r.asked);
+    }
 }
 
-// maxima without ties: independent of everything else
+// maxima without ties: independent of everything else; ties: refined ahead of their decision
 __global__ __launch_bounds__(kDetThreads) void det_refine_kernel(DetArgs a)
 {
     __shared__ __attribute__((aligned(4))) uint8_t windows[kDetThreads * kWinStride];
@@ -800,10 +848,15 @@ __global__ __launch_bounds__(kDetThreads) void det_refine_kernel(DetArgs a)
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
     if (i >= ls[a.dg->n_layers]) return;
     const int64_t ci = (int64_t)p * a.cand_cap + i;
-    if (a.cand_flag[ci] != kDetMax) return;
+    const uint8_t flag = a.cand_flag[ci];
+    if (flag == kDetNotMax) return;
     const uint32_t xy = a.cand_xy[ci];
     const PairView v = pair_view(a, p);
-    finish_candidate(a, v, windows + threadIdx.x * kWinStride, p, i, layer_of(ls, a.dg->n_layers, i), (int)(xy & 0xffff), (int)(xy >> 16));
+    const int layer = layer_of(ls, a.dg->n_layers, i), x = (int)(xy & 0xffff), y = (int)(xy >> 16);
+    if (flag == kDetMax)
+        finish_candidate<false>(a, v, windows + threadIdx.x * kWinStride, p, i, layer, x, y);
+    else
+        finish_candidate<true>(a, v, windows + threadIdx.x * kWinStride, p, i, layer, x, y);
 }
 
 // ---- ties
@@ -889,12 +942,19 @@ __device__ __forceinline__ bool tie_ready(const PairView &v, const DetLayer &L, 
     return true;
 }
 
-__device__ __forceinline__ void tie_decide(const DetArgs &a, const PairView &v, uint8_t *lds_cells, const DetLayer &L, int p, int i, int layer, int px, int py)
+__device__ __forceinline__ void tie_decide(const DetArgs &a, const PairView &v, const DetLayer &L, int p, int i, int layer, int px, int py)
 {
     const int64_t ci = (int64_t)p * a.cand_cap + i;
-    if (tie_is_max(v, L, a.safe_threshold, px, py)) {
+    if (tie_is_max(v, L, a.safe_threshold, px, py)) {  // publish what the refinement kernel parked
+        const uint8_t spec = a.cand_spec[ci];
         a.cand_flag[ci] = kDetMax;
-        finish_candidate(a, v, lds_cells, p, i, layer, px, py);
+        a.cand_emit[ci] = (spec & kEmit) ? 1 : 0;
+        v.status[L.off + (int64_t)py * L.w + px] = (spec & kReached) ? kStReached : kStDone;
+        const unsigned long long asked = a.cand_asked[ci];
+        if (asked) {
+            const uint32_t o = a.cand_win[ci];
+            apply_asked(v, layer + 1, (int)(o & 0xffff), (int)(o >> 16), asked);
+        }
     } else {
         a.cand_flag[ci] = kDetNotMax;
         v.status[L.off + (int64_t)py * L.w + px] = kStDone;
@@ -922,7 +982,6 @@ __global__ __launch_bounds__(kDetThreads) void det_tie_ready_kernel(DetArgs a, i
 
 __global__ __launch_bounds__(kDetThreads) void det_tie_decide_kernel(DetArgs a, int layer)
 {
-    __shared__ __attribute__((aligned(4))) uint8_t windows[kDetThreads * kWinStride];
     const int p = blockIdx.y;
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
     const int i = ls[layer] + blockIdx.x * kDetThreads + threadIdx.x;
@@ -931,7 +990,7 @@ __global__ __launch_bounds__(kDetThreads) void det_tie_decide_kernel(DetArgs a, 
     if (a.cand_flag[ci] != kDetTieReady) return;
     const uint32_t xy = a.cand_xy[ci];
     const PairView v = pair_view(a, p);
-    tie_decide(a, v, windows + threadIdx.x * kWinStride, a.dg->L[layer], p, i, layer, (int)(xy & 0xffff), (int)(xy >> 16));
+    tie_decide(a, v, a.dg->L[layer], p, i, layer, (int)(xy & 0xffff), (int)(xy >> 16));
 }
 
 // Whatever the global rounds left waiting (chains of ties that depend on each other): one workgroup per pair loops
@@ -939,7 +998,6 @@ __global__ __launch_bounds__(kDetThreads) void det_tie_decide_kernel(DetArgs a, 
 __global__ __launch_bounds__(kDetThreads) void det_tie_residual_kernel(DetArgs a, int layer, const int32_t *waiting)
 {
     __shared__ int remaining;
-    __shared__ __attribute__((aligned(4))) uint8_t windows[kDetThreads * kWinStride];
     const int p = blockIdx.x;
     if (waiting[p] == 0) return;
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
@@ -963,7 +1021,7 @@ __global__ __launch_bounds__(kDetThreads) void det_tie_residual_kernel(DetArgs a
         for (int i = lo + threadIdx.x; i < hi; i += kDetThreads) {
             if (a.cand_flag[cb + i] != kDetTieReady) continue;
             const uint32_t xy = a.cand_xy[cb + i];
-            tie_decide(a, v, windows + threadIdx.x * kWinStride, L, p, i, layer, (int)(xy & 0xffff), (int)(xy >> 16));
+            tie_decide(a, v, L, p, i, layer, (int)(xy & 0xffff), (int)(xy >> 16));
         }
         __threadfence_block();
         __syncthreads();

@@ -178,6 +178,9 @@ struct DetArgs {
     uint32_t *cand_xy;                      // [n_pairs][cand_cap]  x | y << 16
     uint8_t *cand_flag;                     // [n_pairs][cand_cap]
     uint8_t *cand_emit;                     // [n_pairs][cand_cap]
+    uint8_t *cand_spec;                     // [n_pairs][cand_cap] ties: emit / reached bits of the refinement run ahead of the decision
+    unsigned long long *cand_asked;         // [n_pairs][cand_cap] ties: cells asked for in the layer above (bit mask over a 6 x 6 window)
+    uint32_t *cand_win;                     // [n_pairs][cand_cap] ties: that window's origin, x | y << 16
     DetResult *cand_res;                    // [n_pairs][cand_cap]
     int32_t *layer_start;                   // [n_pairs][kDetMaxLayers + 1]
     int32_t *emit_count;                    // [n_pairs]
@@ -189,7 +192,7 @@ struct DetArgs {
     int64_t out_capacity, out_base;
     int64_t *out_offsets;                   // whole-call CSR offsets; this batch fills [first_pair .. first_pair + n_pairs]
     int64_t first_pair;
-    int32_t *status_word;                   // bit 2: more candidates than cand_cap; bit 3: more keypoints than out_capacity
+    int32_t *status_word;                   // bit 2: more candidates than cand_cap; bit 3: more keypoints than out_capacity; bit 4: internal (a walk left its window)
 };
 
 // launchers (kernels.hip); all asynchronous on `stream`, return a hipError_t value as int
