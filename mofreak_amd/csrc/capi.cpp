@@ -41,7 +41,7 @@ struct mofreak_ctx {
     DeviceBuffer bow_counts;
     // keypoint detector workspace
     DeviceBuffer det_img, det_score, det_touch, det_status, det_rows, det_cand_xy, det_cand_flag, det_cand_emit, det_cand_spec, det_cand_asked, det_cand_win, det_cand_res, det_layer_start,
-        det_emit_count, det_tie_waiting, det_geom, det_emit_offsets, det_running, det_out_kps, det_out_offsets, det_out_resp, det_out_layer, det_planes_out;
+        det_emit_count, det_tie_waiting, det_wait_list, det_geom, det_emit_offsets, det_running, det_out_kps, det_out_offsets, det_out_resp, det_out_layer, det_planes_out;
     int det_cand_cap = 131072;
     ThetaBound *d_theta = nullptr;
     unsigned long long *d_stamps = nullptr;  // MOFREAK_TILE_STAMPS=1: per-phase tick sums of the diagnostic tile kernel
@@ -568,7 +568,7 @@ void mofreak_destroy(mofreak_ctx *ctx)
     release(ctx->slow_count);
     release(ctx->bow_counts);
     for (DeviceBuffer *b : {&ctx->det_img, &ctx->det_score, &ctx->det_touch, &ctx->det_status, &ctx->det_rows, &ctx->det_cand_xy, &ctx->det_cand_flag,
-                            &ctx->det_cand_emit, &ctx->det_cand_spec, &ctx->det_cand_asked, &ctx->det_cand_win, &ctx->det_cand_res, &ctx->det_layer_start, &ctx->det_emit_count, &ctx->det_tie_waiting, &ctx->det_geom, &ctx->det_emit_offsets,
+                            &ctx->det_cand_emit, &ctx->det_cand_spec, &ctx->det_cand_asked, &ctx->det_cand_win, &ctx->det_cand_res, &ctx->det_layer_start, &ctx->det_emit_count, &ctx->det_tie_waiting, &ctx->det_wait_list, &ctx->det_geom, &ctx->det_emit_offsets,
                             &ctx->det_running, &ctx->det_out_kps, &ctx->det_out_offsets, &ctx->det_out_resp, &ctx->det_out_layer, &ctx->det_planes_out})
         release(*b);
     release(ctx->integral);
@@ -1232,6 +1232,8 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     a.emit_count = static_cast<int32_t *>(ctx->det_emit_count.ptr);
     a.emit_offsets = static_cast<int64_t *>(ctx->det_emit_offsets.ptr);
     a.tie_waiting = static_cast<int32_t *>(ctx->det_tie_waiting.ptr);
+    if ((rc = ensure(ctx, ctx->det_wait_list, (size_t)batch * 4096 * sizeof(int32_t)))) return rc;
+    a.wait_list = static_cast<int32_t *>(ctx->det_wait_list.ptr);
     a.status_word = ctx->d_status;
     return MOFREAK_OK;
 }

@@ -964,6 +964,8 @@ __device__ __forceinline__ void tie_decide(const DetArgs &a, const PairView &v, 
 // Ties of one layer, all pairs at once, in rounds of mutually independent ones: `ready` marks them (and counts the
 // ones that have to wait), `decide` settles the marked ones.  Two launches, because a tie must not see a neighbour
 // half-way through its decision.
+constexpr int kDetWaitCap = 4096;  // waiting ties per pair and layer the residual loop takes from a list (more: it scans)
+
 __global__ __launch_bounds__(kDetThreads) void det_tie_ready_kernel(DetArgs a, int layer, int32_t *waiting)
 {
     const int p = blockIdx.y;
@@ -976,8 +978,10 @@ __global__ __launch_bounds__(kDetThreads) void det_tie_ready_kernel(DetArgs a, i
     const PairView v = pair_view(a, p);
     if (tie_ready(v, a.dg->L[layer], a.safe_threshold, (int)(xy & 0xffff), (int)(xy >> 16)))
         a.cand_flag[ci] = kDetTieReady;
-    else
-        atomicAdd(&waiting[p], 1);
+    else {
+        const int k = atomicAdd(&waiting[p], 1);
+        if (k < kDetWaitCap) a.wait_list[(int64_t)p * kDetWaitCap + k] = i;
+    }
 }
 
 __global__ __launch_bounds__(kDetThreads) void det_tie_decide_kernel(DetArgs a, int layer)
@@ -1005,10 +1009,16 @@ __global__ __launch_bounds__(kDetThreads) void det_tie_residual_kernel(DetArgs a
     const int64_t cb = (int64_t)p * a.cand_cap;
     const DetLayer L = a.dg->L[layer];
     const int lo = ls[layer], hi = ls[layer + 1];
+    // the waiting ties: from the list the last global round left, or (list overflow) every candidate of the layer
+    const int n_wait = waiting[p];
+    const bool listed = n_wait <= kDetWaitCap;
+    const int32_t *list = a.wait_list + (int64_t)p * kDetWaitCap;
+    const int n_items = listed ? n_wait : hi - lo;
     for (;;) {
         if (threadIdx.x == 0) remaining = 0;
         __syncthreads();
-        for (int i = lo + threadIdx.x; i < hi; i += kDetThreads) {
+        for (int k = threadIdx.x; k < n_items; k += kDetThreads) {
+            const int i = listed ? list[k] : lo + k;
             if (a.cand_flag[cb + i] != kDetTie) continue;
             const uint32_t xy = a.cand_xy[cb + i];
             if (tie_ready(v, L, a.safe_threshold, (int)(xy & 0xffff), (int)(xy >> 16)))
@@ -1018,10 +1028,27 @@ __global__ __launch_bounds__(kDetThreads) void det_tie_residual_kernel(DetArgs a
         }
         __threadfence_block();
         __syncthreads();
-        for (int i = lo + threadIdx.x; i < hi; i += kDetThreads) {
+        for (int k = threadIdx.x; k < n_items; k += kDetThreads) {
+            const int i = listed ? list[k] : lo + k;
             if (a.cand_flag[cb + i] != kDetTieReady) continue;
-            const uint32_t xy = a.cand_xy[cb + i];
-            tie_decide(a, v, L, p, i, layer, (int)(xy & 0xffff), (int)(xy >> 16));
+            uint32_t xy = a.cand_xy[cb + i];
+            int px = (int)(xy & 0xffff), py = (int)(xy >> 16);
+            tie_decide(a, v, L, p, i, layer, px, py);
+            // The usual chain is a run of equal scores along a row, each tie waiting for its left neighbour only:
+            // follow it instead of spending a round per link.  The next candidate in raster order is taken if it sits
+            // within reach on the same row, is still waiting (so no other thread owns it this round) and has become
+            // ready; everything it then reads is final (a decided status is written once and never changes).
+            for (int j = i + 1; j < hi; ++j) {
+                __threadfence_block();
+                if (a.cand_flag[cb + j] != kDetTie) break;
+                xy = a.cand_xy[cb + j];
+                const int nx = (int)(xy & 0xffff), ny = (int)(xy >> 16);
+                if (ny != py || nx - px > 3) break;
+                if (!tie_ready(v, L, a.safe_threshold, nx, ny)) break;
+                tie_decide(a, v, L, p, j, layer, nx, ny);
+                atomicSub(&remaining, 1);
+                px = nx;
+            }
         }
         __threadfence_block();
         __syncthreads();
