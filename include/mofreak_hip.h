@@ -203,6 +203,16 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
                          int64_t pair_stride, int n_pairs, int threshold, int octaves, mofreak_keypoint *out_kps,
                          int64_t capacity, int64_t *out_offsets, float *out_response, int32_t *out_layer, int64_t *n_out,
                          unsigned flags);
+/*
+ * The whole frame loop of MoFREAKUtilities::computeMoFREAKFromFile (MoFREAKUtilities.cpp:391-491) for a T-frame gray
+ * stack already in memory: for every frame from index gap on, BRISK keypoints on |frame - frame[-gap]|
+ * (mofreak_detect_pairs), their MoFREAK descriptors (mofreak_extract_pairs) and the rows FREAK did not erase, in the
+ * order the reference appends them (mofreak_compact_rows).  Equivalent to those three calls; frames cross the host
+ * boundary once.  Synchronises the stream.
+ */
+int mofreak_compute_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W, int H, int threshold, int octaves,
+                           mofreak_row *rows_out, int64_t rows_capacity, int64_t *n_rows_out, int64_t *n_keypoints_out,
+                           unsigned flags);
 /* Candidates per pair the detector reserves room for (default 131072); more corners than that in one pair's pyramid
  * make mofreak_detect_pairs return MOFREAK_ERR_CAPACITY. */
 int mofreak_detect_set_capacity(mofreak_ctx *ctx, int candidates_per_pair);

@@ -36,7 +36,7 @@ EXPORTS = [
     "mofreak_parse_rows", "mofreak_diff_integral", "mofreak_mip19", "mofreak_roi19", "mofreak_freak_info",
     "mofreak_theta_index", "mofreak_pattern_sizes", "mofreak_scale_index", "mofreak_table_pattern",
     "mofreak_table_orientation", "mofreak_table_bit_pairs", "mofreak_table_resize",
-    "mofreak_detect_pairs", "mofreak_detect_set_capacity", "mofreak_brisk_pyramid",
+    "mofreak_detect_pairs", "mofreak_detect_set_capacity", "mofreak_brisk_pyramid", "mofreak_compute_stream",
 ]
 
 
@@ -100,6 +100,7 @@ def load() -> C.CDLL:
     L.mofreak_extract_pairs.argtypes = [vp, vp, vp, i32, i32, i64, i64, i32, vp, vp, i64, vp, vp, C.c_uint]
     L.mofreak_detect_pairs.argtypes = [vp, vp, vp, i32, i32, i64, i64, i32, i32, i32, vp, i64, vp, vp, vp, C.POINTER(i64), C.c_uint]
     L.mofreak_detect_set_capacity.argtypes = [vp, i32]
+    L.mofreak_compute_stream.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, i64, C.POINTER(i64), C.POINTER(i64), C.c_uint]
     L.mofreak_brisk_pyramid.argtypes = [vp, vp, i32, i32, i64, i32, vp, vp, vp, vp, C.POINTER(C.c_int), C.c_uint]
     L.mofreak_compact_rows.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, i64, C.POINTER(i64), C.c_uint]
     L.mofreak_extract_stream.argtypes = [vp, vp, i32, i32, i32, vp, vp, i64, vp, i64, C.POINTER(i64), C.c_uint]
@@ -280,6 +281,31 @@ class Context:
         layer = np.zeros(capacity, np.int32)
         n = self.detect_pairs(cur, prev, W, H, n_pairs, kps, offs, threshold, octaves, resp, layer, capacity=capacity)
         return kps[:n].copy(), offs, resp[:n].copy(), layer[:n].copy()
+
+    def compute_stream(self, frames, T, W, H, rows_out, threshold=30, octaves=3, capacity=None):
+        """Detector + descriptors + compaction for a gray frame stack (numpy = host, torch cuda = device).
+        Returns (n_rows, n_keypoints)."""
+        host = _is_host(frames, rows_out)
+        capacity = int(rows_out.shape[0]) if capacity is None else capacity
+        n_rows, n_kp = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.mofreak_compute_stream(self._h, _ptr(frames), T, W, H, threshold, octaves, _ptr(rows_out), capacity,
+                                                     C.byref(n_rows), C.byref(n_kp), MEM_HOST if host else MEM_DEVICE))
+        return n_rows.value, n_kp.value
+
+    def compute_stream_host(self, frames: np.ndarray, threshold=30, octaves=3, capacity=None) -> np.ndarray:
+        """(T, H, W) u8 -> the rows of the .mofreak file the reference would write for this clip (ROW_DTYPE)."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        T, H, W = frames.shape
+        capacity = max(1, T) * 8192 if capacity is None else capacity
+        while True:
+            rows = np.zeros(capacity, ROW_DTYPE)
+            try:
+                n, _ = self.compute_stream(frames, T, W, H, rows, threshold, octaves)
+                return rows[:n].copy()
+            except MoFREAKError as e:
+                if e.code != ERR_CAPACITY or capacity > (1 << 28):
+                    raise
+                capacity *= 4
 
     def set_detect_capacity(self, candidates_per_pair: int):
         self._check(self._lib.mofreak_detect_set_capacity(self._h, candidates_per_pair))

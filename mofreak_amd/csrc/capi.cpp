@@ -43,6 +43,7 @@ struct mofreak_ctx {
     DeviceBuffer det_img, det_score, det_touch, det_status, det_rows, det_cand_xy, det_cand_flag, det_cand_emit, det_cand_spec, det_cand_asked, det_cand_win, det_cand_res, det_layer_start,
         det_emit_count, det_tie_waiting, det_wait_list, det_geom, det_emit_offsets, det_running, det_out_kps, det_out_offsets, det_out_resp, det_out_layer, det_planes_out;
     int det_cand_cap = 131072;
+    int64_t det_kp_capacity = 0;
     ThetaBound *d_theta = nullptr;
     unsigned long long *d_stamps = nullptr;  // MOFREAK_TILE_STAMPS=1: per-phase tick sums of the diagnostic tile kernel
     MipSample *d_mip_samples = nullptr;
@@ -1347,6 +1348,58 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
         }
     }
     if ((st & 8) || total > capacity) return fail(ctx, MOFREAK_ERR_CAPACITY, "more keypoints than out_kps holds");
+    return MOFREAK_OK;
+}
+
+int mofreak_compute_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W, int H, int threshold, int octaves, mofreak_row *rows_out,
+                           int64_t rows_capacity, int64_t *n_rows_out, int64_t *n_keypoints_out, unsigned flags)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    if (n_rows_out) *n_rows_out = 0;
+    if (n_keypoints_out) *n_keypoints_out = 0;
+    if (T < 0 || rows_capacity < 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "negative count");
+    const int gap = ctx->params.gap_for_frame_difference;
+    const int n_pairs = T - gap;
+    if (n_pairs <= 0) return MOFREAK_OK;
+    if (!frames || (rows_capacity > 0 && !rows_out)) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null pointer");
+    NEED_DEVICE(ctx);
+    const bool host = (flags & MOFREAK_MEM_HOST) != 0;
+    const int64_t fsz = (int64_t)W * H;
+    int rc;
+    const uint8_t *d_frames = frames;
+    if (host) {
+        if ((rc = upload(ctx, ctx->stage[0], frames, (size_t)T * fsz))) return rc;
+        d_frames = static_cast<const uint8_t *>(ctx->stage[0].ptr);
+    }
+    // keypoints: room for what the last call needed (at least 4096 per pair), grown once if this stream has more
+    int64_t n_kp = 0;
+    for (int attempt = 0;; ++attempt) {
+        const int64_t cap = std::max<int64_t>(ctx->det_kp_capacity, (int64_t)4096 * n_pairs);
+        if ((rc = ensure(ctx, ctx->det_out_kps, (size_t)cap * sizeof(mofreak_keypoint)))) return rc;
+        if ((rc = ensure(ctx, ctx->det_out_offsets, (size_t)(n_pairs + 1) * sizeof(int64_t)))) return rc;
+        rc = mofreak_detect_pairs(ctx, d_frames + (int64_t)gap * fsz, d_frames, W, H, W, fsz, n_pairs, threshold, octaves,
+                                  static_cast<mofreak_keypoint *>(ctx->det_out_kps.ptr), cap, static_cast<int64_t *>(ctx->det_out_offsets.ptr),
+                                  nullptr, nullptr, &n_kp, MOFREAK_MEM_DEVICE);
+        if (rc == MOFREAK_ERR_CAPACITY && n_kp > cap && attempt == 0) {
+            ctx->det_kp_capacity = n_kp + n_kp / 8;
+            continue;
+        }
+        if (rc) return rc;
+        break;
+    }
+    if (n_keypoints_out) *n_keypoints_out = n_kp;
+    if (n_kp == 0) return MOFREAK_OK;
+    mofreak_row *d_rows = rows_out;
+    if (host) {
+        if ((rc = ensure(ctx, ctx->stage[5], (size_t)std::max<int64_t>(rows_capacity, 1) * sizeof(mofreak_row)))) return rc;
+        d_rows = static_cast<mofreak_row *>(ctx->stage[5].ptr);
+    }
+    int64_t total = 0;
+    rc = mofreak_extract_stream(ctx, d_frames, T, W, H, static_cast<const mofreak_keypoint *>(ctx->det_out_kps.ptr),
+                                static_cast<const int64_t *>(ctx->det_out_offsets.ptr), n_kp, d_rows, rows_capacity, &total, MOFREAK_MEM_DEVICE);
+    if (n_rows_out) *n_rows_out = total;
+    if (rc) return rc;
+    if (host && total) HIP_TRY(ctx, hipMemcpy(rows_out, d_rows, (size_t)total * sizeof(mofreak_row), hipMemcpyDeviceToHost));
     return MOFREAK_OK;
 }
 

@@ -34,7 +34,7 @@ namespace mofreak {
 namespace {
 
 constexpr int kDetThreads = 256;
-constexpr int kDetTieRounds = 2;  // global rounds of tie decisions per layer before the per-pair loop takes the rest
+constexpr int kDetTieRounds = 1;  // global rounds of tie decisions per layer before the per-pair loop takes the rest
 
 struct PairView {
     const DetGeom *g;

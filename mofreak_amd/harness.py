@@ -2,8 +2,9 @@
 
   MoFREAKUtilities      the reference class (src/MoFREAK/MoFREAKUtilities.h:55-104): same method names,
                         argument meaning and outputs; "videos" are raw gray frame stacks (.npy, T x H x W u8)
-                        because neither box has a video decoder, and keypoints come from a provider
-                        (dense grid by default; the BRISK detector is SURVEY.md 8(f) row 1, not built yet)
+                        because neither box has a video decoder; keypoints come from the BRISK detector on the
+                        difference image like the reference's (keypoint_provider="brisk", MoFREAKUtilities.cpp:420-423)
+                        or from a provider callback (dense grid by default, the benchmark configuration)
   compute_mofreak_files computeMoFREAKFiles() (src/MoFREAK/main.cpp:854-924): walk a directory of videos, one
                         .mofreak file each -- sharded one-video-per-GPU across ranks (no data-path collective)
   gather_rows           the only exchange step: variable-length gather of 32-byte rows to rank 0
@@ -50,7 +51,10 @@ class MoFREAKUtilities:
     NUMBER_OF_BYTES_FOR_APPEARANCE = 8  # MoFREAKUtilities.h:72
     NUMBER_OF_BYTES_FOR_MOTION = 8      # MoFREAKUtilities.h:73
 
-    def __init__(self, dset: int, device: int = 0, keypoint_provider: KeypointProvider | None = None, **params):
+    BRISK_THRESHOLD = 30  # cv::BriskFeatureDetector(30) (MoFREAKUtilities.cpp:420-421)
+    BRISK_OCTAVES = 3     # its default (brisk.h:293)
+
+    def __init__(self, dset: int, device: int = 0, keypoint_provider: KeypointProvider | str | None = None, **params):
         self.dataset = dset
         self.current_action = 0
         self.actions: dict[str, int] = {}
@@ -99,7 +103,11 @@ class MoFREAKUtilities:
         T, H, W = frames.shape
         gap = self._ctx.params.gap_for_frame_difference
         prov = self.keypoint_provider
-        if getattr(prov, "shared", False):
+        if isinstance(prov, str):
+            if prov != "brisk":
+                raise ValueError(f"unknown keypoint source {prov!r}")
+            rows = self._ctx.compute_stream_host(frames, self.BRISK_THRESHOLD, self.BRISK_OCTAVES)
+        elif getattr(prov, "shared", False):
             rows = self._ctx.extract_stream_host(frames, prov(gap, W, H))
         else:
             lists = [np.ascontiguousarray(prov(frame_offset + t, W, H), np.float32).reshape(-1, 3) for t in range(gap, T)]

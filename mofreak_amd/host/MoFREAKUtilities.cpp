@@ -98,7 +98,8 @@ void check(mofreak_ctx *ctx, int rc, const char *what)
 }  // namespace
 
 MoFREAKUtilities::MoFREAKUtilities(int dset)
-    : current_action(0), dataset(dset), device_(0), ctx_(nullptr), provider_shared_(true)
+    : current_action(0), dataset(dset), device_(0), ctx_(nullptr), provider_shared_(true), use_brisk_(false), brisk_threshold_(30),
+      brisk_octaves_(3)
 {
     mofreak_default_params(&params_);
     setDenseGrid(16, 12.0f, 38);
@@ -129,6 +130,14 @@ void MoFREAKUtilities::setDenseGrid(int step, float size, int lo)
         return k;
     };
     provider_shared_ = true;
+    use_brisk_ = false;
+}
+
+void MoFREAKUtilities::useBriskDetector(int threshold, int octaves)
+{
+    use_brisk_ = true;
+    brisk_threshold_ = threshold;
+    brisk_octaves_ = octaves;
 }
 
 mofreak_ctx *MoFREAKUtilities::context()
@@ -171,6 +180,24 @@ void MoFREAKUtilities::computeMoFREAKFromFrames(const uint8_t *frames, int T, in
     const int n_pairs = T - gap;
     if (n_pairs <= 0) return;
     mofreak_ctx *ctx = context();
+    std::vector<mofreak_row> rows;
+    int64_t n_rows = 0;
+    if (use_brisk_) {  // detector + descriptors in one call; room for the rows is grown until they fit
+        int64_t capacity = (int64_t)n_pairs * 8192;
+        for (;;) {
+            rows.resize((size_t)capacity);
+            const int rc = mofreak_compute_stream(ctx, frames, T, W, H, brisk_threshold_, brisk_octaves_, rows.data(), capacity, &n_rows,
+                                                  nullptr, MOFREAK_MEM_HOST);
+            if (rc == MOFREAK_ERR_CAPACITY && n_rows > capacity) {
+                capacity = n_rows;
+                continue;
+            }
+            check(ctx, rc, "mofreak_compute_stream");
+            break;
+        }
+        appendRows(rows.data(), n_rows, video_filename);
+        return;
+    }
 
     // keypoints of every processed frame (frame index gap .. T-1), detector order
     std::vector<mofreak_keypoint> kps;
@@ -187,17 +214,20 @@ void MoFREAKUtilities::computeMoFREAKFromFrames(const uint8_t *frames, int T, in
     }
     const int64_t capacity = provider_shared_ ? (int64_t)n_pairs * (int64_t)kps.size() : (int64_t)kps.size();
     if (capacity == 0) return;
-    std::vector<mofreak_row> rows((size_t)capacity);
-    int64_t n_rows = 0;
+    rows.resize((size_t)capacity);
     check(ctx,
           mofreak_extract_stream(ctx, frames, T, W, H, kps.data(), provider_shared_ ? nullptr : offsets.data(),
                                  (int64_t)kps.size(), rows.data(), capacity, &n_rows, MOFREAK_MEM_HOST),
           "mofreak_extract_stream");
+    appendRows(rows.data(), n_rows, video_filename);
+}
 
+void MoFREAKUtilities::appendRows(const mofreak_row *rows, int64_t n_rows, const std::string &video_filename)
+{
     int action = 0, person = 0, video_number = 0;
     readMetadata(video_filename, action, video_number, person);  // the reference re-parses this per keypoint (:469)
     for (int64_t i = 0; i < n_rows; ++i) {
-        const mofreak_row &r = rows[(size_t)i];
+        const mofreak_row &r = rows[i];
         MoFREAKFeature ftr(NUMBER_OF_BYTES_FOR_MOTION, NUMBER_OF_BYTES_FOR_APPEARANCE);
         ftr.frame_number = r.frame_number;
         ftr.scale = r.scale;

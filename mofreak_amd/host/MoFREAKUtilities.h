@@ -6,8 +6,9 @@
 // Differences, all forced by the environment:
 //   * "video files" are raw gray frame stacks (NumPy .npy, uint8, shape (T, H, W)): there is no video decoder
 //     on either box (the reference uses cv::VideoCapture + BGR2GRAY, MoFREAKUtilities.cpp:380-410);
-//   * keypoints come from a KeypointProvider (dense grid by default); the reference runs its vendored BRISK
-//     detector on the difference image (:420-423), which is SURVEY.md 8(f) row 1 and not part of this path;
+//   * keypoints: useBriskDetector() runs the reference's detector, BriskFeatureDetector(30) on the difference image
+//     (:420-423), on the GPU (mofreak_compute_stream); the default is a KeypointProvider with a dense grid, the
+//     configuration the benchmark is quoted on;
 //   * the dead MoSIFT code path (buildMoFREAKFeaturesFromMoSIFT, :598-663, never called) is not provided.
 #ifndef MOFREAK_HOST_MOFREAKUTILITIES_H
 #define MOFREAK_HOST_MOFREAKUTILITIES_H
@@ -85,6 +86,7 @@ public:
     typedef std::function<std::vector<mofreak_keypoint>(int, int, int)> KeypointProvider;
     void setKeypointProvider(KeypointProvider provider, bool same_for_every_frame);
     void setDenseGrid(int step, float size, int lo);  // x = step*i, y = step*j, lo < x < W-lo, lo < y < H-lo
+    void useBriskDetector(int threshold = 30, int octaves = 3);  // cv::BriskFeatureDetector(30) (:420-421), brisk.h:293
     void setDevice(int device_id);                    // before the first computation; default 0
     void setParams(const mofreak_params &p);          // before the first computation
     // The frame loop of computeMoFREAKFromFile on frames already in memory (T x H x W gray).
@@ -92,6 +94,7 @@ public:
 
 private:
     void readMetadata(const std::string &filename, int &action, int &video_number, int &person);
+    void appendRows(const mofreak_row *rows, int64_t n_rows, const std::string &video_filename);
     mofreak_ctx *context();
 
     std::deque<MoFREAKFeature> features;
@@ -101,6 +104,8 @@ private:
     mofreak_ctx *ctx_;
     KeypointProvider provider_;
     bool provider_shared_;
+    bool use_brisk_;
+    int brisk_threshold_, brisk_octaves_;
 };
 
 #endif

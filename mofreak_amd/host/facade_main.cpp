@@ -1,5 +1,5 @@
 // Small driver over the C++ MoFREAKUtilities facade, used by tests/test_facade.py and as a usage example:
-//   facade_main extract <video.npy> <out.mofreak> [grid_step grid_size grid_lo]   (needs a GPU)
+//   facade_main extract <video.npy> <out.mofreak> [grid_step grid_size grid_lo | brisk]   (needs a GPU)
 //   facade_main files <video_dir> <mofreak_dir>      computeMoFREAKFiles() of main.cpp:854-924 for *.npy (needs a GPU)
 //   facade_main roundtrip <in.mofreak> <out.mofreak>  read (reversed, as the reference) + write (no GPU)
 #include <dirent.h>
@@ -45,6 +45,7 @@ int main(int argc, char **argv)
         if (mode == "extract" && argc >= 4) {
             MoFREAKUtilities mofreak(MoFREAKUtilities::KTH);
             if (argc >= 7) mofreak.setDenseGrid(std::atoi(argv[4]), (float)std::atof(argv[5]), std::atoi(argv[6]));
+            if (argc == 5 && std::string(argv[4]) == "brisk") mofreak.useBriskDetector();  // the reference's own keypoint source
             mofreak.computeMoFREAKFromFile(argv[2], argv[3], false);
             std::cout << mofreak.getMoFREAKFeatures().size() << " features" << std::endl;
             return 0;

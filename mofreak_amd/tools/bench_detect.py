@@ -5,7 +5,6 @@ import argparse
 import json
 import os
 import sys
-import time
 
 import numpy as np
 import torch
@@ -21,7 +20,6 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--cpu-pairs", type=int, default=0, help="time the CPU oracle on this many pairs (0: skip)")
     a = ap.parse_args()
     W, H = a.width, a.height
     distinct = 4
@@ -57,13 +55,6 @@ def main():
            "detect_pixels_per_s": a.pairs * W * H / det_ms * 1e3,
            "detect_and_describe_ms_per_call": both_ms, "frames_per_s_detect_and_describe": a.pairs / both_ms * 1e3,
            "valid_descriptors_per_pair": float(valid[:n].sum().item()) / a.pairs}
-    if a.cpu_pairs:
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
-        import oracle_lib as O
-        t0 = time.perf_counter()
-        for p in range(a.cpu_pairs):
-            O.brisk_detect(O.absdiff(cur[p], prev[p]))
-        out["cpu_oracle_pairs_per_s_1_core"] = a.cpu_pairs / (time.perf_counter() - t0)
     print(json.dumps(out))
     ctx.set_stream(None)
     ctx.close()

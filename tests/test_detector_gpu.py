@@ -148,3 +148,29 @@ def test_empty_and_flat_inputs(ctx):
     tiny = np.random.default_rng(0).integers(0, 256, (1, 20, 24), dtype=np.uint8)
     kps, offs, resp, layer = ctx.detect_pairs_host(tiny, None)
     _assert_same_keypoints((kps, resp, layer), _oracle_keypoints(tiny[0]), "tiny")
+
+
+def test_compute_stream_is_the_whole_frame_loop(ctx, oracle, tmp_path):
+    """mofreak_compute_stream == detector + descriptors + compaction: the rows of the .mofreak file the reference
+    would write for the clip, through the C ABI, the Python mirror and the C++ facade."""
+    import os
+    import subprocess
+    from mofreak_amd import harness
+    fr = synth.moving_objects_stack(12, 320, 240, seed=5)
+    T = len(fr)
+    lists = [_oracle_keypoints(O.absdiff(fr[t], fr[t - 5]))[0] for t in range(5, T)]
+    offs = np.concatenate([[0], np.cumsum([len(k) for k in lists])]).astype(np.int64)
+    want = oracle.Freak().extract_stream(fr, np.concatenate(lists), offs)
+    rows = ctx.compute_stream_host(fr)
+    assert rows.tobytes() == want.tobytes() and len(rows) > 100
+    assert len(ctx.compute_stream_host(fr[:5])) == 0 and len(ctx.compute_stream_host(fr, capacity=16)) == len(rows)
+    mf = harness.MoFREAKUtilities(harness.KTH, device=0, keypoint_provider="brisk")
+    assert mf.extract_rows(fr).tobytes() == want.tobytes()
+    assert mf.extract_rows(fr, chunk_frames=8).tobytes() == want.tobytes()
+    mf.close()
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mofreak_amd", "host")
+    subprocess.check_call(["make", "-C", host, "-s"])
+    vid, out = tmp_path / "person01_walking_d1.npy", tmp_path / "clip.mofreak"
+    np.save(vid, fr)
+    subprocess.check_call([os.path.join(host, "facade_main"), "extract", str(vid), str(out), "brisk"])
+    assert out.read_bytes() == oracle.format_rows(want)
