@@ -121,17 +121,22 @@ def moving_objects_stack(T: int, W: int, H: int, n_objects: int | None = None, s
     vx, vy = rng.uniform(-3, 3, n_objects), rng.uniform(-3, 3, n_objects)
     gray = rng.integers(0, 256, n_objects)
     base = synth_stack(T, W, H)
-    yy, xx = np.mgrid[0:H, 0:W]
     out = np.empty((T, H, W), np.uint8)
     for t in range(T):
         f = base[t].copy()
         for k in range(n_objects):
             x0, y0 = cx[k] + vx[k] * t, cy[k] + vy[k] * t
             x0, y0 = x0 % W, y0 % H
+            # only the object's bounding box is touched (clipped at the frame border)
+            xa, xb = max(int(np.floor(x0 - sx[k] / 2)), 0), min(int(np.ceil(x0 + sx[k] / 2)) + 1, W)
+            ya, yb = max(int(np.floor(y0 - sy[k] / 2)), 0), min(int(np.ceil(y0 + sy[k] / 2)) + 1, H)
+            if xa >= xb or ya >= yb:
+                continue
+            yy, xx = np.mgrid[ya:yb, xa:xb]
             if kind[k] == 0:
                 m = (np.abs(xx - x0) <= sx[k] / 2) & (np.abs(yy - y0) <= sy[k] / 2)
             else:
                 m = ((xx - x0) / (sx[k] / 2)) ** 2 + ((yy - y0) / (sy[k] / 2)) ** 2 <= 1.0
-            f[m] = gray[k]
+            f[ya:yb, xa:xb][m] = gray[k]
         out[t] = f
     return out
