@@ -174,3 +174,23 @@ def test_compute_stream_is_the_whole_frame_loop(ctx, oracle, tmp_path):
     np.save(vid, fr)
     subprocess.check_call([os.path.join(host, "facade_main"), "extract", str(vid), str(out), "brisk"])
     assert out.read_bytes() == oracle.format_rows(want)
+
+
+def test_many_pairs_in_several_batches(ctx):
+    """The detector works through a call in batches sized from its workspace; a large candidate reservation forces one
+    pair per batch here, and the CSR offsets / running totals have to carry across batches."""
+    fr = synth.moving_objects_stack(10, 240, 176, seed=21)
+    cur, prev = fr[5:], fr[:5]
+    one = ctx.detect_pairs_host(cur, prev)
+    ctx.set_detect_capacity(1 << 24)
+    try:
+        many = ctx.detect_pairs_host(cur, prev)
+    finally:
+        ctx.set_detect_capacity(131072)
+    for a, b in zip(one, many):
+        assert a.tobytes() == b.tobytes()
+    assert len(one[1]) == 6 and np.all(np.diff(one[1]) > 0)
+    for p in range(5):
+        want = _oracle_keypoints(O.absdiff(cur[p], prev[p]))
+        s = slice(one[1][p], one[1][p + 1])
+        _assert_same_keypoints((one[0][s], one[2][s], one[3][s]), want, f"pair {p}")
