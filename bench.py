@@ -58,6 +58,43 @@ def cpu_baseline(frames, kps, n_pairs, cores):
                       f"(gcc -O2, strict FP), {cores} threads over pairs, {dt:.1f} s wall"}
 
 
+def detector_figures(ctx, torch, synth, W, H, pairs=32, steps=3, with_cpu=True):
+    """BRISK keypoints on |cur - prev| of moving-object frames, and detector + descriptors back to back, per frame pair."""
+    distinct = 4
+    fr = synth.moving_objects_stack(5 + distinct, W, H)
+    cur = torch.from_numpy(np.stack([fr[5 + (p % distinct)] for p in range(pairs)])).cuda()
+    prev = torch.from_numpy(np.stack([fr[p % distinct] for p in range(pairs)])).cuda()
+    cap = 32768 * pairs
+    kps = torch.empty((cap, 3), dtype=torch.float32, device="cuda")
+    offs = torch.empty(pairs + 1, dtype=torch.int64, device="cuda")
+    desc = torch.empty((cap, 16), dtype=torch.uint8, device="cuda")
+    valid = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    n = ctx.detect_pairs(cur, prev, W, H, pairs, kps, offs, capacity=cap)
+    ctx.extract_pairs(cur, prev, W, H, pairs, kps, desc, valid, kp_offsets=offs, n_kp=n)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        n = ctx.detect_pairs(cur, prev, W, H, pairs, kps, offs, capacity=cap)  # synchronises
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        n = ctx.detect_pairs(cur, prev, W, H, pairs, kps, offs, capacity=cap)
+        ctx.extract_pairs(cur, prev, W, H, pairs, kps, desc, valid, kp_offsets=offs, n_kp=n)
+    ctx.synchronize()
+    t2 = time.perf_counter()
+    out = {"workload": f"{W}x{H} moving-object frame pairs, BriskFeatureDetector(30, 3 octaves) on |cur - prev|, {pairs} pairs/call",
+           "keypoints_per_pair": n / pairs, "pairs_per_s": pairs * steps / (t1 - t0),
+           "detect_and_describe_pairs_per_s": pairs * steps / (t2 - t1)}
+    if with_cpu:  # part of the cpu_baseline leg: the oracle as a reported baseline, never as the product
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        a, b = fr[5], fr[0]
+        t0 = time.perf_counter()
+        k = oracle_lib.brisk_detect(oracle_lib.absdiff(a, b))
+        out["cpu_baseline"] = {"value": 1.0 / (time.perf_counter() - t0), "unit": "pairs/s", "cores": 1, "kind": "port",
+                               "sample": f"1 of the pairs, oracle/brisk_oracle.c, {len(k)} keypoints"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,6 +107,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL); 'gloo' + "
                     "--share-device rehearses the N > 1 control flow on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
+    ap.add_argument("--no-detector", action="store_true", help="skip the (untimed-region) keypoint detector figures")
     args = ap.parse_args()
 
     import torch
@@ -189,6 +227,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cp = min(args.cpu_pairs, n_pairs)
             out["cpu_baseline"] = cpu_baseline(frames, kps, cp, cores=min(ncpu, 16))
+        if world == 1 and not args.no_detector:
+            # Outside the metric and its timed region: the row in front of the path, for the record.
+            try:
+                out["detector"] = detector_figures(ctx, torch, synth, W, H, with_cpu=not args.no_cpu_baseline)
+            except Exception as e:  # never let the side figure take the metric line down
+                out["detector"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     ctx.set_stream(None)
     ctx.close()
