@@ -194,3 +194,34 @@ def test_many_pairs_in_several_batches(ctx):
         want = _oracle_keypoints(O.absdiff(cur[p], prev[p]))
         s = slice(one[1][p], one[1][p + 1])
         _assert_same_keypoints((one[0][s], one[2][s], one[3][s]), want, f"pair {p}")
+
+
+def test_device_buffers_strides_and_thresholds(ctx):
+    """Device-resident frames with padded rows and a pair stride that skips frames; other thresholds than the reference's 30."""
+    import torch
+    W, H, n = 200, 150, 3
+    fr = synth.moving_objects_stack(5 + 2 * n, W, H, seed=31)
+    stride, fstride = 224, 224 * 160  # padded rows, padded frames
+    buf = torch.zeros((5 + 2 * n, 160, stride), dtype=torch.uint8)
+    buf[:, :H, :W] = torch.from_numpy(fr)
+    d = buf.cuda()
+    cap = 1 << 16
+    kps = torch.zeros((cap, 3), dtype=torch.float32, device="cuda")
+    offs = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    resp = torch.zeros(cap, dtype=torch.float32, device="cuda")
+    layer = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    for thr in (30, 12, 70):
+        torch.cuda.synchronize()
+        # pairs (5, 0), (7, 2), (9, 4): every other frame
+        total = ctx.detect_pairs(d[5:], d, W, H, n, kps, offs, threshold=thr, octaves=3, out_response=resp, out_layer=layer,
+                                 capacity=cap, row_stride=stride, pair_stride=2 * fstride)
+        o = offs.cpu().numpy()
+        assert o[-1] == total
+        for p in range(n):
+            want = _oracle_keypoints(O.absdiff(fr[5 + 2 * p], fr[2 * p]), thr, 3)
+            s = slice(o[p], o[p + 1])
+            _assert_same_keypoints((kps[s].cpu().numpy(), resp[s].cpu().numpy(), layer[s].cpu().numpy()), want, f"thr {thr} pair {p}")
+    with pytest.raises(M.MoFREAKError):
+        ctx.detect_pairs(d[5:], d, W, H, n, kps, offs, threshold=0, capacity=cap, row_stride=stride, pair_stride=fstride)
+    with pytest.raises(M.MoFREAKError):
+        ctx.detect_pairs(d[5:], d, W, H, n, kps, offs, octaves=5, capacity=cap, row_stride=stride, pair_stride=fstride)
