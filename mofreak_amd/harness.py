@@ -219,3 +219,64 @@ def compute_mofreak_files(video_paths: Sequence[str], out_dir: str, mofreak: MoF
         mofreak.computeMoFREAKFromFile(video_paths[i], out, True)
         written.append(out)
     return written
+
+
+# ------------------------------------------------------------------ .mofreak file utilities
+CHOP_LINES = 40000  # src/merge_mofreak_files.py:96
+
+
+def chop_mofreak_file(path: str, out_dir: str, lines_per_file: int = CHOP_LINES) -> list[str]:
+    """chop() of the reference's merge_mofreak_files.py:89-112 for one file: a .mofreak file with more than
+    `lines_per_file` rows is cut into `<stem>.<k>.mofreak` pieces, k = 0, 1, ...; shorter files are left alone."""
+    with open(path, "rb") as f:
+        lines = f.read().splitlines(keepends=True)
+    if len(lines) <= lines_per_file:
+        return []
+    os.makedirs(out_dir, exist_ok=True)
+    stem = ".".join(os.path.basename(path).split(".")[:-1])
+    out = []
+    for k, i in enumerate(range(0, len(lines), lines_per_file)):
+        name = os.path.join(out_dir, f"{stem}.{k}.mofreak")
+        with open(name, "wb") as f:
+            f.writelines(lines[i:i + lines_per_file])
+        out.append(name)
+    return out
+
+
+def merge_mofreak_files(in_dir: str, out_dir: str, action: str = "TestSequence", first_id: int = 1) -> list[str]:
+    """merge() of merge_mofreak_files.py:115-160: files `<group>.<...>.<id>.mofreak` are concatenated per group in id
+    order, starting at id `first_id` (the script starts at 1) and stopping at the first missing id, into
+    `<group>.mpeg.<action>.mofreak`."""
+    groups: dict[str, list[list[str]]] = {}
+    for name in sorted(os.listdir(in_dir)):
+        if not os.path.isfile(os.path.join(in_dir, name)):
+            continue
+        parts = name.split(".")
+        groups.setdefault(parts[0], []).append(parts)
+    os.makedirs(out_dir, exist_ok=True)
+    written = []
+    for group, files in groups.items():
+        out_name = os.path.join(out_dir, f"{group}.mpeg.{action}.mofreak")
+        with open(out_name, "wb") as out:
+            file_id = first_id
+            while True:
+                hit = next((p for p in files if len(p) >= 2 and p[-2].isdigit() and int(p[-2]) == file_id), None)
+                if hit is None:
+                    break
+                with open(os.path.join(in_dir, ".".join(hit)), "rb") as f:
+                    out.write(f.read())
+                file_id += 1
+        written.append(out_name)
+    return written
+
+
+def write_rows_binary(path: str, rows: np.ndarray) -> None:
+    """Binary sidecar of a .mofreak file: the 32-byte rows as they leave the device (api.ROW_DTYPE), no text round trip."""
+    np.save(path, np.ascontiguousarray(rows, api.ROW_DTYPE), allow_pickle=False)
+
+
+def read_rows_binary(path: str) -> np.ndarray:
+    rows = np.load(path, allow_pickle=False)
+    if rows.dtype != api.ROW_DTYPE:
+        raise ValueError(f"{path}: not a MoFREAK row file")
+    return rows

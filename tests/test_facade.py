@@ -156,3 +156,24 @@ def test_long_stream_in_chunks_equals_one_pass(native_lib, oracle):
     want = oracle.Freak().extract_stream(fr, np.concatenate(lists), offs)
     assert whole.tobytes() == want.tobytes() and len(whole) > 200
     mf.close()
+
+
+def test_chop_merge_and_binary_sidecar(native_lib, tmp_path):
+    """The reference's file utilities (src/merge_mofreak_files.py): 40k-line chunks numbered from 0; merge in id order from 1."""
+    rows = _random_rows(25, 3)
+    text = M.format_rows(rows)
+    src = tmp_path / "LGW_20071101_E1_CAM1.mpeg.mofreak"
+    src.write_bytes(text)
+    assert harness.chop_mofreak_file(str(src), str(tmp_path / "chop")) == []  # short files are left alone
+    pieces = harness.chop_mofreak_file(str(src), str(tmp_path / "chop"), lines_per_file=10)
+    assert [os.path.basename(p) for p in pieces] == [f"LGW_20071101_E1_CAM1.mpeg.{k}.mofreak" for k in range(3)]
+    assert b"".join(open(p, "rb").read() for p in pieces) == text
+    merged = harness.merge_mofreak_files(str(tmp_path / "chop"), str(tmp_path / "merged"))
+    assert [os.path.basename(m) for m in merged] == ["LGW_20071101_E1_CAM1.mpeg.TestSequence.mofreak"]
+    lines = text.splitlines(keepends=True)
+    assert open(merged[0], "rb").read() == b"".join(lines[10:])  # ids 1 and 2: the script's merge starts at 1, piece 0 is skipped
+    assert open(harness.merge_mofreak_files(str(tmp_path / "chop"), str(tmp_path / "m0"), first_id=0)[0], "rb").read() == text
+    side = tmp_path / "rows.npy"
+    harness.write_rows_binary(str(side), rows)
+    assert harness.read_rows_binary(str(side)).tobytes() == rows.tobytes()
+    assert M.parse_rows(text).tobytes() == rows.tobytes()
