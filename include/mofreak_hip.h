@@ -213,6 +213,26 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
 int mofreak_compute_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W, int H, int threshold, int octaves,
                            mofreak_row *rows_out, int64_t rows_capacity, int64_t *n_rows_out, int64_t *n_keypoints_out,
                            unsigned flags);
+/* ------------------------------------------------------------------ frame at a time */
+/*
+ * The reference's loop as it is written: `capture >> current_frame` one frame at a time against a queue of the last
+ * gap frames (MoFREAKUtilities.cpp:391-401, 402-411, 485-488).  The ring of gap + 1 gray frames lives on the device;
+ * a pushed frame is converted (channels == 3: interleaved BGR, cv::cvtColor(BGR2GRAY) :395,410) or copied
+ * (channels == 1) into it, and from the (gap + 1)-th frame on its rows come back: keypoints from the BRISK detector
+ * on |frame - frame[-gap]| (use_detector != 0, :420-423) or from the caller (kps, n_kp; ignored with the detector),
+ * described against the frame gap pushes ago, labelled gap - 1, gap, ... (:401, :488).  For throughput use
+ * mofreak_compute_stream / mofreak_extract_stream on whole stacks; this interface is for callers that decode as
+ * they go.  frame / kps / rows_out are host or device pointers according to flags; *n_rows_out is a host integer.
+ */
+typedef struct mofreak_stream mofreak_stream;
+int mofreak_stream_open(mofreak_ctx *ctx, int W, int H, int use_detector, int threshold, int octaves,
+                        mofreak_stream **out);
+int mofreak_stream_push(mofreak_stream *s, const uint8_t *frame, int channels, int64_t row_stride,
+                        const mofreak_keypoint *kps, int64_t n_kp, mofreak_row *rows_out, int64_t rows_capacity,
+                        int64_t *n_rows_out, unsigned flags);
+int64_t mofreak_stream_frames(const mofreak_stream *s); /* frames pushed so far */
+void mofreak_stream_close(mofreak_stream *s);
+
 /* Candidates per pair the detector reserves room for (default 131072); more corners than that in one pair's pyramid
  * make mofreak_detect_pairs return MOFREAK_ERR_CAPACITY. */
 int mofreak_detect_set_capacity(mofreak_ctx *ctx, int candidates_per_pair);

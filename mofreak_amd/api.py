@@ -36,7 +36,7 @@ EXPORTS = [
     "mofreak_parse_rows", "mofreak_diff_integral", "mofreak_mip19", "mofreak_roi19", "mofreak_freak_info",
     "mofreak_theta_index", "mofreak_pattern_sizes", "mofreak_scale_index", "mofreak_table_pattern",
     "mofreak_table_orientation", "mofreak_table_bit_pairs", "mofreak_table_resize",
-    "mofreak_detect_pairs", "mofreak_detect_set_capacity", "mofreak_brisk_pyramid", "mofreak_compute_stream",
+    "mofreak_detect_pairs", "mofreak_detect_set_capacity", "mofreak_brisk_pyramid", "mofreak_compute_stream", "mofreak_stream_open", "mofreak_stream_push", "mofreak_stream_frames", "mofreak_stream_close",
 ]
 
 
@@ -100,6 +100,12 @@ def load() -> C.CDLL:
     L.mofreak_extract_pairs.argtypes = [vp, vp, vp, i32, i32, i64, i64, i32, vp, vp, i64, vp, vp, C.c_uint]
     L.mofreak_detect_pairs.argtypes = [vp, vp, vp, i32, i32, i64, i64, i32, i32, i32, vp, i64, vp, vp, vp, C.POINTER(i64), C.c_uint]
     L.mofreak_detect_set_capacity.argtypes = [vp, i32]
+    L.mofreak_stream_open.argtypes = [vp, i32, i32, i32, i32, i32, C.POINTER(vp)]
+    L.mofreak_stream_push.argtypes = [vp, vp, i32, i64, vp, i64, vp, i64, C.POINTER(i64), C.c_uint]
+    L.mofreak_stream_frames.argtypes = [vp]
+    L.mofreak_stream_frames.restype = i64
+    L.mofreak_stream_close.argtypes = [vp]
+    L.mofreak_stream_close.restype = None
     L.mofreak_compute_stream.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, i64, C.POINTER(i64), C.POINTER(i64), C.c_uint]
     L.mofreak_brisk_pyramid.argtypes = [vp, vp, i32, i32, i64, i32, vp, vp, vp, vp, C.POINTER(C.c_int), C.c_uint]
     L.mofreak_compact_rows.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, i64, C.POINTER(i64), C.c_uint]
@@ -306,6 +312,10 @@ class Context:
                 if e.code != ERR_CAPACITY or capacity > (1 << 28):
                     raise
                 capacity *= 4
+
+    def open_stream(self, W: int, H: int, use_detector: bool = True, threshold: int = 30, octaves: int = 3) -> "FrameStream":
+        """Frame-at-a-time interface over a device ring of gap + 1 frames (mofreak_stream_*)."""
+        return FrameStream(self, W, H, use_detector, threshold, octaves)
 
     def set_detect_capacity(self, candidates_per_pair: int):
         self._check(self._lib.mofreak_detect_set_capacity(self._h, candidates_per_pair))
@@ -531,3 +541,40 @@ def parse_rows(text: bytes) -> np.ndarray:
     if rc != OK:
         raise MoFREAKError(rc, "parse_rows")
     return rows[:n.value].copy()
+
+
+class FrameStream:
+    """capture >> frame, one frame at a time (MoFREAKUtilities.cpp:402-411): push() returns that frame's rows."""
+
+    def __init__(self, ctx: "Context", W, H, use_detector, threshold, octaves):
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        ctx._check(ctx._lib.mofreak_stream_open(ctx._h, W, H, int(use_detector), threshold, octaves, C.byref(self._h)))
+        self.W, self.H = W, H
+
+    def push(self, frame: np.ndarray, kps: np.ndarray | None = None, capacity: int = 1 << 16) -> np.ndarray:
+        """frame: (H, W) gray or (H, W, 3) BGR uint8 host array; kps: (n, 3) float32 when the stream has no detector."""
+        frame = np.ascontiguousarray(frame, np.uint8)
+        channels = 1 if frame.ndim == 2 else int(frame.shape[2])
+        k = None if kps is None else np.ascontiguousarray(kps, np.float32).reshape(-1, 3)
+        rows = np.zeros(capacity, ROW_DTYPE)
+        n = C.c_int64(0)
+        # a frame is consumed even when its rows do not fit: size `capacity` for the densest frame expected
+        self._ctx._check(self._ctx._lib.mofreak_stream_push(self._h, _ptr(frame), channels, channels * self.W, _ptr(k),
+                                                            0 if k is None else len(k), _ptr(rows), capacity, C.byref(n), MEM_HOST))
+        return rows[:n.value].copy()
+
+    @property
+    def frames(self) -> int:
+        return int(self._ctx._lib.mofreak_stream_frames(self._h))
+
+    def close(self):
+        if self._h:
+            self._ctx._lib.mofreak_stream_close(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

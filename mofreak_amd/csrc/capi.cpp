@@ -1403,6 +1403,139 @@ int mofreak_compute_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W
     return MOFREAK_OK;
 }
 
+struct mofreak_stream {
+    mofreak_ctx *ctx;
+    int W, H, use_detector, threshold, octaves;
+    int64_t n_seen;
+    DeviceBuffer ring, in, kps, offs, desc, valid, rows;
+};
+
+int mofreak_stream_open(mofreak_ctx *ctx, int W, int H, int use_detector, int threshold, int octaves, mofreak_stream **out)
+{
+    if (!ctx || !out) return MOFREAK_ERR_BAD_ARG;
+    *out = nullptr;
+    if (W <= 0 || H <= 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "W, H must be positive");
+    if (use_detector) {
+        DetGeom g;
+        const int rc = det_geometry(ctx, W, H, octaves, g);
+        if (rc) return rc;
+        if (threshold < 1 || threshold > 255) return fail(ctx, MOFREAK_ERR_BAD_ARG, "threshold must be in 1..255");
+    }
+    NEED_DEVICE(ctx);
+    mofreak_stream *s = new (std::nothrow) mofreak_stream();
+    if (!s) return fail(ctx, MOFREAK_ERR_OOM, "out of host memory");
+    s->ctx = ctx;
+    s->W = W;
+    s->H = H;
+    s->use_detector = use_detector;
+    s->threshold = threshold;
+    s->octaves = octaves;
+    s->n_seen = 0;
+    const int rc = ensure(ctx, s->ring, (size_t)(ctx->params.gap_for_frame_difference + 1) * W * H);
+    if (rc) {
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return MOFREAK_OK;
+}
+
+int64_t mofreak_stream_frames(const mofreak_stream *s) { return s ? s->n_seen : 0; }
+
+void mofreak_stream_close(mofreak_stream *s)
+{
+    if (!s) return;
+    if (s->ctx && s->ctx->device >= 0) {
+        (void)hipSetDevice(s->ctx->device);
+        if (s->ctx->stream) (void)hipStreamSynchronize(s->ctx->stream);
+    }
+    for (DeviceBuffer *b : {&s->ring, &s->in, &s->kps, &s->offs, &s->desc, &s->valid, &s->rows}) release(*b);
+    delete s;
+}
+
+int mofreak_stream_push(mofreak_stream *s, const uint8_t *frame, int channels, int64_t row_stride, const mofreak_keypoint *kps, int64_t n_kp,
+                        mofreak_row *rows_out, int64_t rows_capacity, int64_t *n_rows_out, unsigned flags)
+{
+    if (!s || !s->ctx) return MOFREAK_ERR_BAD_ARG;
+    mofreak_ctx *ctx = s->ctx;
+    if (n_rows_out) *n_rows_out = 0;
+    if (!frame) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null frame");
+    if (channels != 1 && channels != 3) return fail(ctx, MOFREAK_ERR_BAD_ARG, "channels must be 1 (gray) or 3 (BGR)");
+    if (row_stride < (int64_t)channels * s->W) return fail(ctx, MOFREAK_ERR_BAD_ARG, "row_stride too small");
+    if (rows_capacity < 0 || n_kp < 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "negative count");
+    NEED_DEVICE(ctx);
+    const bool host = (flags & MOFREAK_MEM_HOST) != 0;
+    const int W = s->W, H = s->H, gap = ctx->params.gap_for_frame_difference, slots = gap + 1;
+    const int64_t fsz = (int64_t)W * H;
+    uint8_t *ring = static_cast<uint8_t *>(s->ring.ptr);
+    uint8_t *slot = ring + (s->n_seen % slots) * fsz;
+    int rc;
+    // the frame into its ring slot, gray
+    if (channels == 1) {
+        HIP_TRY(ctx, hipMemcpy2DAsync(slot, (size_t)W, frame, (size_t)row_stride, (size_t)W, (size_t)H,
+                                      host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        const uint8_t *d_in = frame;
+        if (host) {
+            const size_t span = (size_t)((int64_t)(H - 1) * row_stride + (int64_t)3 * W);
+            if ((rc = upload(ctx, s->in, frame, span))) return rc;
+            d_in = static_cast<const uint8_t *>(s->in.ptr);
+        }
+        if ((rc = mofreak_bgr_to_gray(ctx, d_in, W, H, row_stride, 0, 1, slot, MOFREAK_MEM_DEVICE))) return rc;
+    }
+    const int64_t index = s->n_seen++;
+    if (index < gap) {  // the first gap frames only fill the queue (:391-399)
+        if (host) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the caller may reuse its frame buffer
+        return MOFREAK_OK;
+    }
+    const uint8_t *cur = slot, *prev = ring + ((index - gap) % slots) * fsz;
+    const mofreak_keypoint *d_kps = kps;
+    if (s->use_detector) {
+        if ((rc = ensure(ctx, s->offs, 2 * sizeof(int64_t)))) return rc;
+        for (int attempt = 0;; ++attempt) {
+            const int64_t cap = std::max<int64_t>((int64_t)(s->kps.bytes / sizeof(mofreak_keypoint)), 16384);
+            if ((rc = ensure(ctx, s->kps, (size_t)cap * sizeof(mofreak_keypoint)))) return rc;
+            rc = mofreak_detect_pairs(ctx, cur, prev, W, H, W, fsz, 1, s->threshold, s->octaves, static_cast<mofreak_keypoint *>(s->kps.ptr), cap,
+                                      static_cast<int64_t *>(s->offs.ptr), nullptr, nullptr, &n_kp, MOFREAK_MEM_DEVICE);
+            if (rc == MOFREAK_ERR_CAPACITY && n_kp > cap && attempt == 0) {
+                if ((rc = ensure(ctx, s->kps, (size_t)(n_kp + n_kp / 8) * sizeof(mofreak_keypoint)))) return rc;
+                continue;
+            }
+            if (rc) return rc;
+            break;
+        }
+        d_kps = static_cast<const mofreak_keypoint *>(s->kps.ptr);
+    } else if (n_kp > 0) {
+        if (!kps) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null keypoint pointer");
+        if (host) {
+            if ((rc = upload(ctx, s->kps, kps, (size_t)n_kp * sizeof(mofreak_keypoint)))) return rc;
+            d_kps = static_cast<const mofreak_keypoint *>(s->kps.ptr);
+        }
+    }
+    if (n_kp == 0) {
+        if (host) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return MOFREAK_OK;
+    }
+    if ((rc = ensure(ctx, s->desc, (size_t)n_kp * 16))) return rc;
+    if ((rc = ensure(ctx, s->valid, (size_t)n_kp))) return rc;
+    if ((rc = mofreak_extract_pairs(ctx, cur, prev, W, H, W, fsz, 1, d_kps, nullptr, n_kp, static_cast<uint8_t *>(s->desc.ptr),
+                                    static_cast<uint8_t *>(s->valid.ptr), MOFREAK_MEM_DEVICE)))
+        return rc;
+    mofreak_row *d_rows = rows_out;
+    if (host) {
+        if ((rc = ensure(ctx, s->rows, (size_t)std::max<int64_t>(rows_capacity, 1) * sizeof(mofreak_row)))) return rc;
+        d_rows = static_cast<mofreak_row *>(s->rows.ptr);
+    }
+    int64_t total = 0;
+    // frame `index` carries the label index - 1: the first processed frame (index gap) is gap - 1 (:401, :488)
+    rc = mofreak_compact_rows(ctx, d_kps, nullptr, n_kp, 1, (int)(index - 1), static_cast<const uint8_t *>(s->desc.ptr),
+                              static_cast<const uint8_t *>(s->valid.ptr), d_rows, rows_capacity, &total, MOFREAK_MEM_DEVICE);
+    if (n_rows_out) *n_rows_out = total;
+    if (rc) return rc;
+    if (host && total) HIP_TRY(ctx, hipMemcpy(rows_out, d_rows, (size_t)total * sizeof(mofreak_row), hipMemcpyDeviceToHost));
+    return MOFREAK_OK;
+}
+
 int mofreak_brisk_pyramid(mofreak_ctx *ctx, const uint8_t *img, int W, int H, int64_t row_stride, int octaves, uint8_t *layers_out,
                           uint8_t *scores_out, int32_t *dims_out, float *scale_offset_out, int *n_layers_out, unsigned flags)
 {

@@ -225,3 +225,27 @@ def test_device_buffers_strides_and_thresholds(ctx):
         ctx.detect_pairs(d[5:], d, W, H, n, kps, offs, threshold=0, capacity=cap, row_stride=stride, pair_stride=fstride)
     with pytest.raises(M.MoFREAKError):
         ctx.detect_pairs(d[5:], d, W, H, n, kps, offs, octaves=5, capacity=cap, row_stride=stride, pair_stride=fstride)
+
+
+def test_frame_at_a_time_stream_equals_the_stack_calls(ctx, oracle):
+    """mofreak_stream_*: the reference's loop shape (one decoded frame per iteration against a queue of the last five).
+    Rows per pushed frame, concatenated, equal the whole-stack calls -- with the detector on gray frames, and with
+    caller keypoints on BGR frames (BGR2GRAY happens on the way into the ring)."""
+    fr = synth.moving_objects_stack(11, 256, 192, seed=41)
+    want = ctx.compute_stream_host(fr)
+    with ctx.open_stream(256, 192, use_detector=True) as st:
+        parts = [st.push(f) for f in fr]
+        assert st.frames == len(fr)
+    assert all(len(p) == 0 for p in parts[:5]) and sum(len(p) for p in parts) == len(want) > 50
+    assert np.concatenate(parts).tobytes() == want.tobytes()
+    # BGR frames, keypoints from the caller
+    rng = np.random.default_rng(3)
+    bgr = rng.integers(0, 256, (9, 120, 160, 3), dtype=np.uint8)
+    bgr[:, 30:90, 40:120] //= 4
+    gray = ctx.bgr_to_gray_host(bgr)
+    per_frame = [synth.random_keypoints(rng, 40, 160, 120, sizes=(7.0, 9.0, 12.0)) for _ in range(9)]
+    offs = np.concatenate([[0], np.cumsum([len(k) for k in per_frame[5:]])]).astype(np.int64)
+    want = oracle.Freak().extract_stream(gray, np.concatenate(per_frame[5:]), offs)
+    with ctx.open_stream(160, 120, use_detector=False) as st:
+        parts = [st.push(bgr[t], per_frame[t]) for t in range(9)]
+    assert np.concatenate(parts).tobytes() == want.tobytes() and len(want) > 20
