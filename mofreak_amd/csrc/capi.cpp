@@ -1239,11 +1239,12 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     return MOFREAK_OK;
 }
 
-// pairs per batch: about 1 GiB of planes and candidate records
+// pairs per batch: about 4 GiB of planes and candidate records (a small share of the 288 GB): the tie rounds are a
+// chain of short latency-bound launches per batch, so the more pairs share them the better
 int det_batch(const mofreak_ctx *ctx, const DetGeom &g, int n_pairs)
 {
     const size_t per_pair = 4 * (size_t)g.plane_bytes + (size_t)ctx->det_cand_cap * (sizeof(uint32_t) + 3 + 12 + sizeof(DetResult));
-    const size_t b = std::max<size_t>(1, ((size_t)1 << 30) / per_pair);
+    const size_t b = std::max<size_t>(1, ((size_t)4 << 30) / per_pair);
     return (int)std::min<size_t>({b, (size_t)std::max(n_pairs, 1), (size_t)16384});
 }
 
