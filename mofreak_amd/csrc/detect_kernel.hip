@@ -139,18 +139,28 @@ __device__ __forceinline__ int arc9_max_of_min(const int (&d)[16])
     return best;
 }
 
-constexpr int kScoreTileW = 64, kScoreTileH = 16, kScoreLdsW = 72;
+constexpr int kScoreTileW = 64, kScoreTileH = 32, kScoreLdsW = 72;  // LDS rows start at image column x0 - 4: aligned dwords
 
 __global__ __launch_bounds__(kDetThreads) void det_score_kernel(DetArgs a, int layer)
 {
-    __shared__ uint8_t tile[(kScoreTileH + 6) * kScoreLdsW];
+    __shared__ __attribute__((aligned(4))) uint8_t tile[(kScoreTileH + 6) * kScoreLdsW];
     const DetLayer L = a.dg->L[layer];
     const int p = blockIdx.z, x0 = blockIdx.x * kScoreTileW, y0 = blockIdx.y * kScoreTileH;
     const uint8_t *img = a.img + (int64_t)p * a.dg->plane_bytes + L.off;
-    for (int t = threadIdx.x; t < (kScoreTileH + 6) * (kScoreTileW + 6); t += kDetThreads) {
-        const int r = t / (kScoreTileW + 6), c = t - r * (kScoreTileW + 6);
-        const int gx = x0 - 3 + c, gy = y0 - 3 + r;
-        tile[r * kScoreLdsW + c] = (gx >= 0 && gx < L.w && gy >= 0 && gy < L.h) ? img[(int64_t)gy * L.w + gx] : 0;
+    if ((L.w & 3) == 0) {  // rows start on dword boundaries (layer planes are 64-byte aligned): 18 aligned dwords per tile row
+        for (int t = threadIdx.x; t < (kScoreTileH + 6) * (kScoreLdsW / 4); t += kDetThreads) {
+            const int r = t / (kScoreLdsW / 4), k = t - r * (kScoreLdsW / 4);
+            const int gx = x0 - 4 + 4 * k, gy = y0 - 3 + r;
+            const bool in = gx >= 0 && gx < L.w && gy >= 0 && gy < L.h;
+            const uint32_t v = in ? *reinterpret_cast<const uint32_t *>(img + (int64_t)gy * L.w + gx) : 0u;
+            *reinterpret_cast<uint32_t *>(tile + r * kScoreLdsW + 4 * k) = v;
+        }
+    } else {
+        for (int t = threadIdx.x; t < (kScoreTileH + 6) * kScoreLdsW; t += kDetThreads) {
+            const int r = t / kScoreLdsW, c = t - r * kScoreLdsW;
+            const int gx = x0 - 4 + c, gy = y0 - 3 + r;
+            tile[r * kScoreLdsW + c] = (gx >= 0 && gx < L.w && gy >= 0 && gy < L.h) ? img[(int64_t)gy * L.w + gx] : 0;
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(kDetThreads) void det_score_kernel(DetArgs a, int l
         const int ry = wave + 4 * it, x = x0 + lane, y = y0 + ry;
         int s = 0;
         if (x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3) {
-            const uint8_t *t = tile + (ry + 3) * kScoreLdsW + lane + 3;
+            const uint8_t *t = tile + (ry + 3) * kScoreLdsW + lane + 4;
             const int c = t[0];
             int d[16];
             // Bresenham circle of radius 3 in the order of OastDetector9_16::init_pattern (oast9_16.h:74-92)
@@ -291,10 +301,10 @@ __device__ __forceinline__ int score_at(const PairView &v, int layer, int x, int
 }
 
 // The part of a neighbouring layer's score map one refinement walk can reach -- at most 5 x 5 cells from the corner
-// ((int)x_1 - 1, (int)y_1 - 1) of getScoreMaxAbove/Below's sampling square, patch and tie rings included -- fetched with 36
-// independent loads into the thread's own 36 bytes of LDS.  The walk itself is a chain of data-dependent early
+// ((int)x_1 - 1, (int)y_1 - 1) of getScoreMaxAbove/Below's sampling square, patch and tie rings included -- fetched with six
+// independent 8-byte loads into the thread's own 48 bytes of LDS.  The walk itself is a chain of data-dependent early
 // exits: on global memory every step would pay a full memory latency.
-constexpr int kWinSide = 6, kWinStride = 36;  // bytes per thread (9 dwords: neighbouring threads hit different banks)
+constexpr int kWinSide = 6, kWinRow = 8, kWinStride = 52;  // 6 rows of 8 bytes per thread; 13 dwords apart: neighbouring threads hit different banks
 struct Window {
     uint8_t *cells;
     int ox, oy, layer;
@@ -305,17 +315,29 @@ struct Window {
 __device__ __forceinline__ void window_load(const PairView &v, Window &w)
 {
     const DetLayer &L = v.g->L[w.layer];
-    uint8_t tmp[kWinSide * kWinSide];
+    // which of the six columns lie inside the scored region (3-pixel border): a byte mask over one 8-byte row
+    unsigned long long colmask = 0;
 #pragma unroll
-    for (int k = 0; k < kWinSide * kWinSide; ++k) {
-        const int x = w.ox + k % kWinSide, y = w.oy + k / kWinSide;
-        const bool in = x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3;
-        const uint8_t s = v.score[L.off + (in ? (int64_t)y * L.w + x : 0)];
-        tmp[k] = in ? s : (uint8_t)0;
+    for (int k = 0; k < kWinSide; ++k) {
+        const int x = w.ox + k;
+        if (x >= 3 && x < L.w - 3) colmask |= 0xffull << (8 * k);
+    }
+    const int oxc = min(max(w.ox, 0), max(L.w - 1, 0));  // ox >= 0 by construction; the clamp only keeps the address sane
+    if (oxc != w.ox) colmask = 0;
+    unsigned long long rows[kWinSide];
+#pragma unroll
+    for (int r = 0; r < kWinSide; ++r) {  // one unaligned 8-byte load per row, all six in flight together; the plane is
+        const int y = w.oy + r;           // padded, so the two bytes past the window never leave the allocation
+        const int yc = min(max(y, 0), max(L.h - 1, 0));
+        unsigned long long q;
+        __builtin_memcpy(&q, v.score + L.off + (int64_t)yc * L.w + oxc, 8);
+        rows[r] = (y >= 3 && y < L.h - 3) ? (q & colmask) : 0ull;
     }
 #pragma unroll
-    for (int k = 0; k < kWinSide * kWinSide; k += 4)
-        *reinterpret_cast<uint32_t *>(w.cells + k) = (uint32_t)tmp[k] | (uint32_t)tmp[k + 1] << 8 | (uint32_t)tmp[k + 2] << 16 | (uint32_t)tmp[k + 3] << 24;
+    for (int r = 0; r < kWinSide; ++r) {
+        *reinterpret_cast<uint32_t *>(w.cells + r * kWinRow) = (uint32_t)rows[r];
+        *reinterpret_cast<uint32_t *>(w.cells + r * kWinRow + 4) = (uint32_t)(rows[r] >> 32);
+    }
 }
 
 template <bool MARK>
@@ -330,7 +352,7 @@ __device__ __forceinline__ int window_at(const PairView &v, Window &w, int x, in
         const DetLayer &L = v.g->L[w.layer];
         if (x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3) w.asked |= 1ull << (iy * kWinSide + ix);
     }
-    return w.cells[iy * kWinSide + ix];
+    return w.cells[iy * kWinRow + ix];
 }
 
 // The cells a walk asked for in the layer above become "cached" there -- once the walker is known to be a maximum.
