@@ -128,15 +128,23 @@ __global__ __launch_bounds__(kDetThreads) void det_twothird_kernel(DetArgs a, in
 // ------------------------------------------------------------------ dense corner scores
 // score = largest b in [1, 254] for which 9 contiguous ring pixels are all > c + b or all < c - b, 0 if none:
 // what OastDetector9_16::cornerScore's bisection converges to (oast9_16_nms.cc:42-2116), for any start value <= it.
-__device__ __forceinline__ int arc9_max_of_min(const int (&d)[16])
+// over the 16 arcs of 9 contiguous ring pixels: the largest arc minimum and the smallest arc maximum of the raw values
+__device__ __forceinline__ void arc9_extremes(const int (&p)[16], int &max_of_min, int &min_of_max)
 {
-    int m3[16];
+    int lo3[16], hi3[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m3[k] = min(d[k], min(d[(k + 1) & 15], d[(k + 2) & 15]));
-    int best = -256;
+    for (int k = 0; k < 16; ++k) {
+        lo3[k] = min(p[k], min(p[(k + 1) & 15], p[(k + 2) & 15]));
+        hi3[k] = max(p[k], max(p[(k + 1) & 15], p[(k + 2) & 15]));
+    }
+    int best_lo = 0, best_hi = 255;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) best = max(best, min(m3[k], min(m3[(k + 3) & 15], m3[(k + 6) & 15])));
-    return best;
+    for (int k = 0; k < 16; ++k) {
+        best_lo = max(best_lo, min(lo3[k], min(lo3[(k + 3) & 15], lo3[(k + 6) & 15])));
+        best_hi = min(best_hi, max(hi3[k], max(hi3[(k + 3) & 15], hi3[(k + 6) & 15])));
+    }
+    max_of_min = best_lo;
+    min_of_max = best_hi;
 }
 
 constexpr int kScoreTileW = 64, kScoreTileH = 32, kScoreLdsW = 72;  // LDS rows start at image column x0 - 4: aligned dwords
@@ -173,28 +181,27 @@ __global__ __launch_bounds__(kDetThreads) void det_score_kernel(DetArgs a, int l
         if (x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3) {
             const uint8_t *t = tile + (ry + 3) * kScoreLdsW + lane + 4;
             const int c = t[0];
-            int d[16];
+            int q[16];
             // Bresenham circle of radius 3 in the order of OastDetector9_16::init_pattern (oast9_16.h:74-92)
-            d[0] = t[-3] - c;
-            d[1] = t[-kScoreLdsW - 3] - c;
-            d[2] = t[-2 * kScoreLdsW - 2] - c;
-            d[3] = t[-3 * kScoreLdsW - 1] - c;
-            d[4] = t[-3 * kScoreLdsW] - c;
-            d[5] = t[-3 * kScoreLdsW + 1] - c;
-            d[6] = t[-2 * kScoreLdsW + 2] - c;
-            d[7] = t[-kScoreLdsW + 3] - c;
-            d[8] = t[3] - c;
-            d[9] = t[kScoreLdsW + 3] - c;
-            d[10] = t[2 * kScoreLdsW + 2] - c;
-            d[11] = t[3 * kScoreLdsW + 1] - c;
-            d[12] = t[3 * kScoreLdsW] - c;
-            d[13] = t[3 * kScoreLdsW - 1] - c;
-            d[14] = t[2 * kScoreLdsW - 2] - c;
-            d[15] = t[kScoreLdsW - 3] - c;
-            const int vb = arc9_max_of_min(d);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) d[k] = -d[k];
-            const int vd = arc9_max_of_min(d);
+            q[0] = t[-3];
+            q[1] = t[-kScoreLdsW - 3];
+            q[2] = t[-2 * kScoreLdsW - 2];
+            q[3] = t[-3 * kScoreLdsW - 1];
+            q[4] = t[-3 * kScoreLdsW];
+            q[5] = t[-3 * kScoreLdsW + 1];
+            q[6] = t[-2 * kScoreLdsW + 2];
+            q[7] = t[-kScoreLdsW + 3];
+            q[8] = t[3];
+            q[9] = t[kScoreLdsW + 3];
+            q[10] = t[2 * kScoreLdsW + 2];
+            q[11] = t[3 * kScoreLdsW + 1];
+            q[12] = t[3 * kScoreLdsW];
+            q[13] = t[3 * kScoreLdsW - 1];
+            q[14] = t[2 * kScoreLdsW - 2];
+            q[15] = t[kScoreLdsW - 3];
+            int arc_lo, arc_hi;
+            arc9_extremes(q, arc_lo, arc_hi);
+            const int vb = arc_lo - c, vd = c - arc_hi;  // brightest all-brighter arc margin, darkest all-darker arc margin
             s = max(max(vb, vd) - 1, 0);
         }
         if (x < L.w && y < L.h) score[(int64_t)y * L.w + x] = (uint8_t)s;
