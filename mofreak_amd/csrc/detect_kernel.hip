@@ -68,10 +68,20 @@ __global__ __launch_bounds__(kDetThreads) void det_diff_kernel(DetArgs a)
     const uint8_t *c = a.f.cur + (int64_t)p * a.f.pair_stride + (int64_t)y * a.f.row_stride + x0;
     const uint8_t *q = a.f.prev ? a.f.prev + (int64_t)p * a.f.pair_stride + (int64_t)y * a.f.row_stride + x0 : nullptr;
     uint8_t *d = a.img + (int64_t)p * a.dg->plane_bytes + a.dg->L[0].off + (int64_t)y * W + x0;
+    // cv::absdiff (MoFREAKUtilities.cpp:413-414), four pixels per thread; one dword each way where everything is aligned
+    const bool wide = x0 + 4 <= W && (((uintptr_t)c | (uintptr_t)d | (q ? (uintptr_t)q : 0)) & 3) == 0;
+    if (wide) {
+        const uint32_t u = *reinterpret_cast<const uint32_t *>(c), v = q ? *reinterpret_cast<const uint32_t *>(q) : 0u;
+        uint32_t r = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r |= (uint32_t)absdiff_u8(u, v, k) << (8 * k);
+        *reinterpret_cast<uint32_t *>(d) = r;
+        return;
+    }
     const int n = min(4, W - x0);
     for (int k = 0; k < n; ++k) {
         const int u = c[k], v = q ? q[k] : 0;
-        d[k] = (uint8_t)(u > v ? u - v : v - u);  // cv::absdiff (MoFREAKUtilities.cpp:413-414)
+        d[k] = (uint8_t)(u > v ? u - v : v - u);
     }
 }
 
@@ -264,15 +274,30 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
     const int64_t plane = (int64_t)p * a.dg->plane_bytes + L.off;
     const uint8_t *sc = a.score + plane;
     const int64_t cbase = (int64_t)p * a.cand_cap;
-    for (int x0 = 0; x0 < L.w; x0 += 64) {
-        const int x = x0 + lane;
-        const int s = x < L.w ? sc[(int64_t)y * L.w + x] : 0;
-        const bool hit = s >= a.safe_threshold;  // the score is zero outside the detector's 3-pixel border
-        const unsigned long long m = __ballot(hit);
-        if (hit) {
-            const int idx = base + __popcll(m & ((1ull << lane) - 1));
+    // four pixels per lane where the rows are dword aligned (256 per step), else one; raster order = lane, then byte
+    const bool wide = (L.w & 3) == 0;
+    const int per = wide ? 4 : 1;
+    const uint8_t *srow = sc + (int64_t)y * L.w;
+    for (int x0 = 0; x0 < L.w; x0 += 64 * per) {
+        const int xl = x0 + per * lane;
+        uint32_t v4 = 0;
+        if (xl < L.w) v4 = wide ? *reinterpret_cast<const uint32_t *>(srow + xl) : (uint32_t)srow[xl];
+        int below = 0, total = 0;
+        bool hit[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            hit[j] = j < per && (int)((v4 >> (8 * j)) & 0xff) >= a.safe_threshold;  // the score is zero outside the 3-pixel border
+            const unsigned long long m = __ballot(hit[j]);
+            below += __popcll(m & ((1ull << lane) - 1));
+            total += __popcll(m);
+        }
+        int idx = base + below;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!hit[j]) continue;
+            const int x = xl + j, s = (int)((v4 >> (8 * j)) & 0xff);
             if (idx < a.cand_cap) {
-                const uint8_t *q = sc + (int64_t)y * L.w + x;
+                const uint8_t *q = srow + x;
                 int hi = 0, eq = 0;
 #pragma unroll
                 for (int dy = -1; dy <= 1; ++dy)
@@ -289,8 +314,9 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
                 a.cand_emit[cbase + idx] = 0;
                 if (flag == kDetTie) a.status[plane + (int64_t)y * L.w + x] = kStPending;
             }
+            ++idx;
         }
-        base += __popcll(m);
+        base += total;
     }
 }
 
