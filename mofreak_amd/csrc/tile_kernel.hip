@@ -201,19 +201,37 @@ __global__ __launch_bounds__(256) void bin_count_kernel(BinArgs a)
         }
     }
     a.kp_key[g] = key;
+    // how many keypoints already need the gather path: pass 2 decides from it whether thin tiles follow them there
+    const unsigned long long slow = __ballot(key == -2);
+    if (slow && lane_id() == __ffsll((long long)slow) - 1) atomicAdd(a.slow_count, __popcll(slow));
 }
 
+// A tile costs the same whether it holds 5 keypoints or 90 (gray tiles, the 192 x 160 integral), the gather path
+// costs per keypoint.  When the gather path runs anyway for a good share of the call (large keypoints: a detector's
+// output), thinly populated tiles are cheaper there; on dense grids nothing changes.
+constexpr int kSparseTile = 16;  // keypoints below which a tile is handed to the gather path
+constexpr int kSparseMarker = -(1 << 30);
+
 // Pass 2: exclusive scan of the tile populations (single workgroup; n_keys is a few hundred to ~1e5).
-__global__ __launch_bounds__(256) void bin_scan_kernel(int32_t *tile_start, int64_t n_keys)
+__global__ __launch_bounds__(256) void bin_scan_kernel(int32_t *tile_start, int32_t *tile_cursor, int32_t *slow_count, int64_t n_kp,
+                                                       int64_t n_keys)
 {
     __shared__ int carry_s;
     __shared__ int wave_tot[4];
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     const int lane = lane_id(), w = threadIdx.x >> 6;
+    const int n_slow = *slow_count;  // counted by pass 1; pass 3 counts again while it fills the list
+    const bool drop_sparse = n_slow > 0 && (int64_t)n_slow * 8 >= n_kp;
+    __syncthreads();
+    if (threadIdx.x == 0) *slow_count = 0;
     for (int64_t b0 = 0; b0 < n_keys; b0 += 256) {
         const int64_t b = b0 + threadIdx.x;
-        const int v = b < n_keys ? tile_start[b] : 0;
+        int v = b < n_keys ? tile_start[b] : 0;
+        if (drop_sparse && v > 0 && v < kSparseTile) {
+            v = 0;
+            tile_cursor[b] = kSparseMarker;  // pass 3 sends this tile's keypoints to the slow list
+        }
         const int incl = wave_inclusive_scan(v);
         if (lane == 63) wave_tot[w] = incl;
         __syncthreads();
@@ -233,7 +251,9 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs a)
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= a.n_kp) return;
     const int key = a.kp_key[g];
-    if (key >= 0) {
+    if (key >= 0 && a.tile_cursor[key] < 0) {
+        a.slow_list[atomicAdd(a.slow_count, 1)] = (int)g;
+    } else if (key >= 0) {
         const int pos = a.tile_start[key] + atomicAdd(&a.tile_cursor[key], 1);
         const mofreak_keypoint kp = a.kps[g];
         SortedKp s;
@@ -790,7 +810,7 @@ int launch_bin(const BinArgs &a, void *stream)
     if (e != hipSuccess) return (int)e;
     const int blocks = (int)((a.n_kp + 255) / 256);
     if (blocks > 0) hipLaunchKernelGGL(bin_count_kernel, dim3(blocks), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, s, a.tile_start, a.n_keys);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, s, a.tile_start, a.tile_cursor, a.slow_count, a.n_kp, a.n_keys);
     if (blocks > 0) hipLaunchKernelGGL(bin_scatter_kernel, dim3(blocks), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
