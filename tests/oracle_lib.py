@@ -37,7 +37,8 @@ def lib():
     if _lib is not None:
         return _lib
     build()
-    L = C.CDLL(LIB_PATH)
+    # MOFREAK_ORACLE_LIBRARY: e.g. the `make -C oracle asan` build (run with LD_PRELOAD=libasan.so)
+    L = C.CDLL(os.environ.get("MOFREAK_ORACLE_LIBRARY", LIB_PATH))
     u8p, i32p, f32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_float)
     L.mo_freak_create.restype = C.c_void_p
     L.mo_freak_create.argtypes = [C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
