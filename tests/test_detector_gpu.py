@@ -249,3 +249,12 @@ def test_frame_at_a_time_stream_equals_the_stack_calls(ctx, oracle):
     with ctx.open_stream(160, 120, use_detector=False) as st:
         parts = [st.push(bgr[t], per_frame[t]) for t in range(9)]
     assert np.concatenate(parts).tobytes() == want.tobytes() and len(want) > 20
+
+
+@pytest.mark.parametrize("w,h", [(7, 7), (6, 6), (33, 9), (9, 40), (53, 47), (2, 2)])
+def test_tiny_images_and_every_depth(ctx, w, h):
+    """Layers that shrink to nothing (no scored region, zero-sized planes) must neither crash nor differ from the oracle."""
+    img = np.random.default_rng(w * 100 + h).integers(0, 256, (h, w), dtype=np.uint8)
+    for octaves in (0, 1, 3, 4):
+        kps, offs, resp, layer = ctx.detect_pairs_host(img, None, 30, octaves)
+        _assert_same_keypoints((kps, resp, layer), _oracle_keypoints(img, 30, octaves), f"{w}x{h} octaves {octaves}")
