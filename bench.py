@@ -205,9 +205,20 @@ def main():
         all_ms = prof["tile_ms"] + prof["bin_ms"] + prof["gather_ms"]
         pipeline_gbs = b_alg_pair * prof["pairs"] / (all_ms * 1e-3) / 1e9
         traffic = None
+        valu = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("tile_kernel_hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("tile_kernel_hbm_bytes_per_launch")
+            if tj.get("valu_wave_instr_per_descriptor"):
+                # what actually bounds the kernel: vector instruction issue.  Instructions per descriptor from the PMC pass
+                # (profiles/), issue rate of a wave64 VALU instruction measured on this part; duration measured live.
+                n_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+                clk = 2.4e9
+                issued = tj["valu_wave_instr_per_descriptor"] * n_desc / (tile_ms_avg * 1e-3)
+                peak_issue = n_cus * 4 * clk / tj.get("valu_cycles_per_wave_instr", 2.0)
+                valu = {"achieved_wave_instr_per_s": issued, "peak_wave_instr_per_s": peak_issue, "frac": issued / peak_issue,
+                        "wave_instr_per_descriptor": tj["valu_wave_instr_per_descriptor"], "clock_hz_assumed": clk}
         out = {
             "metric": "MoFREAK descriptors/sec on dense 1080p frames; achieved HBM GB/s vs peak",
             "value": value, "unit": "descriptors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -221,7 +232,8 @@ def main():
                          "algorithmic_bytes_per_pair": b_alg_pair, "pairs_per_launch": pairs_per_launch,
                          "avg_launch_ms": tile_ms_avg, "launches_timed": prof["calls"],
                          "binning_avg_ms": prof["bin_ms"] / launches, "gather_path_avg_ms": prof["gather_ms"] / launches,
-                         "pipeline_achieved_GBs": pipeline_gbs, "pipeline_frac": pipeline_gbs / HBM_PEAK_GBS},
+                         "pipeline_achieved_GBs": pipeline_gbs, "pipeline_frac": pipeline_gbs / HBM_PEAK_GBS,
+                         "valu_issue": valu},
             "gather_ms": gather_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
