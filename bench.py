@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=256, help="resident frame pairs per GPU")
     ap.add_argument("--config", default="C3", help="synthetic config (C3 = the metric's: 1080p, 8-px grid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=64)
+    ap.add_argument("--cpu-pairs", type=int, default=192, help="pairs of the workload the CPU oracle is timed on (about 25 core-seconds)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL); 'gloo' + "
                     "--share-device rehearses the N > 1 control flow on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
