@@ -177,3 +177,21 @@ def test_chop_merge_and_binary_sidecar(native_lib, tmp_path):
     harness.write_rows_binary(str(side), rows)
     assert harness.read_rows_binary(str(side)).tobytes() == rows.tobytes()
     assert M.parse_rows(text).tobytes() == rows.tobytes()
+
+
+@pytest.mark.gpu
+def test_trecvid_shaped_stream_in_chunks(native_lib, oracle):
+    """BASELINE config 5 shape: 720x576 frames, dense 8-px grid, walked in 10-frame chunks with the 5-frame halo."""
+    c = synth.CONFIGS["C5"]
+    W, H, T = c["W"], c["H"], 23
+    fr = synth.synth_stack(T, W, H, t0=100)
+    grid = synth.config_grid("C5")
+    mf = harness.MoFREAKUtilities(harness.TRECVID, device=0,
+                                  keypoint_provider=harness.dense_grid_provider(c["step"], c["size"], c["lo"]))
+    rows = mf.extract_rows(fr, chunk_frames=10)
+    assert rows.tobytes() == mf.extract_rows(fr).tobytes()
+    offs = np.arange(T - 5 + 1, dtype=np.int64) * len(grid)
+    want = oracle.Freak().extract_stream(fr, np.tile(grid, (T - 5, 1)), offs)
+    assert rows.tobytes() == want.tobytes() and len(rows) == (T - 5) * len(grid) > 50000
+    assert list(np.unique(rows["frame_number"])) == list(range(4, T - 1))
+    mf.close()
