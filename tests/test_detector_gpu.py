@@ -258,3 +258,21 @@ def test_tiny_images_and_every_depth(ctx, w, h):
     for octaves in (0, 1, 3, 4):
         kps, offs, resp, layer = ctx.detect_pairs_host(img, None, 30, octaves)
         _assert_same_keypoints((kps, resp, layer), _oracle_keypoints(img, 30, octaves), f"{w}x{h} octaves {octaves}")
+
+
+def test_other_frame_gaps(native_lib, oracle):
+    """gap_for_frame_difference is a parameter (the reference hard-codes 5, MoFREAKUtilities.cpp:378): pairing, labels, the
+    frame ring and the whole-loop call all follow it."""
+    fr = synth.moving_objects_stack(9, 224, 160, seed=51)
+    for gap in (1, 3):
+        c = M.Context(0, gap_for_frame_difference=gap)
+        T = len(fr)
+        lists = [_oracle_keypoints(O.absdiff(fr[t], fr[t - gap]))[0] for t in range(gap, T)]
+        offs = np.concatenate([[0], np.cumsum([len(k) for k in lists])]).astype(np.int64)
+        want = oracle.Freak().extract_stream(fr, np.concatenate(lists), offs, gap=gap)
+        assert c.compute_stream_host(fr).tobytes() == want.tobytes() and len(want) > 50
+        with c.open_stream(224, 160) as st:
+            got = np.concatenate([st.push(f) for f in fr])
+        assert got.tobytes() == want.tobytes()
+        assert want["frame_number"].min() == gap - 1
+        c.close()
