@@ -119,6 +119,20 @@ __device__ __forceinline__ int run_row(int t) { return 4 * ((t >> 3) / (kTileRW 
 __device__ __forceinline__ int run_col(int t) { return 2 * ((t >> 3) % (kTileRW / 32)) + (t & 1); }
 
 // FREAK::meanIntensity (box branch) on the tile-local integral; (ox, oy) = image coordinates of the region origin.
+// div_box for the tile path: quotient <= 255 and box area < 2^12 (patterns up to the 48-pixel halo), so the fix-up
+// product is a 24-bit multiply (full rate) instead of v_mul_lo_u32
+__device__ __forceinline__ int div_box24(int v, int a)
+{
+    int q = (int)((float)v * __builtin_amdgcn_rcpf((float)a));
+    int r = v - __mul24(q, a);
+    if (r < 0) {
+        --q;
+        r += a;
+    }
+    if (r >= a) ++q;
+    return q;
+}
+
 __device__ __forceinline__ int mean_intensity_tile(const int32_t *__restrict__ I, int ox, int oy, float kx, float ky,
                                                    const PatternPoint P)
 {
@@ -136,7 +150,7 @@ __device__ __forceinline__ int mean_intensity_tile(const int32_t *__restrict__ I
     ret_val -= bot[x_left];
     ret_val += top[x_left];
     ret_val -= top[x_right];
-    return div_box(ret_val, __mul24(x_right - x_left, y_bottom - y_top)) & 0xff;
+    return div_box24(ret_val, __mul24(x_right - x_left, y_bottom - y_top)) & 0xff;
 }
 
 // ------------------------------------------------------------------------------------------------
