@@ -9,6 +9,8 @@ single byte shows up against them.
   golden_pair.npz     one 288x272 frame pair, 500 keypoints of mixed sizes spread over the whole frame
                       -> 16-byte descriptors + validity flags, in the three FREAK bit layouts
   golden_stream.npz   a 9-frame 176x144 stack with per-frame keypoint lists -> .mofreak rows (binary + text)
+  golden_detector.npz a 160x120 moving-object frame pair and a tie-heavy 96x72 image -> BRISK keypoints (x, y, size,
+                      response, layer) from oracle/brisk_oracle.c, and the rows of detector + descriptors on a 7-frame clip
 
 Run from the repo root:  python tests/golden/make_golden.py
 """
@@ -53,8 +55,22 @@ def main():
     text = O.format_rows(rows)
     np.savez_compressed(os.path.join(HERE, "golden_stream.npz"), frames=fr, kps=kps, kp_offsets=offs,
                         rows=rows.view(np.uint8).reshape(-1, 32), text=np.frombuffer(text, np.uint8))
-    print(f"golden_pair: {int(out['valid_sse'].sum())}/{len(out['kps'])} valid; golden_stream: {len(rows)} rows, {len(text)} text bytes")
-    for f in ("golden_pair.npz", "golden_stream.npz"):
+    # ---- the detector
+    clip = synth.moving_objects_stack(7, 160, 120, seed=77)
+    diff = O.absdiff(clip[5], clip[0])
+    kp_pair = O.brisk_detect(diff, 30, 3)
+    small = rng.integers(0, 4, (24, 32)) * 85
+    ties = np.kron(small, np.ones((3, 3), np.int64)).astype(np.uint8)  # 96 x 72, blocky four-level noise: many equal scores
+    kp_ties = O.brisk_detect(ties, 30, 3)
+    lists = [O.brisk_detect(O.absdiff(clip[t], clip[t - 5])) for t in (5, 6)]
+    kk = np.concatenate([np.stack([k["x"], k["y"], k["size"]], 1) for k in lists]).astype(np.float32)
+    clip_rows = O.Freak().extract_stream(clip, kk, np.int64([0, len(lists[0]), len(kk)]))
+    assert len(kp_pair) > 50 and len(kp_ties) > 50 and len(clip_rows) > 5
+    np.savez_compressed(os.path.join(HERE, "golden_detector.npz"), clip=clip, kp_pair=kp_pair.view(np.uint8).reshape(-1, 20),
+                        ties=ties, kp_ties=kp_ties.view(np.uint8).reshape(-1, 20), clip_rows=clip_rows.view(np.uint8).reshape(-1, 32))
+    print(f"golden_pair: {int(out['valid_sse'].sum())}/{len(out['kps'])} valid; golden_stream: {len(rows)} rows, {len(text)} text bytes; "
+          f"golden_detector: {len(kp_pair)} + {len(kp_ties)} keypoints, {len(clip_rows)} rows")
+    for f in ("golden_pair.npz", "golden_stream.npz", "golden_detector.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -56,3 +56,29 @@ def test_hip_reproduces_golden_stream(gpu_ctx):
     rows = gpu_ctx.extract_stream_host(g["frames"], g["kps"], kp_offsets=g["kp_offsets"])
     assert rows.view(np.uint8).reshape(-1, 32).tobytes() == g["rows"].tobytes()
     assert M.format_rows(rows) == g["text"].tobytes()
+
+
+def _kp(a):
+    import oracle_lib
+    return a.copy().view(oracle_lib.KEYPOINT_DTYPE).reshape(-1)
+
+
+def test_oracle_reproduces_golden_detector(oracle):
+    g = np.load(os.path.join(GOLD, "golden_detector.npz"))
+    clip = g["clip"]
+    assert oracle.brisk_detect(oracle.absdiff(clip[5], clip[0])).tobytes() == _kp(g["kp_pair"]).tobytes()
+    assert oracle.brisk_detect(g["ties"]).tobytes() == _kp(g["kp_ties"]).tobytes()
+    assert len(np.unique(_kp(g["kp_ties"])["layer"])) >= 4
+
+
+@pytest.mark.gpu
+def test_device_reproduces_golden_detector(native_lib):
+    g = np.load(os.path.join(GOLD, "golden_detector.npz"))
+    clip = g["clip"]
+    with M.Context(0) as ctx:
+        for img_cur, img_prev, want in [(clip[5], clip[0], _kp(g["kp_pair"])), (g["ties"], None, _kp(g["kp_ties"]))]:
+            kps, offs, resp, layer = ctx.detect_pairs_host(img_cur, img_prev)
+            assert kps.tobytes() == np.stack([want["x"], want["y"], want["size"]], 1).astype(np.float32).tobytes()
+            assert resp.tobytes() == want["response"].tobytes() and np.array_equal(layer, want["layer"])
+        rows = ctx.compute_stream_host(clip)
+        assert rows.view(np.uint8).reshape(-1, 32).tobytes() == g["clip_rows"].tobytes()
