@@ -921,7 +921,13 @@ constexpr uint8_t kDetTieReady = 3;
 // it (see the header comment): a cell holds its score if it is a detected corner, if the layer below asked for it,
 // or if it lies in the 3x3 patch of a maximum that was processed earlier (raster order) and got as far as its patch;
 // otherwise it still holds zero.  All loads are issued up front (they are independent); the logic runs on registers.
-__device__ __forceinline__ bool tie_is_max(const PairView &v, const DetLayer &L, int safe_threshold, int px, int py)
+struct TieStep {
+    bool ready, is_max;
+};
+
+// One bulk load, both answers: is the tie ready (see tie_ready below: no undecided earlier tie whose patch overlaps an
+// unsettled cell of this window) and, if so, does it survive the smoothed comparison.
+__device__ __forceinline__ TieStep tie_step(const PairView &v, const DetLayer &L, int safe_threshold, int px, int py)
 {
     uint8_t st[7][7];
     int sc[5][5];
@@ -946,17 +952,23 @@ __device__ __forceinline__ bool tie_is_max(const PairView &v, const DetLayer &L,
             tc[dy + 2][dx + 2] = in ? v.touch[o] : (uint8_t)0;
         }
     int r[5][5];
+    bool waits = false;
 #pragma unroll
     for (int y = 0; y < 5; ++y)
 #pragma unroll
         for (int x = 0; x < 5; ++x) {
             const int s = sc[y][x];
-            bool filled = s >= safe_threshold || tc[y][x] != 0;
+            const bool settled = s == 0 || s >= safe_threshold || tc[y][x] != 0;
+            bool filled = s >= safe_threshold || tc[y][x] != 0, pending_near = false;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) filled |= st[y + dy][x + dx] == kStReached;  // window (y+dy, x+dx) = cell + (dx-1, dy-1)
+                for (int dx = 0; dx < 3; ++dx) {  // window (y+dy, x+dx) = cell + (dx-1, dy-1)
+                    filled |= st[y + dy][x + dx] == kStReached;
+                    pending_near |= st[y + dy][x + dx] == kStPending;
+                }
             r[y][x] = filled ? s : 0;
+            waits |= !settled && pending_near;
         }
     const int center = r[2][2];
     auto smooth = [&](int cx, int cy) {  // 1 2 1 / 2 4 2 / 1 2 1 around (cx, cy) in window coordinates
@@ -972,7 +984,12 @@ __device__ __forceinline__ bool tie_is_max(const PairView &v, const DetLayer &L,
             if (dx == 0 && dy == 0) continue;
             if (r[2 + dy][2 + dx] == center && smooth(2 + dx, 2 + dy) > smoothedcenter) is_max = false;
         }
-    return is_max;
+    return TieStep{!waits, is_max};
+}
+
+__device__ __forceinline__ bool tie_is_max(const PairView &v, const DetLayer &L, int safe_threshold, int px, int py)
+{
+    return tie_step(v, L, safe_threshold, px, py).is_max;
 }
 
 // A tie is ready when no undecided tie that precedes it in raster order could still change a cell it reads: such a
@@ -997,10 +1014,10 @@ __device__ __forceinline__ bool tie_ready(const PairView &v, const DetLayer &L, 
     return true;
 }
 
-__device__ __forceinline__ void tie_decide(const DetArgs &a, const PairView &v, const DetLayer &L, int p, int i, int layer, int px, int py)
+__device__ __forceinline__ void tie_apply(const DetArgs &a, const PairView &v, const DetLayer &L, int p, int i, int layer, int px, int py, bool is_max)
 {
     const int64_t ci = (int64_t)p * a.cand_cap + i;
-    if (tie_is_max(v, L, a.safe_threshold, px, py)) {  // publish what the refinement kernel parked
+    if (is_max) {  // publish what the refinement kernel parked
         const uint8_t spec = a.cand_spec[ci];
         a.cand_flag[ci] = kDetMax;
         a.cand_emit[ci] = (spec & kEmit) ? 1 : 0;
@@ -1014,6 +1031,11 @@ __device__ __forceinline__ void tie_decide(const DetArgs &a, const PairView &v, 
         a.cand_flag[ci] = kDetNotMax;
         v.status[L.off + (int64_t)py * L.w + px] = kStDone;
     }
+}
+
+__device__ __forceinline__ void tie_decide(const DetArgs &a, const PairView &v, const DetLayer &L, int p, int i, int layer, int px, int py)
+{
+    tie_apply(a, v, L, p, i, layer, px, py, tie_is_max(v, L, a.safe_threshold, px, py));
 }
 
 // Ties of one layer, all pairs at once, in rounds of mutually independent ones: `ready` marks them (and counts the
@@ -1099,8 +1121,9 @@ __global__ __launch_bounds__(kDetThreads) void det_tie_residual_kernel(DetArgs a
                 xy = a.cand_xy[cb + j];
                 const int nx = (int)(xy & 0xffff), ny = (int)(xy >> 16);
                 if (ny != py || nx - px > 3) break;
-                if (!tie_ready(v, L, a.safe_threshold, nx, ny)) break;
-                tie_decide(a, v, L, p, j, layer, nx, ny);
+                const TieStep step = tie_step(v, L, a.safe_threshold, nx, ny);  // one round of loads per link of the chain
+                if (!step.ready) break;
+                tie_apply(a, v, L, p, j, layer, nx, ny, step.is_max);
                 atomicSub(&remaining, 1);
                 px = nx;
             }
