@@ -302,6 +302,7 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
         b.sorted_kp = static_cast<SortedKp *>(ctx->sorted_idx.ptr);
         b.slow_list = static_cast<int32_t *>(ctx->slow_list.ptr);
         b.slow_count = static_cast<int32_t *>(ctx->slow_count.ptr);
+        b.max_ps = static_cast<int32_t *>(ctx->slow_count.ptr) + 16;  // same 256-byte buffer, its own 64-byte line
         b.out_desc = out_desc;
         b.out_valid = out_valid;
         b.out_info = out_info;
@@ -336,6 +337,7 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
             // CSR: bins are per (pair, tile); shared list: per tile, outputs offset by the pair
             t.tile_start = static_cast<const int32_t *>(ctx->tile_start.ptr) + (d_offsets ? (int64_t)p0 * tiles_x * tiles_y : 0);
             t.sorted_kp = static_cast<const SortedKp *>(ctx->sorted_idx.ptr);
+            t.max_ps = static_cast<const int32_t *>(ctx->slow_count.ptr) + 16;
             t.tile_lmin = static_cast<const uint32_t *>(ctx->tile_lmin.ptr) + (d_offsets ? (int64_t)p0 * tiles_x * tiles_y : 0);
             t.tile_lmax = static_cast<const uint32_t *>(ctx->tile_lmax.ptr) + (d_offsets ? (int64_t)p0 * tiles_x * tiles_y : 0);
             t.out_desc = d_offsets ? out_desc : out_desc + (int64_t)p0 * n_kp * 16;

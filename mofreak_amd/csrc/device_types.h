@@ -100,6 +100,7 @@ struct BinArgs {
     SortedKp *sorted_kp;        // [n_kp] keypoints grouped by key
     int32_t *slow_list;         // [n_kp]
     int32_t *slow_count;        // [1]
+    int32_t *max_ps;            // [1] largest patternSizes[] among the tile-path keypoints: sizes the tile kernel's halo
     uint8_t *out_desc;          // erased keypoints are finalised by the binning pass (zeros, valid = 0)
     uint8_t *out_valid;
     int32_t *out_info;
@@ -121,6 +122,7 @@ struct TileArgs {
     const int32_t *tile_start;
     const uint32_t *tile_lmin, *tile_lmax;
     const SortedKp *sorted_kp;
+    const int32_t *max_ps;      // device word written by the binning pass (see BinArgs)
     uint8_t *out_desc;
     uint8_t *out_valid;
     int32_t *out_info;          // optional

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace mofreak {
@@ -333,6 +334,9 @@ void build_tables(const FreakParams &p, Tables &t)
                 m.off11 = static_cast<uint16_t>(ty[dy].ofs1 * kTileCW + tx[dx].ofs1);
                 m.c0x = tx[dx].c0;
                 m.c1x = tx[dx].c1;
+                // the tile kernel reads a row pair as (off, off + 1): a clamped column has to carry a zero weight
+                if (m.off01 != m.off00 + 1 && m.c1x != 0) std::abort();
+                if (m.off11 != m.off10 + 1 && m.c1x != 0) std::abort();
                 m.c0y = ty[dy].c0;
                 m.c1y = ty[dy].c1;
             }

@@ -1,20 +1,25 @@
-// Fused tile kernel of the MoFREAK path for gfx950 (CDNA4): one 1024-thread workgroup owns a 96x64-pixel tile of
-// one frame pair and describes every keypoint whose pixel falls in it, entirely out of LDS.
+// Fused tile kernel of the MoFREAK path for gfx950 (CDNA4): one 512-thread workgroup owns a 96x64-pixel tile of one
+// frame pair and describes every keypoint whose pixel falls in it, entirely out of LDS.  Two workgroups share a CU
+// (75 KB of LDS each), so one workgroup's barriers and global-memory latencies are covered by the other's work.
 //
 //   stage 0  gray tiles: the tile + 8-px rim of `current` and `previous` (u8, 112x80 each) -> LDS
-//   stage 1  MIP (MoFREAKUtilities.cpp:288-325, 46-99): for each keypoint the ~300 pixels of the two 19x19 resamples
-//            that motionInterchangePattern actually reads (cv::resize fixed-point bilinear, host-built sample
-//            table per ROI side, held in registers across the batch) -> LDS; then lane = 8*centre + offset,
-//            strip SSD, __ballot = the 8 motion bytes
-//   stage 2  integral image of |current - previous| over tile + 48-px halo (192x160), built in LDS with two-level
-//            blocked scans; box sums are translation-invariant, so this tile-local integral gives bit-identical
-//            box means to cv::integral of the whole frame -- and the frame-sized integral never exists in HBM
-//   stage 3  FREAK (cv::FREAK::compute on the difference image, :427-428): (keypoint, retina point) pairs flattened
-//            over all lanes for the 43 box means; orientation with 8 lanes per keypoint; rotated means;
-//            lane = descriptor bit, __ballot = the 8 appearance bytes
+//   stage 1  MIP (MoFREAKUtilities.cpp:288-325, 46-99), one wave per keypoint, no workgroup barrier: the ~280 pixels of
+//            the two 19x19 resamples that motionInterchangePattern actually reads (cv::resize fixed-point bilinear,
+//            host-built sample table per ROI side held in registers) -> the wave's own LDS buffer; then
+//            lane = 8*centre + offset, strip SSD, __ballot = the 8 motion bytes
+//   stage 2  integral image of |current - previous| over tile + halo, kept MODULO 2^16 (u16, two pixels per dword):
+//            the row pass scans inside a wave (v_sad_u8 inside a lane's 16 pixels, DPP row_shr across the 16 lanes
+//            of a region row), the column pass adds packed pairs (v_pk_add_u16).  A box sum is exact modulo 2^16 as
+//            long as the box holds at most 257 pixels (257 * 255 < 2^16); larger boxes are summed in horizontal
+//            slices of at most 257 pixels each.  Box sums are translation-invariant, so the tile-local integral gives
+//            the same box means as cv::integral of the whole frame -- which never exists in HBM.
+//            The halo is sized per call from the largest FREAK pattern among the call's tile-path keypoints
+//            (binning pass, device-resident word): 24, 32, 40 or 48 pixels.
+//   stage 3  FREAK (cv::FREAK::compute on the difference image, :427-428), one wave per group of four keypoints, no
+//            workgroup barrier: 43 box means per keypoint (172 tasks over three 64-lane passes), orientation with
+//            16 lanes per keypoint (DPP row reduction), rotated means, lane = descriptor bit, __ballot = the 8
+//            appearance bytes, one 16-byte store per descriptor
 //
-// The kernel runs one workgroup per CU (LDS-bound), so latency is hidden inside the workgroup: 16 waves, and every
-// phase issues all of a thread's loads before it consumes any of them.
 // HBM traffic is the two frames (halo re-reads are served by L2 / Infinity Cache) + keypoints in + descriptors out.
 // Keypoints whose FREAK pattern does not fit the 48-px halo (patternSizes[scale] > 48, i.e. size >= ~14.9) or whose
 // ROI does not fit the rim are left to the gather path (describe_kernel over a global integral) by the binning pass.
@@ -23,42 +28,48 @@
 namespace mofreak {
 namespace {
 
-constexpr int kTileThreads = 1024;                   // 16 waves: 4 per SIMD
+constexpr int kTileThreads = 512;                    // 8 waves; two workgroups per CU = 4 waves per SIMD
 constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kBatch = 96;                           // keypoints described per pass over a tile's list
-constexpr int kIP = kTileRW + 4;                     // LDS integral pitch (int32); logical column c at physical c+3
-constexpr int kIntegralInts = (kTileRH + 1) * kIP;   // 161 x 196
-constexpr int kRunsPerRow = kTileRW / 16;            // 16-pixel runs per region row
-constexpr int kColBlocks = 8;
-constexpr int kColBlockRows = kTileRH / kColBlocks;  // 20
-constexpr int kVStride = 44;                         // bytes per keypoint in the box-mean array (11 dwords: odd)
+constexpr int kGroup = 4;                            // keypoints one wave describes together in stage 3
+constexpr int kMinHalo = 24;                         // smallest integral halo (patternSizes[0] = 23)
+constexpr int kIPitch = kTileRW + 8;                 // LDS integral pitch (u16); logical column c at physical c+7
+constexpr int kIColOff = 7;
+constexpr int kIPitchDw = kIPitch / 2;
+constexpr int kIntegralBytes = (kTileRH + 1) * kIPitch * 2;
+constexpr int kRowGroupIters = (kTileRH / 4 + kTileWaves - 1) / kTileWaves;   // 4-row groups per wave in the row pass
+constexpr int kColBlockRows = 16;
+constexpr int kMaxColBlocks = kTileRH / kColBlockRows;                         // 10
+constexpr int kMaxDcols = kTileRW / 2;                                         // 96 dword columns (pixel pairs)
+constexpr int kColIters = (kMaxColBlocks * kMaxDcols + kTileThreads - 1) / kTileThreads;
+constexpr int kVStride = 44;                         // bytes per keypoint in a wave's box-mean buffer (11 dwords: odd)
 constexpr int kMipIters = 5;                         // 64-lane passes over the <= 320 sampled 19x19 positions
-constexpr int kBoxIters = (kBatch * kNbPoints + kTileThreads - 1) / kTileThreads;    // box-mean tasks per thread
-constexpr int kRunIters = (kTileRH * kRunsPerRow + kTileThreads - 1) / kTileThreads;  // 16-px runs per thread
-constexpr int kGrayTasks = kTileCH * (kTileCW / 8);
+constexpr int kBoxIters = (kGroup * kNbPoints + 63) / 64;                       // 3
+constexpr int kBigPoints = 12;                       // points of the two outer rings: the boxes that may need slices
+constexpr int kGrayTasks = 2 * kTileCH * (kTileCW / 16);
 constexpr int kGrayIters = (kGrayTasks + kTileThreads - 1) / kTileThreads;
-constexpr int kOrientLanes = 8;                      // lanes that share one keypoint's 45 orientation pairs
+constexpr int kP19Wave = 2 * 2 * kP19Pad;            // a wave's MIP buffers: two keypoints x (cur19, prev19)
 
 // ---- LDS carve (bytes); every offset is a multiple of 16
 constexpr int kOffIntegral = 0;
-constexpr int kOffCur = kIntegralInts * 4;
+// stages 0-1 use the (not yet built) integral area: gray tiles and the waves' 19x19 buffers
+constexpr int kOffCur = 0;
 constexpr int kOffPrev = kOffCur + kTileCW * kTileCH;
-constexpr int kOffScratch = kOffPrev + kTileCW * kTileCH;
-constexpr int kScratchBytes = kTileRH * kRunsPerRow * 4;  // 7680: row carries; also column carries / per-keypoint arrays
-constexpr int kOffSmall = kOffScratch + kScratchBytes;
-constexpr int kOffTheta = kOffSmall + (int)((sizeof(SmallTables) + 15) / 16 * 16);
-constexpr int kOffKf = kOffTheta + kThetaBounds * (int)sizeof(ThetaBound);   // the batch's FREAK records (outlive the scratch area)
-constexpr int kOffBits = kOffKf + kBatch * 16;                               // 8 descriptor bytes per keypoint, staged
-constexpr int kOffMot = kOffBits + kBatch * 8;                               // motion bytes kept for the fused store
+constexpr int kOffP19 = kOffPrev + kTileCW * kTileCH;
+constexpr int kOffScratch = (kIntegralBytes + 15) / 16 * 16;
+constexpr int kScratchBytes = kMaxColBlocks * kMaxDcols * 4;   // column-block totals; stage-1 records; stage-3 box means
+constexpr int kOffTheta = kOffScratch + kScratchBytes;
+constexpr int kOffKf = kOffTheta + kThetaBounds * (int)sizeof(ThetaBound);   // the batch's FREAK records
+constexpr int kOffMot = kOffKf + kBatch * 16;                                // motion bytes kept for the fused store
 constexpr int kOffStamps = kOffMot + kBatch * 8;                             // diagnostic build only: 32 x u64
 constexpr int kTileLdsBytes = kOffStamps + 256;
-static_assert(kOffCur % 16 == 0 && kOffPrev % 16 == 0 && kOffScratch % 16 == 0 && kOffSmall % 16 == 0, "LDS carve alignment");
-static_assert(kTileLdsBytes <= 160 * 1024, "tile kernel LDS budget");
-static_assert(kTileRW % 16 == 0 && kTileRH % kColBlocks == 0, "region blocking");
-static_assert(kColBlocks * kTileRW * 4 <= kScratchBytes, "column carries fit the scratch area");
-// during stage 1 the (not yet built) integral area holds the 19x19 buffers
-constexpr int kOffP19 = 0;
-static_assert(kBatch * 2 * kP19Pad <= kOffCur, "stage-1 buffers fit the integral area");
+static_assert(kOffP19 % 16 == 0 && kP19Wave % 16 == 0 && kOffScratch % 16 == 0 && kOffTheta % 16 == 0, "LDS carve alignment");
+static_assert(kOffP19 + kTileWaves * kP19Wave <= kIntegralBytes, "stage-1 buffers fit the integral area");
+static_assert(2 * kTileLdsBytes <= 160 * 1024, "two workgroups per CU");
+static_assert(kTileRW % 16 == 0 && kTileRH % kColBlockRows == 0 && kTileRW / 16 <= 16, "region blocking");
+static_assert((kIPitch * 2) % 16 == 0, "integral rows start on 16 bytes");
+static_assert(kTileWaves * kGroup * kVStride <= kScratchBytes, "stage-3 box means fit the scratch area");
+static_assert(kBatch % (kGroup * kTileWaves) == 0, "whole groups per wave in a full batch");
 
 struct KpFreak {   // stage 3 per-keypoint record
     float kx, ky;
@@ -70,87 +81,109 @@ struct KpMip {     // stage 1 per-keypoint record
     uint16_t roi_off;
     uint8_t L, pad;
 };
-static_assert(kBatch * kVStride <= kScratchBytes, "stage-3 box means fit the scratch area");
 static_assert(kBatch * (int)sizeof(KpMip) <= kScratchBytes, "stage-1 records fit the scratch area");
 static_assert(sizeof(KpFreak) == 16, "record size used by the LDS carve");
 
-// 16 pixels of one row starting at image column gx (zero outside the image).
-__device__ __forceinline__ uint4 load_px16(const uint8_t *row, int gx, int W, bool row_ok, bool fast16)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef const volatile __attribute__((address_space(3))) uint8_t lds_vu8;   // byte loads the optimiser must not fuse
+
+struct __attribute__((aligned(8))) Px16 {
+    uint32_t w[4];
+};
+
+// 16 pixels of one row starting at image column gx (zero outside the image).  gx is a multiple of 8.
+__device__ __forceinline__ Px16 load_px16(const uint8_t *row, int gx, int W, bool row_ok, bool fast8)
 {
-    if (row_ok && fast16 && gx >= 0 && gx + 16 <= W) return *reinterpret_cast<const uint4 *>(row + gx);
-    uint32_t w[4] = {0, 0, 0, 0};
+    if (row_ok && fast8 && gx >= 0 && gx + 16 <= W) return *reinterpret_cast<const Px16 *>(row + gx);
+    Px16 r = {{0, 0, 0, 0}};
     if (row_ok) {
         for (int k = 0; k < 16; ++k) {
             const int x = gx + k;
-            if (x >= 0 && x < W) w[k >> 2] |= (uint32_t)row[x] << (8 * (k & 3));
+            if (x >= 0 && x < W) r.w[k >> 2] |= (uint32_t)row[x] << (8 * (k & 3));
         }
     }
-    return make_uint4(w[0], w[1], w[2], w[3]);
+    return r;
 }
 
-__device__ __forceinline__ uint2 load_px8(const uint8_t *row, int gx, int W, bool row_ok, bool fast8)
+// (int)((double)a + 0.5) for a float 0.5 <= a < 2^22 with one float add: a + 0.5f is exact while it stays in a's
+// binade; when it crosses into the next one the sum lies in [2^k, 2^k + 0.5), so rounding it to the coarser grid cannot
+// reach another integer.  (Tile-path taps are > 1: the keypoint passed FREAK's border filter.)
+__device__ __forceinline__ int round_half_up_pos(float a) { return (int)(a + 0.5f); }
+
+// floor(v / a) for 0 <= v <= 255 * a, 0 < a <= 8192: (v + 0.5) / a lies at least 0.5 / a away from an integer, and the
+// relative error of v_rcp_f32 (1 ulp) plus one rounding of the fma is below 2^-22, i.e. below 256 * 2^-22 = 6e-5 absolute.
+__device__ __forceinline__ int div_box_small(int v, int a)
 {
-    if (row_ok && fast8 && gx >= 0 && gx + 8 <= W) return *reinterpret_cast<const uint2 *>(row + gx);
-    uint32_t w[2] = {0, 0};
-    if (row_ok) {
-        for (int k = 0; k < 8; ++k) {
-            const int x = gx + k;
-            if (x >= 0 && x < W) w[k >> 2] |= (uint32_t)row[x] << (8 * (k & 3));
-        }
+    const float r = __builtin_amdgcn_rcpf((float)a);
+    return (int)__builtin_fmaf((float)v, r, 0.5f * r);
+}
+
+__device__ __forceinline__ int dpp_row_shr(int v, int n)
+{
+    switch (n) {  // bound_ctrl: lanes shifted in from outside the 16-lane row read 0
+    case 1: return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    case 2: return __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    case 4: return __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    default: return __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
     }
-    return make_uint2(w[0], w[1]);
 }
-
-// (int)((double)a + 0.5) for a float 0 <= a < 2^23 without leaving single precision: the double sum is exact, so the
-// result is trunc(a) plus one when the fraction reaches one half.  (Tile-path taps are always > 0: the keypoint
-// passed FREAK's border filter.)
-__device__ __forceinline__ int round_half_up_pos(float a)
+__device__ __forceinline__ int dpp_row_ror(int v, int n)
 {
-    const int i = (int)a;
-    return i + ((a - (float)i) >= 0.5f ? 1 : 0);
-}
-
-// Which 16-pixel run of the region a row-pass task owns.  Eight consecutive tasks (the lane group of one
-// ds_write_b128) take a 4-row x 2-run cell: rows are kIP = 196 dwords apart (4 mod 32) and runs 16 dwords, so the eight
-// 16-byte stores of a group fall into eight different bank quads.  (Row-major task order puts lanes l and l+2 on the
-// same banks: a 4-way conflict on every store of the pass, measured at 29 % of the kernel's LDS cycles.)
-static_assert(kTileRH % 4 == 0 && (kTileRW / 16) % 2 == 0, "run cells");
-__device__ __forceinline__ int run_row(int t) { return 4 * ((t >> 3) / (kTileRW / 32)) + ((t & 7) >> 1); }
-__device__ __forceinline__ int run_col(int t) { return 2 * ((t >> 3) % (kTileRW / 32)) + (t & 1); }
-
-// FREAK::meanIntensity (box branch) on the tile-local integral; (ox, oy) = image coordinates of the region origin.
-// div_box for the tile path: quotient <= 255 and box area < 2^12 (patterns up to the 48-pixel halo), so the fix-up
-// product is a 24-bit multiply (full rate) instead of v_mul_lo_u32
-__device__ __forceinline__ int div_box24(int v, int a)
-{
-    int q = (int)((float)v * __builtin_amdgcn_rcpf((float)a));
-    int r = v - __mul24(q, a);
-    if (r < 0) {
-        --q;
-        r += a;
+    switch (n) {
+    case 1: return __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false);
+    case 2: return __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false);
+    case 4: return __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);
+    default: return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);
     }
-    if (r >= a) ++q;
-    return q;
+}
+// sum over the 16 lanes of a DPP row, in every lane of the row
+__device__ __forceinline__ int row16_sum(int v)
+{
+    v += dpp_row_ror(v, 8);
+    v += dpp_row_ror(v, 4);
+    v += dpp_row_ror(v, 2);
+    v += dpp_row_ror(v, 1);
+    return v;
 }
 
-__device__ __forceinline__ int mean_intensity_tile(const int32_t *__restrict__ I, int ox, int oy, float kx, float ky,
-                                                   const PatternPoint P)
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b)));
+}
+
+// FREAK::meanIntensity (box branch) on the tile-local integral modulo 2^16.  `ibase` = LDS byte address of logical
+// (row 0, column 0) minus the region origin: the u16 of image corner (y, x) sits at ibase + 2 * (y * kIPitch + x).
+__device__ __forceinline__ int mean_intensity_tile(const uint8_t *lds, int ibase, float kx, float ky, const PatternPoint P)
 {
     const float xf = P.x + kx;
     const float yf = P.y + ky;
     const float radius = P.sigma;
     // int(xf - radius + 0.5), int(xf + radius + 1.5): the reference adds 0.5 / 1.5 in double, i.e. exactly
-    const int x_left = round_half_up_pos(xf - radius) - ox;
-    const int y_top = round_half_up_pos(yf - radius) - oy;
-    const int x_right = round_half_up_pos(xf + radius) + 1 - ox;
-    const int y_bottom = round_half_up_pos(yf + radius) + 1 - oy;
-    const int32_t *top = I + __mul24(y_top, kIP) + kIntegralColOffset;
-    const int32_t *bot = I + __mul24(y_bottom, kIP) + kIntegralColOffset;
-    int ret_val = bot[x_right];
-    ret_val -= bot[x_left];
-    ret_val += top[x_left];
-    ret_val -= top[x_right];
-    return div_box24(ret_val, __mul24(x_right - x_left, y_bottom - y_top)) & 0xff;
+    const int x_left = round_half_up_pos(xf - radius);
+    const int y_top = round_half_up_pos(yf - radius);
+    const int x_right = round_half_up_pos(xf + radius) + 1;
+    const int y_bottom = round_half_up_pos(yf + radius) + 1;
+    const int w = x_right - x_left, h = y_bottom - y_top;
+    const int w2 = 2 * w;
+    int addr = ibase + 2 * ((int)__umul24(y_top, kIPitch) + x_left);
+    // rows per slice: the largest count whose slice stays within 257 pixels (floor(257 / w); 257 is prime, so the
+    // quotient is never within 1/64 of an integer and the float reciprocal cannot land on the wrong side)
+    const int rps = max(1, (int)(257.0f * __builtin_amdgcn_rcpf((float)w)));
+    int prev = (int)*reinterpret_cast<const uint16_t *>(lds + addr + w2) - (int)*reinterpret_cast<const uint16_t *>(lds + addr);
+    int step = min(rps, h);
+    addr += (int)__umul24(step, 2 * kIPitch);
+    int cur = (int)*reinterpret_cast<const uint16_t *>(lds + addr + w2) - (int)*reinterpret_cast<const uint16_t *>(lds + addr);
+    int sum = (cur - prev) & 0xffff;
+    int left = h - step;
+    while (left > 0) {  // outer rings of the larger patterns only
+        prev = cur;
+        step = min(rps, left);
+        addr += (int)__umul24(step, 2 * kIPitch);
+        cur = (int)*reinterpret_cast<const uint16_t *>(lds + addr + w2) - (int)*reinterpret_cast<const uint16_t *>(lds + addr);
+        sum += (cur - prev) & 0xffff;
+        left -= step;
+    }
+    return div_box_small(sum, (int)__umul24(w, h)) & 0xff;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -197,6 +230,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(BinArgs a)
     const int ps = st->pattern_sizes[idx];
     if (kx <= ps || ky <= ps || kx >= a.W - ps || ky >= a.H - ps) ok = false;
     int key = -1;
+    int tile_ps = 0;
     if (ok) {
         const int x_i = (int)kx, y_i = (int)ky;
         const int half = ((int)size) / 2, L = (int)ceilf(size);
@@ -207,6 +241,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(BinArgs a)
             const int tile = (y_i / kTileH) * a.tiles_x + (x_i / kTileW);
             const int64_t k64 = a.kp_offsets ? (int64_t)pair_of(a.kp_offsets, a.n_pairs, g) * (a.tiles_x * a.tiles_y) + tile : tile;
             key = (int)k64;
+            tile_ps = ps;
             atomicAdd(&a.tile_start[key], 1);
             atomicMin(&a.tile_lmin[key], (uint32_t)L);
             atomicMax(&a.tile_lmax[key], (uint32_t)L);
@@ -218,11 +253,16 @@ __global__ __launch_bounds__(256) void bin_count_kernel(BinArgs a)
     // how many keypoints already need the gather path: pass 2 decides from it whether thin tiles follow them there
     const unsigned long long slow = __ballot(key == -2);
     if (slow && lane_id() == __ffsll((long long)slow) - 1) atomicAdd(a.slow_count, __popcll(slow));
+    // the largest pattern on the tile path sizes the tile kernel's integral halo
+    int m = tile_ps;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if (m > 0 && lane_id() == 0) atomicMax(a.max_ps, m);
 }
 
-// A tile costs the same whether it holds 5 keypoints or 90 (gray tiles, the 192 x 160 integral), the gather path
-// costs per keypoint.  When the gather path runs anyway for a good share of the call (large keypoints: a detector's
-// output), thinly populated tiles are cheaper there; on dense grids nothing changes.
+// A tile costs the same whether it holds 5 keypoints or 90 (gray tiles, the integral), the gather path costs per
+// keypoint.  When the gather path runs anyway for a good share of the call (large keypoints: a detector's output),
+// thinly populated tiles are cheaper there; on dense grids nothing changes.
 constexpr int kSparseTile = 16;  // keypoints below which a tile is handed to the gather path
 constexpr int kSparseMarker = -(1 << 30);
 
@@ -300,8 +340,8 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs a)
 // the tile kernel
 // ------------------------------------------------------------------------------------------------
 // Diagnostic build of the same kernel (STAMPS = true, launched only when the context was created with
-// MOFREAK_TILE_STAMPS=1): thread 0 of every workgroup adds the s_memtime ticks spent between consecutive
-// workgroup barriers into a.stamps[phase].  In the product instantiation no stamp executes.
+// MOFREAK_TILE_STAMPS=1): thread 0 of every workgroup adds the s_memtime ticks it spent between consecutive
+// stamps into a.stamps[phase].  In the product instantiation no stamp executes.
 #define TILE_STAMP(i)                                                               \
     do {                                                                            \
         if (STAMPS && tid == 0) {                                                   \
@@ -314,16 +354,16 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs a)
 // The vertical step of the 8-bit bilinear resize, ((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2, with the
 // weights pre-shifted by 12: t < 2^20 and b << 12 <= 2^23 are 24-bit operands, and the high half of their 48-bit
 // product, (t & ~15) * (b << 12) >> 32, is (b * (t >> 4)) >> 16 exactly (all factors non-negative).
-__device__ __forceinline__ int resize_y(int t0, int t1, uint32_t b0s, uint32_t b1s)
+__device__ __forceinline__ int resize_y(uint32_t t0, uint32_t t1, uint32_t b0s, uint32_t b1s)
 {
     uint32_t p0, p1;
-    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(p0) : "v"((uint32_t)t0 & ~15u), "v"(b0s));
-    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(p1) : "v"((uint32_t)t1 & ~15u), "v"(b1s));
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(p0) : "v"(t0 & ~15u), "v"(b0s));
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(p1) : "v"(t1 & ~15u), "v"(b1s));
     return (int)((p0 + p1 + 2u) >> 2);
 }
 
 template <bool STAMPS>
-__global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
+__global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     unsigned long long *s_stamps = reinterpret_cast<unsigned long long *>(lds + kOffStamps);
@@ -344,29 +384,29 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
     const int n_tile_kp = a.tile_start[key + 1] - kp_begin;
     if (n_tile_kp == 0) return;
 
-    int32_t *I = reinterpret_cast<int32_t *>(lds + kOffIntegral);
-    uint8_t *s_cur = lds + kOffCur, *s_prev = lds + kOffPrev;
     uint8_t *scratch = lds + kOffScratch;
-    SmallTables &st = *reinterpret_cast<SmallTables *>(lds + kOffSmall);
+    lds_vu8 *ldsv = (lds_vu8 *)lds;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int W = a.f.W, H = a.f.H;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const int ox = tx * kTileW - kTileHalo, oy = ty * kTileH - kTileHalo;        // integral region origin
+    // integral halo of this call: the largest pattern the binning pass met, in steps of 8 pixels
+    const int halo = min(kTileHalo, max(kMinHalo, (*a.max_ps + 7) & ~7));
+    const int RW = kTileW + 2 * halo, RH = kTileH + 2 * halo;
+    const int ox = tx * kTileW - halo, oy = ty * kTileH - halo;                    // integral region origin
     const int cx0 = tx * kTileW - kTileMipHalo, cy0 = ty * kTileH - kTileMipHalo;  // gray tile origin
     const uint8_t *cur = a.f.cur + (int64_t)pair * a.f.pair_stride;
     const uint8_t *prev = a.f.prev + (int64_t)pair * a.f.pair_stride;
-    const bool fast16 = (((uintptr_t)cur | (uintptr_t)prev | (uintptr_t)a.f.row_stride) & 15) == 0;
     const bool fast8 = (((uintptr_t)cur | (uintptr_t)prev | (uintptr_t)a.f.row_stride) & 7) == 0;
     const int64_t out_base = a.kp_offsets ? 0 : (int64_t)pair * a.n_kp;
     const SortedKp *tile_kps = a.sorted_kp + kp_begin;
+    const SmallTables *st = a.small;
+    const int bit_mode = st->bit_mode, mip_theta = st->mip_theta;
+    const bool orientation_normalized = st->orientation_normalized != 0;
 
-    for (int i = tid; i < (int)(sizeof(SmallTables) / 4); i += kTileThreads)
-        reinterpret_cast<int32_t *>(&st)[i] = reinterpret_cast<const int32_t *>(a.small)[i];
     ThetaBound *s_theta = reinterpret_cast<ThetaBound *>(lds + kOffTheta);
-    for (int i = tid; i < kThetaBounds; i += kTileThreads) s_theta[i] = a.theta[i];
+    if (tid < kThetaBounds) s_theta[tid] = a.theta[tid];
 
-    uint2 *s_bits = reinterpret_cast<uint2 *>(lds + kOffBits);
     uint2 *s_mot = reinterpret_cast<uint2 *>(lds + kOffMot);
     KpMip *km = reinterpret_cast<KpMip *>(scratch);            // stage-1 records (scratch area: gone once stage 2 starts)
     KpFreak *kf = reinterpret_cast<KpFreak *>(lds + kOffKf);   // stage-3 records (outside the scratch area)
@@ -399,13 +439,14 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
     };
 
     // per-lane constants of the MIP sampling passes: where each sampled pixel goes, and (once the ROI side is known)
-    // the LDS byte offsets of its four source bytes relative to the ROI origin, frame base included.  Their loads are
-    // issued here, ahead of stage 0, so that the three global latencies overlap.
-    int pos[kMipIters], a0[kMipIters], a1[kMipIters], e0[kMipIters], e1[kMipIters];
+    // the LDS byte offsets of its two source rows relative to the ROI origin, frame base included (the second byte of
+    // a row pair is the next one: where cv::resize clamps the column instead, its weight is zero).  Their loads are
+    // issued here, ahead of stage 0, so that the global latencies overlap.
+    int pos[kMipIters], a0[kMipIters], a1[kMipIters];
     uint32_t cxp[kMipIters];                   // the two 11-bit x weights, packed as loaded (c0 | c1 << 16)
     uint32_t c0ys[kMipIters], c1ys[kMipIters];  // the y weights << 12: (w * (t >> 4)) >> 16 == mul_hi_u24(t & ~15, w << 12)
 #pragma unroll
-    for (int u = 0; u < kMipIters; ++u) pos[u] = a.mip_pos[min(lane + 64 * u, a.mip_stride - 1)];
+    for (int u = 0; u < kMipIters; ++u) pos[u] = kOffP19 + wave * kP19Wave + a.mip_pos[min(lane + 64 * u, a.mip_stride - 1)];
     auto load_samples = [&](int L) {
         const MipSample *tab = a.mip_samples + (int64_t)L * a.mip_stride;
 #pragma unroll
@@ -414,11 +455,6 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
             const int frame = (lane + 64 * u) < a.mip_n_cur ? kOffCur : kOffPrev;
             a0[u] = frame + sm.off00;
             a1[u] = frame + sm.off10;
-            e0[u] = frame + sm.off01;
-            e1[u] = frame + sm.off11;
-            // The four bytes are fetched with four ds_read_u8.  Hide from the optimiser that e = a + 1 in most
-            // lanes: it would fuse the pairs into ds_read_u16 at odd addresses, which the LDS replays slowly.
-            asm volatile("" : "+v"(e0[u]), "+v"(e1[u]));
             cxp[u] = (uint32_t)(uint16_t)sm.c0x | (uint32_t)(uint16_t)sm.c1x << 16;
             c0ys[u] = (uint32_t)(uint16_t)sm.c0y << 12;
             c1ys[u] = (uint32_t)(uint16_t)sm.c1y << 12;
@@ -430,35 +466,33 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
         load_samples(tile_L);
     }
 
-    // ================= stage 0: gray tiles (tile + 8-px rim), 8 bytes per lane; all loads first, then the stores.
+    // ================= stage 0: gray tiles (tile + 8-px rim), 16 bytes per lane; all loads first, then the stores.
     // The first batch's keypoint records ride along.
     {
-        uint2 c[kGrayIters], p[kGrayIters];
+        Px16 v[kGrayIters];
 #pragma unroll
         for (int u = 0; u < kGrayIters; ++u) {
             const int t = tid + u * kTileThreads;
-            const int r = t / (kTileCW / 8), q = t - r * (kTileCW / 8);
-            const int gy = cy0 + r, gx = cx0 + 8 * q;
+            const int fr = t >= kGrayTasks / 2 ? 1 : 0, tt = t - fr * (kGrayTasks / 2);
+            const int r = tt / (kTileCW / 16), q = tt - r * (kTileCW / 16);
+            const int gy = cy0 + r, gx = cx0 + 16 * q;
             const bool row_ok = t < kGrayTasks && gy >= 0 && gy < H;
             const int64_t ro = (int64_t)gy * a.f.row_stride;
-            c[u] = load_px8(cur + ro, gx, W, row_ok, fast8);
-            p[u] = load_px8(prev + ro, gx, W, row_ok, fast8);
+            v[u] = load_px16((fr ? prev : cur) + ro, gx, W, row_ok, fast8);
         }
         make_records(0, min(kBatch, n_tile_kp));
 #pragma unroll
         for (int u = 0; u < kGrayIters; ++u) {
             const int t = tid + u * kTileThreads;
-            if (t < kGrayTasks) {
-                reinterpret_cast<uint2 *>(s_cur)[t] = c[u];
-                reinterpret_cast<uint2 *>(s_prev)[t] = p[u];
-            }
+            if (t < kGrayTasks)  // cur tile, then prev tile: contiguous in LDS
+                reinterpret_cast<uint4 *>(lds + kOffCur)[t] = make_uint4(v[u].w[0], v[u].w[1], v[u].w[2], v[u].w[3]);
         }
     }
     __syncthreads();  TILE_STAMP(0);
 
     // ================= stage 1: MIP
     {
-        uint8_t *p19 = lds + kOffP19;
+        uint8_t *p19 = lds + kOffP19 + wave * kP19Wave;  // this wave's two pairs of 19x19 buffers
         // per-lane constants of the bit pass: lane = 8*centre + offset (MoFREAKUtilities.cpp:56-70, 308-316)
         const int mc = lane >> 3, mi = lane & 7;
         const int mcx = (0xDDD99555u >> (4 * mc)) & 15, mcy = (0xD95D5D95u >> (4 * mc)) & 15;
@@ -487,51 +521,55 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
                             have_L = mm.L;
                             load_samples(mm.L);
                         }
-                        uint8_t *dst = p19 + (h ? kk2 : kk) * (2 * kP19Pad);
 #pragma unroll
                         for (int u = 0; u < kMipIters; ++u) {
-                            const int c0x = (int)(cxp[u] & 0xffffu), c1x = (int)(cxp[u] >> 16);
-                            const int t0 = __mul24((int)lds[a0[u] + mm.roi_off], c0x) + __mul24((int)lds[e0[u] + mm.roi_off], c1x);
-                            const int t1 = __mul24((int)lds[a1[u] + mm.roi_off], c0x) + __mul24((int)lds[e1[u] + mm.roi_off], c1x);
+                            const int b0a = a0[u] + mm.roi_off, b1a = a1[u] + mm.roi_off;
+                            u16x2 r0, r1;
+                            r0.x = ldsv[b0a];
+                            r0.y = ldsv[b0a + 1];
+                            r1.x = ldsv[b1a];
+                            r1.y = ldsv[b1a + 1];
+                            const u16x2 wx = __builtin_bit_cast(u16x2, cxp[u]);
+                            const uint32_t t0 = __builtin_amdgcn_udot2(r0, wx, 0u, false), t1 = __builtin_amdgcn_udot2(r1, wx, 0u, false);
                             const int px = resize_y(t0, t1, c0ys[u], c1ys[u]);
-                            if (lane + 64 * u < a.mip_n) dst[pos[u]] = (uint8_t)px;
+                            if (lane + 64 * u < a.mip_n) lds[pos[u] + h * (2 * kP19Pad)] = (uint8_t)px;
                         }
                     }
                 } else {
-                    int s00[2][kMipIters], s01[2][kMipIters], s10[2][kMipIters], s11[2][kMipIters];
+                    u16x2 r0[2][kMipIters], r1[2][kMipIters];
 #pragma unroll
                     for (int u = 0; u < kMipIters; ++u) {
-                        s00[0][u] = lds[a0[u] + m.roi_off];
-                        s01[0][u] = lds[e0[u] + m.roi_off];
-                        s10[0][u] = lds[a1[u] + m.roi_off];
-                        s11[0][u] = lds[e1[u] + m.roi_off];
-                        s00[1][u] = lds[a0[u] + m2.roi_off];
-                        s01[1][u] = lds[e0[u] + m2.roi_off];
-                        s10[1][u] = lds[a1[u] + m2.roi_off];
-                        s11[1][u] = lds[e1[u] + m2.roi_off];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int roi = h ? m2.roi_off : m.roi_off;
+                            const int b0a = a0[u] + roi, b1a = a1[u] + roi;
+                            r0[h][u].x = ldsv[b0a];
+                            r0[h][u].y = ldsv[b0a + 1];
+                            r1[h][u].x = ldsv[b1a];
+                            r1[h][u].y = ldsv[b1a + 1];
+                        }
                     }
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        uint8_t *dst = p19 + (h ? kk2 : kk) * (2 * kP19Pad);
 #pragma unroll
                         for (int u = 0; u < kMipIters; ++u) {
-                            // every factor fits 24 bits: full-rate v_mul_i32_i24 / v_mad_i32_i24
-                            const int c0x = (int)(cxp[u] & 0xffffu), c1x = (int)(cxp[u] >> 16);
-                            const int t0 = __mul24(s00[h][u], c0x) + __mul24(s01[h][u], c1x);
-                            const int t1 = __mul24(s10[h][u], c0x) + __mul24(s11[h][u], c1x);
+                            const u16x2 wx = __builtin_bit_cast(u16x2, cxp[u]);
+                            const uint32_t t0 = __builtin_amdgcn_udot2(r0[h][u], wx, 0u, false);
+                            const uint32_t t1 = __builtin_amdgcn_udot2(r1[h][u], wx, 0u, false);
                             const int px = resize_y(t0, t1, c0ys[u], c1ys[u]);
-                            if ((h == 0 || two) && lane + 64 * u < a.mip_n) dst[pos[u]] = (uint8_t)px;
+                            if ((h == 0 || two) && lane + 64 * u < a.mip_n) lds[pos[u] + h * (2 * kP19Pad)] = (uint8_t)px;
                         }
                     }
                 }
                 wave_lds_sync();
                 // the two 9-byte strips sit at arbitrary byte offsets: fetch the covering aligned dwords (a byte-wise
                 // formulation lets the compiler fuse the loads into misaligned ds_read_b64s, 64 cycles each) and
-                // shift the strips out; SSD = sum c^2 + sum p^2 - 2 sum c*p with packed u8 dot products
+                // shift the strips out; SSD = sum c^2 + sum p^2 - 2 sum c*p over the first eight bytes (packed u8
+                // dot products) + the ninth byte's squared difference
                 uint32_t cd[2][3], pd[2][3];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const uint32_t *b32 = reinterpret_cast<const uint32_t *>(p19 + ((h && two) ? kk2 : kk) * (2 * kP19Pad));
+                    const uint32_t *b32 = reinterpret_cast<const uint32_t *>(p19 + ((h && two) ? 2 * kP19Pad : 0));
 #pragma unroll
                     for (int w3 = 0; w3 < 3; ++w3) {
                         cd[h][w3] = b32[cw + w3];
@@ -541,267 +579,260 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const uint32_t c0 = __builtin_amdgcn_alignbyte(cd[h][1], cd[h][0], cs), c1 = __builtin_amdgcn_alignbyte(cd[h][2], cd[h][1], cs);
-                    const uint32_t c2 = (cd[h][2] >> (8 * cs)) & 0xffu;
                     const uint32_t p0 = __builtin_amdgcn_alignbyte(pd[h][1], pd[h][0], ps), p1 = __builtin_amdgcn_alignbyte(pd[h][2], pd[h][1], ps);
-                    const uint32_t p2 = (pd[h][2] >> (8 * ps)) & 0xffu;
-                    const uint32_t sq = __builtin_amdgcn_udot4(c0, c0, __builtin_amdgcn_udot4(c1, c1, c2 * c2, false), false) +
-                                        __builtin_amdgcn_udot4(p0, p0, __builtin_amdgcn_udot4(p1, p1, p2 * p2, false), false);
-                    const uint32_t cross = __builtin_amdgcn_udot4(c0, p0, __builtin_amdgcn_udot4(c1, p1, c2 * p2, false), false);
+                    const int d8 = (int)((cd[h][2] >> (8 * cs)) & 0xffu) - (int)((pd[h][2] >> (8 * ps)) & 0xffu);
+                    const uint32_t sq = __builtin_amdgcn_udot4(c0, c0, __builtin_amdgcn_udot4(c1, c1, (uint32_t)__mul24(d8, d8), false), false) +
+                                        __builtin_amdgcn_udot4(p0, p0, __builtin_amdgcn_udot4(p1, p1, 0u, false), false);
+                    const uint32_t cross = __builtin_amdgcn_udot4(c0, p0, __builtin_amdgcn_udot4(c1, p1, 0u, false), false);
                     const int ssd = (int)(sq - 2u * cross);
-                    const uint64_t mot = __ballot(ssd > st.mip_theta);
-                    if (lane == 0 && (h == 0 || two)) s_mot[h ? kk2 : kk] = make_uint2((uint32_t)mot, (uint32_t)(mot >> 32));
+                    const uint64_t mot = __ballot(ssd > mip_theta);
+                    if (lane == 0 && (h == 0 || two)) {
+                        const uint2 mv = make_uint2((uint32_t)mot, (uint32_t)(mot >> 32));
+                        if (one_batch)  // kept for one 16-byte store per descriptor at the end of stage 3
+                            s_mot[h ? kk2 : kk] = mv;
+                        else  // a crowded tile (several batches) sends its motion bytes out now
+                            *reinterpret_cast<uint2 *>(a.out_desc + (out_base + (h ? m2.g : m.g)) * 16 + 8) = mv;
+                    }
                 }
+                wave_lds_sync();  // the next pair of keypoints overwrites the 19x19 buffers
             }
-            __syncthreads();  TILE_STAMP(5);
-            // a crowded tile (several batches) sends its motion bytes out now; the usual single batch keeps them in
-            // LDS for one 16-byte store per descriptor at the end of stage 3
-            if (!one_batch && tid < nb) *reinterpret_cast<uint2 *>(a.out_desc + (out_base + km[tid].g) * 16 + 8) = s_mot[tid];
         }
     }
+    __syncthreads();  TILE_STAMP(1);
 
-    // ================= stage 2: integral of |cur - prev| over tile + halo, in LDS
-    // Two blocked scans, each keeping its values in registers across the carry exchange, so that every pixel costs
-    // one LDS write (row pass) plus one read and one write (column pass).
+    // ================= stage 2: integral of |cur - prev| over tile + halo, modulo 2^16, in LDS
     {
-        int32_t *carry = reinterpret_cast<int32_t *>(scratch);  // run totals, then block totals; then their prefixes
-        // 2a: row pass.  A thread owns 16-pixel runs: |cur - prev| and the running sum inside the run (v_sad_u8 on
-        //     masked dwords), run total -> LDS.
-        int4 rv[kRunIters][4];
-        {
-            uint4 c[kRunIters], p[kRunIters];
+        // 2a: row pass, no workgroup barrier.  The 16 lanes of a DPP row share one region row: a lane owns 16 pixels,
+        //     |cur - prev| and the running sum inside them come from v_sad_u8 on masked dwords, the lane totals are
+        //     scanned across the row with four DPP adds.  A wave takes four region rows per step.
+        const int runs = RW >> 4;
+        const int rr = lane >> 4, q = lane & 15;
+        Px16 c[kRowGroupIters], p[kRowGroupIters];
 #pragma unroll
-            for (int u = 0; u < kRunIters; ++u) {
-                const int t = tid + u * kTileThreads;
-                const int r = run_row(t), q = run_col(t);
-                const int gy = oy + r, gx = ox + 16 * q;
-                const bool row_ok = t < kTileRH * kRunsPerRow && gy >= 0 && gy < H;
-                const int64_t ro = (int64_t)gy * a.f.row_stride;
-                c[u] = load_px16(cur + ro, gx, W, row_ok, fast16);
-                p[u] = load_px16(prev + ro, gx, W, row_ok, fast16);
+        for (int u = 0; u < kRowGroupIters; ++u) {
+            const int r = 4 * (wave + kTileWaves * u) + rr;
+            const int gy = oy + r, gx = ox + 16 * q;
+            const bool row_ok = r < RH && q < runs && gy >= 0 && gy < H;
+            const int64_t ro = (int64_t)gy * a.f.row_stride;
+            c[u] = load_px16(cur + ro, gx, W, row_ok, fast8);
+            p[u] = load_px16(prev + ro, gx, W, row_ok, fast8);
+        }
+        for (int i = tid; i < kIPitchDw; i += kTileThreads) reinterpret_cast<uint32_t *>(lds + kOffIntegral)[i] = 0;  // integral row 0
+#pragma unroll
+        for (int u = 0; u < kRowGroupIters; ++u) {
+            const int r = 4 * (wave + kTileWaves * u) + rr;
+            uint32_t pk[8];
+            uint32_t acc = 0;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                const uint32_t x = c[u].w[w4], y = p[u].w[w4];
+                const uint32_t s0 = __builtin_amdgcn_sad_u8(x & 0xffu, y & 0xffu, acc);
+                const uint32_t s1 = __builtin_amdgcn_sad_u8(x & 0xffffu, y & 0xffffu, acc);
+                const uint32_t s2 = __builtin_amdgcn_sad_u8(x & 0xffffffu, y & 0xffffffu, acc);
+                acc = __builtin_amdgcn_sad_u8(x, y, acc);
+                pk[2 * w4] = __builtin_amdgcn_perm(s1, s0, 0x05040100u);      // low halves: s0 | s1 << 16
+                pk[2 * w4 + 1] = __builtin_amdgcn_perm(acc, s2, 0x05040100u);
             }
-#pragma unroll
-            for (int u = 0; u < kRunIters; ++u) {
-                const uint32_t cw4[4] = {c[u].x, c[u].y, c[u].z, c[u].w}, pw4[4] = {p[u].x, p[u].y, p[u].z, p[u].w};
-                uint32_t acc = 0;
-#pragma unroll
-                for (int w4 = 0; w4 < 4; ++w4) {
-                    const uint32_t x = cw4[w4], y = pw4[w4];
-                    rv[u][w4].x = (int)__builtin_amdgcn_sad_u8(x & 0xffu, y & 0xffu, acc);
-                    rv[u][w4].y = (int)__builtin_amdgcn_sad_u8(x & 0xffffu, y & 0xffffu, acc);
-                    rv[u][w4].z = (int)__builtin_amdgcn_sad_u8(x & 0xffffffu, y & 0xffffffu, acc);
-                    acc = __builtin_amdgcn_sad_u8(x, y, acc);
-                    rv[u][w4].w = (int)acc;
-                }
-                const int t = tid + u * kTileThreads;
-                if (t < kTileRH * kRunsPerRow) carry[run_row(t) * kRunsPerRow + run_col(t)] = (int)acc;
+            int incl = (int)acc;  // inclusive scan of the lane totals across the region row (16 x 255 x 12 < 2^16)
+            incl += dpp_row_shr(incl, 1);
+            incl += dpp_row_shr(incl, 2);
+            incl += dpp_row_shr(incl, 4);
+            incl += dpp_row_shr(incl, 8);
+            const uint32_t excl = (uint32_t)incl - acc;
+            const uint32_t carry2 = __builtin_amdgcn_perm(excl, excl, 0x05040504u);  // low half in both halves
+            if (r < RH && q < runs) {
+                uint8_t *row = lds + kOffIntegral + (r + 1) * (kIPitch * 2);
+                uint4 *dst = reinterpret_cast<uint4 *>(row + (8 + 16 * q) * 2);
+                dst[0] = make_uint4(pk_add_u16(pk[0], carry2), pk_add_u16(pk[1], carry2), pk_add_u16(pk[2], carry2), pk_add_u16(pk[3], carry2));
+                dst[1] = make_uint4(pk_add_u16(pk[4], carry2), pk_add_u16(pk[5], carry2), pk_add_u16(pk[6], carry2), pk_add_u16(pk[7], carry2));
+                if (q == 0) *reinterpret_cast<uint32_t *>(row + (kIColOff - 1) * 2) = 0;  // logical column 0
             }
         }
-        for (int i = tid; i < kIP; i += kTileThreads) I[i] = 0;                                    // integral row 0
-        for (int r = tid; r <= kTileRH; r += kTileThreads) I[r * kIP + kIntegralColOffset] = 0;     // logical column 0
-        __syncthreads();  TILE_STAMP(6);
-        // 2b: per row, exclusive prefix of its 12 run totals (in place)
-        if (tid < kTileRH) {
-            int tot[kRunsPerRow];
-#pragma unroll
-            for (int q = 0; q < kRunsPerRow; ++q) tot[q] = carry[tid * kRunsPerRow + q];
-            int run = 0;
-#pragma unroll
-            for (int q = 0; q < kRunsPerRow; ++q) {
-                carry[tid * kRunsPerRow + q] = run;
-                run += tot[q];
-            }
-        }
-        __syncthreads();  TILE_STAMP(7);
-        // 2c: finish the row pass: add the run's carry, one 16-byte LDS store per 4 pixels
-#pragma unroll
-        for (int u = 0; u < kRunIters; ++u) {
-            const int t = tid + u * kTileThreads;
-            if (t < kTileRH * kRunsPerRow) {
-                const int r = run_row(t), q = run_col(t);
-                const int add = carry[r * kRunsPerRow + q];
-                int4 *dst = reinterpret_cast<int4 *>(I + (r + 1) * kIP + 4 + 16 * q);
-#pragma unroll
-                for (int w4 = 0; w4 < 4; ++w4)
-                    dst[w4] = make_int4(rv[u][w4].x + add, rv[u][w4].y + add, rv[u][w4].z + add, rv[u][w4].w + add);
-            }
-        }
-        __syncthreads();  TILE_STAMP(8);
-        // 2d: column pass.  A thread owns 20-row column segments: running sum in registers, segment total -> LDS
-        constexpr int kColTasks = kColBlocks * kTileRW;
-        constexpr int kColIters = (kColTasks + kTileThreads - 1) / kTileThreads;
-        int cv[kColIters][kColBlockRows];
+        __syncthreads();  TILE_STAMP(2);
+        // 2b: column pass.  A thread owns a 16-row segment of one dword column (two pixels): running packed sums in
+        //     registers, segment total -> LDS; after the barrier it adds the totals of the segments above.
+        const int n_dcols = RW >> 1, n_blocks = RH / kColBlockRows;
+        const uint32_t m20 = (1u << 20) / (uint32_t)n_dcols + 1;  // t / n_dcols for t < 2^10 as (t * m20) >> 20
+        uint32_t *carry = reinterpret_cast<uint32_t *>(scratch);  // [block][kMaxDcols]
+        uint32_t cv[kColIters][kColBlockRows];
 #pragma unroll
         for (int u = 0; u < kColIters; ++u) {
-            const int t = min(tid + u * kTileThreads, kColTasks - 1);
-            const int j = t / kTileRW, c = t - j * kTileRW;  // logical column c + 1
-            const int32_t *e = I + (j * kColBlockRows + 1) * kIP + kIntegralColOffset + 1 + c;
+            const int t = tid + u * kTileThreads;
+            const bool ok = t < n_blocks * n_dcols;
+            const int j = ok ? (int)(((uint32_t)t * m20) >> 20) : 0, cc = ok ? t - j * n_dcols : 0;
+            const uint32_t *e = reinterpret_cast<const uint32_t *>(lds + kOffIntegral) + (j * kColBlockRows + 1) * kIPitchDw + (kIColOff + 1) / 2 + cc;
 #pragma unroll
-            for (int r = 0; r < kColBlockRows; ++r) cv[u][r] = e[r * kIP];
-            int acc = 0;
+            for (int r = 0; r < kColBlockRows; ++r) cv[u][r] = e[r * kIPitchDw];
+            uint32_t acc = 0;
 #pragma unroll
             for (int r = 0; r < kColBlockRows; ++r) {
-                acc += cv[u][r];
+                acc = pk_add_u16(acc, cv[u][r]);
                 cv[u][r] = acc;
             }
-            if (tid + u * kTileThreads < kColTasks) carry[t] = acc;
+            if (ok) carry[j * kMaxDcols + cc] = acc;
         }
-        __syncthreads();  TILE_STAMP(9);
-        // 2e: per column, exclusive prefix of its 8 segment totals (in place)
-        if (tid < kTileRW) {
-            int tot[kColBlocks];
-#pragma unroll
-            for (int j = 0; j < kColBlocks; ++j) tot[j] = carry[j * kTileRW + tid];
-            int run = 0;
-#pragma unroll
-            for (int j = 0; j < kColBlocks; ++j) {
-                carry[j * kTileRW + tid] = run;
-                run += tot[j];
-            }
-        }
-        __syncthreads();  TILE_STAMP(10);
-        // 2f: finish the column pass
+        __syncthreads();  TILE_STAMP(3);
 #pragma unroll
         for (int u = 0; u < kColIters; ++u) {
             const int t = tid + u * kTileThreads;
-            if (t < kColTasks) {
-                const int j = t / kTileRW, c = t - j * kTileRW;
-                const int add = carry[t];
-                int32_t *e = I + (j * kColBlockRows + 1) * kIP + kIntegralColOffset + 1 + c;
+            if (t < n_blocks * n_dcols) {
+                const int j = (int)(((uint32_t)t * m20) >> 20), cc = t - j * n_dcols;
+                uint32_t tot[kMaxColBlocks - 1];
 #pragma unroll
-                for (int r = 0; r < kColBlockRows; ++r) e[r * kIP] = cv[u][r] + add;
+                for (int jj = 0; jj < kMaxColBlocks - 1; ++jj) tot[jj] = carry[jj * kMaxDcols + cc];
+                uint32_t add = 0;
+#pragma unroll
+                for (int jj = 0; jj < kMaxColBlocks - 1; ++jj) add = pk_add_u16(add, jj < j ? tot[jj] : 0u);
+                uint32_t *e = reinterpret_cast<uint32_t *>(lds + kOffIntegral) + (j * kColBlockRows + 1) * kIPitchDw + (kIColOff + 1) / 2 + cc;
+#pragma unroll
+                for (int r = 0; r < kColBlockRows; ++r) e[r * kIPitchDw] = pk_add_u16(cv[u][r], add);
             }
         }
-        __syncthreads();  TILE_STAMP(11);
+        __syncthreads();  TILE_STAMP(4);
     }
 
-    // ================= stage 3: FREAK on the difference image
+    // ================= stage 3: FREAK on the difference image, one wave per group of four keypoints
     {
-        uint8_t *vv = scratch;                                             // [kBatch][kVStride] box means
+        uint8_t *vv = scratch + wave * (kGroup * kVStride);   // this wave's box means [kGroup][kVStride]
+        const int ibase = kOffIntegral + 2 * (kIColOff - oy * kIPitch - ox);
+        // box-mean tasks of a group: the outer two rings (whose boxes may need slices) of all four keypoints first
+        int task_kq[kBoxIters], task_p[kBoxIters];
+#pragma unroll
+        for (int u = 0; u < kBoxIters; ++u) {
+            const int t = lane + 64 * u;
+            if (t < kGroup * kBigPoints) {
+                task_kq[u] = t / kBigPoints;
+                task_p[u] = t % kBigPoints;
+            } else {
+                const int t2 = t - kGroup * kBigPoints;
+                task_kq[u] = t2 / (kNbPoints - kBigPoints);
+                task_p[u] = kBigPoints + t2 % (kNbPoints - kBigPoints);
+            }
+            if (t >= kGroup * kNbPoints) task_kq[u] = -1;
+        }
+        // orientation pass: 16 lanes per keypoint, three of the 45 pairs each; weights as floats (w / 2048 is exact, and
+        // so is its product with a difference of two bytes), truncated like the reference's integer division
+        const int oq = lane >> 4, osub = lane & 15;
+        int opi[3], opj[3];
+        float owx[3], owy[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int m = osub + 16 * k;
+            const OrientPair op = st->orient[min(m, kNbOrientPairs - 1)];
+            opi[k] = op.i;
+            opj[k] = op.j;
+            owx[k] = m < kNbOrientPairs ? (float)op.weight_dx * (1.0f / 2048.0f) : 0.0f;
+            owy[k] = m < kNbOrientPairs ? (float)op.weight_dy * (1.0f / 2048.0f) : 0.0f;
+        }
+        const int pi = st->bit_pair_i[lane], pj = st->bit_pair_j[lane];
+        PatternPoint P0[kBoxIters];   // un-rotated pattern points of this lane's tasks, cached per scale index
+        int have_idx = -1;
+
         for (int b0 = 0; b0 < n_tile_kp; b0 += kBatch) {
             const int nb = min(kBatch, n_tile_kp - b0);
             if (!one_batch) {  // crowded tile: the records of this batch (a single batch still has them from stage 0;
-                __syncthreads();  // km is rewritten too, harmlessly: the scratch area is free between batches)
+                __syncthreads();  // km is rewritten too, harmlessly: the scratch area's head is free between batches)
                 make_records(b0, nb);
                 __syncthreads();
             }
-            const int n_box = nb * kNbPoints;
-            if (st.orientation_normalized) {
-                // F1: un-rotated box means; pattern points fetched for all of a thread's tasks before any is used
+            for (int kbase = wave * kGroup; kbase < nb; kbase += kGroup * kTileWaves) {
+                KpFreak rec[kBoxIters];
+                bool t_ok[kBoxIters];
+#pragma unroll
+                for (int u = 0; u < kBoxIters; ++u) {
+                    t_ok[u] = task_kq[u] >= 0 && kbase + task_kq[u] < nb;
+                    rec[u] = kf[t_ok[u] ? kbase + task_kq[u] : kbase];
+                }
+                if (orientation_normalized) {
+                    // F1: un-rotated box means
+#pragma unroll
+                    for (int u = 0; u < kBoxIters; ++u) {
+                        if (rec[u].idx != have_idx)  // (per lane: all of a lane's tasks see the same scale in the usual case)
+                            P0[u] = a.lut[(int64_t)rec[u].idx * kNbOrientation * kNbPoints + task_p[u]];
+                    }
+                    have_idx = rec[kBoxIters - 1].idx == rec[0].idx && rec[1].idx == rec[0].idx ? rec[0].idx : -1;
+#pragma unroll
+                    for (int u = 0; u < kBoxIters; ++u) {
+                        if (t_ok[u])
+                            vv[task_kq[u] * kVStride + task_p[u]] = (uint8_t)mean_intensity_tile(lds, ibase, rec[u].kx, rec[u].ky, P0[u]);
+                    }
+                    wave_lds_sync();
+                    // F2: orientation sums, theta
+                    {
+                        const uint8_t *v = vv + oq * kVStride;
+                        int direction0 = 0, direction1 = 0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const float delta = (float)((int)v[opi[k]] - (int)v[opj[k]]);
+                            direction0 += (int)(delta * owx[k]);  // C division by 2048: truncates toward zero, per term
+                            direction1 += (int)(delta * owy[k]);
+                        }
+                        direction0 = row16_sum(direction0);
+                        direction1 = row16_sum(direction1);
+                        const int theta = theta_index(s_theta, direction0, direction1);
+                        if (osub == 0 && kbase + oq < nb) {
+                            kf[kbase + oq].theta = (int16_t)theta;
+                            if (a.out_info)
+                                *reinterpret_cast<int4 *>(a.out_info + (out_base + kf[kbase + oq].g) * 4) =
+                                    make_int4(kf[kbase + oq].idx, theta, direction0, direction1);
+                        }
+                    }
+                    wave_lds_sync();
+                } else if (a.out_info && lane < kGroup && kbase + lane < nb) {
+                    *reinterpret_cast<int4 *>(a.out_info + (out_base + kf[kbase + lane].g) * 4) = make_int4(kf[kbase + lane].idx, 0, 0, 0);
+                }
+                // F3: box means of the rotated pattern
                 {
                     PatternPoint P[kBoxIters];
-                    float kx[kBoxIters], ky[kBoxIters];
 #pragma unroll
                     for (int u = 0; u < kBoxIters; ++u) {
-                        const int t = min(tid + u * kTileThreads, n_box - 1);
-                        const int kk = t / kNbPoints, p = t - kk * kNbPoints;
-                        const KpFreak k = kf[kk];
-                        kx[u] = k.kx;
-                        ky[u] = k.ky;
-                        P[u] = a.lut[(int64_t)k.idx * kNbOrientation * kNbPoints + p];
+                        const int theta = kf[t_ok[u] ? kbase + task_kq[u] : kbase].theta;
+                        P[u] = a.lut[((int64_t)rec[u].idx * kNbOrientation + theta) * kNbPoints + task_p[u]];
                     }
 #pragma unroll
                     for (int u = 0; u < kBoxIters; ++u) {
-                        const int t = tid + u * kTileThreads;
-                        if (t < n_box) {
-                            const int kk = t / kNbPoints, p = t - kk * kNbPoints;
-                            vv[kk * kVStride + p] = (uint8_t)mean_intensity_tile(I, ox, oy, kx[u], ky[u], P[u]);
+                        if (t_ok[u])
+                            vv[task_kq[u] * kVStride + task_p[u]] = (uint8_t)mean_intensity_tile(lds, ibase, rec[u].kx, rec[u].ky, P[u]);
+                    }
+                }
+                wave_lds_sync();
+                // F4: lane = descriptor bit; lane q stores keypoint q's descriptor
+                {
+                    int va[kGroup], vb[kGroup];
+#pragma unroll
+                    for (int qq = 0; qq < kGroup; ++qq) {
+                        va[qq] = vv[qq * kVStride + pi];
+                        vb[qq] = vv[qq * kVStride + pj];
+                    }
+                    uint2 app = make_uint2(0, 0);
+#pragma unroll
+                    for (int qq = 0; qq < kGroup; ++qq) {
+                        bool bit;
+                        if (bit_mode == MOFREAK_BITS_SSE)
+                            bit = va[qq] >= vb[qq];
+                        else if (bit_mode == MOFREAK_BITS_NATURAL)
+                            bit = va[qq] > vb[qq];
+                        else
+                            bit = (int)(int8_t)va[qq] > (int)(int8_t)vb[qq];
+                        const uint64_t bits = __ballot(bit);
+                        if (lane == qq) app = make_uint2((uint32_t)bits, (uint32_t)(bits >> 32));
+                    }
+                    if (lane < kGroup && kbase + lane < nb) {  // descriptor and validity flag out, side by side
+                        const int64_t out_idx = out_base + kf[kbase + lane].g;
+                        if (one_batch) {
+                            const uint2 mot = s_mot[kbase + lane];
+                            *reinterpret_cast<uint4 *>(a.out_desc + out_idx * 16) = make_uint4(app.x, app.y, mot.x, mot.y);
+                        } else {
+                            *reinterpret_cast<uint2 *>(a.out_desc + out_idx * 16) = app;
                         }
+                        a.out_valid[out_idx] = 1;
                     }
                 }
-                __syncthreads();  TILE_STAMP(13);
-                // F2: 8 lanes per keypoint share the 45 orientation pairs; theta
-                for (int t = tid; t < nb * kOrientLanes; t += kTileThreads) {
-                    const int kk = t / kOrientLanes, sub = t % kOrientLanes;
-                    const uint8_t *v = vv + kk * kVStride;
-                    int direction0 = 0, direction1 = 0;
-#pragma unroll
-                    for (int m0 = 0; m0 < kNbOrientPairs; m0 += kOrientLanes) {
-                        const int m = m0 + sub;
-                        if (m < kNbOrientPairs) {
-                            const OrientPair op = st.orient[m];
-                            const int delta = (int)v[op.i] - (int)v[op.j];
-                            direction0 += __mul24(delta, op.weight_dx) / 2048;  // C division: truncates toward zero, per term
-                            direction1 += __mul24(delta, op.weight_dy) / 2048;
-                        }
-                    }
-#pragma unroll
-                    for (int o = 1; o < kOrientLanes; o <<= 1) {
-                        direction0 += __shfl_xor(direction0, o);
-                        direction1 += __shfl_xor(direction1, o);
-                    }
-                    const int theta = theta_index(s_theta, direction0, direction1);
-                    if (sub == 0) {
-                        kf[kk].theta = (int16_t)theta;
-                        if (a.out_info)
-                            *reinterpret_cast<int4 *>(a.out_info + (out_base + kf[kk].g) * 4) = make_int4(kf[kk].idx, theta, direction0, direction1);
-                    }
-                }
-                __syncthreads();  TILE_STAMP(14);
-            } else if (a.out_info && tid < nb) {
-                *reinterpret_cast<int4 *>(a.out_info + (out_base + kf[tid].g) * 4) = make_int4(kf[tid].idx, 0, 0, 0);
-            }
-            // F3: box means of the rotated pattern
-            {
-                PatternPoint P[kBoxIters];
-                float kx[kBoxIters], ky[kBoxIters];
-#pragma unroll
-                for (int u = 0; u < kBoxIters; ++u) {
-                    const int t = min(tid + u * kTileThreads, n_box - 1);
-                    const int kk = t / kNbPoints, p = t - kk * kNbPoints;
-                    const KpFreak k = kf[kk];
-                    kx[u] = k.kx;
-                    ky[u] = k.ky;
-                    P[u] = a.lut[((int64_t)k.idx * kNbOrientation + k.theta) * kNbPoints + p];
-                }
-#pragma unroll
-                for (int u = 0; u < kBoxIters; ++u) {
-                    const int t = tid + u * kTileThreads;
-                    if (t < n_box) {
-                        const int kk = t / kNbPoints, p = t - kk * kNbPoints;
-                        vv[kk * kVStride + p] = (uint8_t)mean_intensity_tile(I, ox, oy, kx[u], ky[u], P[u]);
-                    }
-                }
-            }
-            __syncthreads();  TILE_STAMP(15);
-            // F4: lane = descriptor bit
-            {
-                const int pi = st.bit_pair_i[lane], pj = st.bit_pair_j[lane];
-                constexpr int kBitIters = (kBatch + kTileWaves - 1) / kTileWaves;
-                int va[kBitIters], vb[kBitIters];
-#pragma unroll
-                for (int u = 0; u < kBitIters; ++u) {  // clamped, unguarded: the byte pairs of all the wave's keypoints in flight
-                    const uint8_t *v = vv + min(wave + u * kTileWaves, nb - 1) * kVStride;
-                    va[u] = v[pi];
-                    vb[u] = v[pj];
-                }
-#pragma unroll
-                for (int u = 0; u < kBitIters; ++u) {
-                    const int kk = wave + u * kTileWaves;
-                    bool bit;
-                    if (st.bit_mode == MOFREAK_BITS_SSE)
-                        bit = va[u] >= vb[u];
-                    else if (st.bit_mode == MOFREAK_BITS_NATURAL)
-                        bit = va[u] > vb[u];
-                    else
-                        bit = (int)(int8_t)va[u] > (int)(int8_t)vb[u];
-                    const uint64_t app = __ballot(bit);
-                    if (lane == 0 && kk < nb) s_bits[kk] = make_uint2((uint32_t)app, (uint32_t)(app >> 32));
-                }
-            }
-            __syncthreads();  TILE_STAMP(16);
-            if (tid < nb) {  // descriptor and validity flag out, side by side
-                const int64_t out_idx = out_base + kf[tid].g;
-                const uint2 app = s_bits[tid];
-                if (one_batch) {
-                    const uint2 mot = s_mot[tid];
-                    *reinterpret_cast<uint4 *>(a.out_desc + out_idx * 16) = make_uint4(app.x, app.y, mot.x, mot.y);
-                } else {
-                    *reinterpret_cast<uint2 *>(a.out_desc + out_idx * 16) = app;
-                }
-                a.out_valid[out_idx] = 1;
+                wave_lds_sync();  // the next group overwrites the box means
             }
         }
     }
+    TILE_STAMP(5);
     if (STAMPS && tid == 0)
         for (int i = 0; i < kTileStampSlots; ++i)
             if (s_stamps[i]) atomicAdd(&a.stamps[i], s_stamps[i]);
@@ -821,6 +852,8 @@ int launch_bin(const BinArgs &a, void *stream)
     e = hipMemsetAsync(a.tile_lmax, 0, (size_t)a.n_keys * sizeof(uint32_t), s);
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(a.slow_count, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(a.max_ps, 0, sizeof(int32_t), s);
     if (e != hipSuccess) return (int)e;
     const int blocks = (int)((a.n_kp + 255) / 256);
     if (blocks > 0) hipLaunchKernelGGL(bin_count_kernel, dim3(blocks), dim3(256), 0, s, a);
