@@ -97,27 +97,39 @@ __device__ __forceinline__ int mean_intensity(const int32_t *__restrict__ integ,
 // its direction (cos, sin) in double.  Which side of a step an INTEGER direction lies on is the sign of a cross
 // product, evaluated in double: the product's rounding error (~1e-12 at these magnitudes) is orders of magnitude
 // below the smallest cross product an integer direction can have with a generic angle, so the result is exact and
-// independent of any libm.  7 bisection steps of 2 mul + 1 sub instead of a ~300-instruction double atan2.
-//   tb[0..127]   upper half plane: idx counts the steps with angle >= beta_k
-//   tb[128..254] lower half plane: idx = 256 - (steps with |angle| > mu_m)
+// independent of any libm.
+//   tb[0..127]   upper half plane: idx counts the steps with angle >= beta_k, beta_k ~ (k - 0.5) * 360/256 degrees
+//   tb[128..254] lower half plane: idx = 256 - (steps with |angle| > mu_m), mu_m ~ (m + 0.5) * 360/256 degrees
+// Which steps to test comes from a cheap single-precision angle (a degree-11 odd polynomial for atan on [0, 1], good
+// to ~1e-5 rad, i.e. 4e-4 of a step): the count it suggests is within one of the true count, so testing the two steps
+// around it decides exactly -- two independent table reads instead of a seven-deep chain of dependent ones.
 __device__ __forceinline__ int theta_index(const ThetaBound *__restrict__ tb, int direction0, int direction1)
 {
     if ((direction0 | direction1) == 0) return 0;  // atan2(0, 0) = 0
     const bool upper = direction1 >= 0;
-    const double y = upper ? (double)direction1 : -(double)direction1, x = (double)direction0;
-    const ThetaBound *t = upper ? tb : tb + 128;
+    const float ax = fabsf((float)direction0), ay = fabsf((float)direction1);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float q = mn * __builtin_amdgcn_rcpf(mx), s = q * q;
+    float r = -0.01172120f;
+    r = __builtin_fmaf(r, s, 0.05265332f);
+    r = __builtin_fmaf(r, s, -0.11643287f);
+    r = __builtin_fmaf(r, s, 0.19354346f);
+    r = __builtin_fmaf(r, s, -0.33262347f);
+    r = __builtin_fmaf(r, s, 0.99997726f);
+    r = r * q;                                   // atan(q), q in [0, 1]
+    if (ay > ax) r = 1.57079632679f - r;
+    if (direction0 < 0) r = 3.14159265359f - r;  // angle of (direction0, |direction1|), in [0, pi]
+    const float pos = r * 40.7436654315f;         // in steps of 360/256 degrees
     const int n = upper ? 128 : 127;
-    int lo = 0, hi = n;  // count = number of leading steps the direction has passed
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        const double cross = y * t[mid].c - x * t[mid].s;
-        const bool passed = upper ? (cross >= 0.0) : (cross > 0.0);
-        if (passed)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    return upper ? lo : (lo == 0 ? 0 : kNbOrientation - lo);
+    const ThetaBound *t = upper ? tb : tb + 128;
+    const int c0 = min(max((int)(upper ? pos + 0.5f : pos), 1), n - 1);  // the suggested count: within one of the true one
+    const double y = (double)(upper ? direction1 : -direction1), x = (double)direction0;
+    const ThetaBound b0 = t[c0 - 1], b1 = t[c0];   // steps number c0 and c0 + 1
+    const double cross0 = y * b0.c - x * b0.s, cross1 = y * b1.c - x * b1.s;
+    const bool p0 = upper ? (cross0 >= 0.0) : (cross0 > 0.0);
+    const bool p1 = upper ? (cross1 >= 0.0) : (cross1 > 0.0);
+    const int count = c0 - 1 + (p0 ? 1 : 0) + (p1 ? 1 : 0);  // steps are ordered: passing step c0 + 1 implies passing step c0
+    return upper ? count : (count == 0 ? 0 : kNbOrientation - count);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -193,7 +193,7 @@ int scale_index_from_size(float size, int n_octaves)
 void build_tables(const FreakParams &p, Tables &t)
 {
     // ---- pattern LUT (buildPattern)
-    t.lut.assign(static_cast<size_t>(kNbScales) * kNbOrientation * kNbPoints, PatternPoint{0, 0, 0, 0});
+    t.lut.assign(static_cast<size_t>(kNbScales) * kNbOrientation * kNbPoints, PatternPoint{0, 0, 0, 1});
     const double scale_step = std::pow(2.0, static_cast<double>(p.n_octaves) / kNbScales);
     const int ring_points[8] = {6, 6, 6, 6, 6, 6, 6, 1};
     const double big_r = 2.0 / 3.0, small_r = 2.0 / 24.0;
@@ -220,6 +220,7 @@ void build_tables(const FreakParams &p, Tables &t)
                     row[pt].x = static_cast<float>(radius[ring] * std::cos(alpha) * scaling * p.pattern_scale);
                     row[pt].y = static_cast<float>(radius[ring] * std::sin(alpha) * scaling * p.pattern_scale);
                     row[pt].sigma = static_cast<float>(sigma[ring] * scaling * p.pattern_scale);
+                    row[pt].rows_per_slice = std::max(1, 257 / (static_cast<int>(2.0f * row[pt].sigma) + 3));
                     t.min_sigma = std::min(t.min_sigma, row[pt].sigma);
                     const int size_max =
                         static_cast<int>(std::ceil((radius[ring] + sigma[ring]) * scaling * p.pattern_scale)) + 1;
@@ -312,26 +313,43 @@ void build_tables(const FreakParams &p, Tables &t)
                 for (int k = 0; k < 9; ++k) need_prev[bp + k] = 1;
             }
         }
+        // Sample order for the tile kernel: the needed bytes are covered by aligned dwords of the (cur19 | prev19)
+        // buffer pair; the first 64 dwords go one per lane with byte u in pass u (so that a lane packs its four
+        // results into one 32-bit store), the remaining dwords byte by byte in the last pass.  Bytes of a covering
+        // dword that the MIP never reads are resampled as well (harmless); bytes in a buffer's padding take the last
+        // pixel's sample.
+        std::vector<int> dwords;
+        for (int d = 0; d < 2 * kP19Pad / 4; ++d) {
+            bool any = false;
+            for (int b = 0; b < 4; ++b) {
+                const int byte = 4 * d + b, fr = byte / kP19Pad, i = byte % kP19Pad;
+                if (i < kPatch * kPatch && (fr ? need_prev[i] : need_cur[i])) any = true;
+            }
+            if (any) dwords.push_back(d);
+        }
         t.mip_pos.clear();
-        for (int i = 0; i < kPatch * kPatch; ++i)
-            if (need_cur[i]) t.mip_pos.push_back(static_cast<uint16_t>(i));
-        t.mip_n_cur = static_cast<int>(t.mip_pos.size());
-        for (int i = 0; i < kPatch * kPatch; ++i)
-            if (need_prev[i]) t.mip_pos.push_back(static_cast<uint16_t>(kP19Pad + i));
+        const int n_dw = static_cast<int>(dwords.size());
+        if (n_dw < 65 || n_dw > 80) std::abort();  // the kernel's five passes assume 64 full dwords plus a partial pass
+        for (int u = 0; u < 4; ++u)
+            for (int lane = 0; lane < 64; ++lane) t.mip_pos.push_back(static_cast<uint16_t>(4 * dwords[lane] + u));
+        for (int d = 64; d < n_dw; ++d)
+            for (int b = 0; b < 4; ++b) t.mip_pos.push_back(static_cast<uint16_t>(4 * dwords[d] + b));
         t.mip_n = static_cast<int>(t.mip_pos.size());
+        t.mip_n_cur = 0;
+        for (int v : t.mip_pos) t.mip_n_cur += v < kP19Pad ? 1 : 0;
         t.mip_stride = (t.mip_n + 63) / 64 * 64;
-        t.mip_pos.resize(t.mip_stride, 0);
+        t.mip_pos.resize(t.mip_stride, t.mip_pos.back());
         t.mip_samples.assign(static_cast<size_t>(kTileMaxRoi + 1) * t.mip_stride, MipSample{0, 0, 0, 0, 0, 0, 0, 0});
         for (int L = 1; L <= kTileMaxRoi; ++L) {
             const ResizeTap *tx = &t.resize[(static_cast<size_t>(L) * 2 + 0) * kPatch];
             const ResizeTap *ty = &t.resize[(static_cast<size_t>(L) * 2 + 1) * kPatch];
             for (int j = 0; j < t.mip_n; ++j) {
-                const int pos = t.mip_pos[j] % kP19Pad, dy = pos / kPatch, dx = pos % kPatch;
+                const int pos = std::min(t.mip_pos[j] % kP19Pad, kPatch * kPatch - 1), dy = pos / kPatch, dx = pos % kPatch;
                 MipSample &m = t.mip_samples[static_cast<size_t>(L) * t.mip_stride + j];
-                m.off00 = static_cast<uint16_t>(ty[dy].ofs * kTileCW + tx[dx].ofs);
-                m.off01 = static_cast<uint16_t>(ty[dy].ofs * kTileCW + tx[dx].ofs1);
-                m.off10 = static_cast<uint16_t>(ty[dy].ofs1 * kTileCW + tx[dx].ofs);
-                m.off11 = static_cast<uint16_t>(ty[dy].ofs1 * kTileCW + tx[dx].ofs1);
+                m.off00 = static_cast<uint16_t>(ty[dy].ofs * kTileStagePitch + tx[dx].ofs);
+                m.off01 = static_cast<uint16_t>(ty[dy].ofs * kTileStagePitch + tx[dx].ofs1);
+                m.off10 = static_cast<uint16_t>(ty[dy].ofs1 * kTileStagePitch + tx[dx].ofs);
+                m.off11 = static_cast<uint16_t>(ty[dy].ofs1 * kTileStagePitch + tx[dx].ofs1);
                 m.c0x = tx[dx].c0;
                 m.c1x = tx[dx].c1;
                 // the tile kernel reads a row pair as (off, off + 1): a clamped column has to carry a zero weight

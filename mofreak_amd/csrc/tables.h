@@ -25,7 +25,10 @@ constexpr int kPatch = 19;         // MoFREAKUtilities.cpp:300
 constexpr int kMaxRoiSide = 2048;  // largest ceil(keypoint size) the resize tables cover
 
 struct PatternPoint {  // 16 bytes on the device so a lane fetches one point with a single dwordx4 load
-    float x, y, sigma, pad;
+    float x, y, sigma;
+    // Tile kernel (integral kept modulo 2^16): rows of this point's sampling box that are certain to hold at most 257
+    // pixels, floor(257 / (floor(2 sigma) + 3)) -- the box is at most floor(2 sigma) + 2 pixels wide -- and at least 1.
+    int32_t rows_per_slice;
 };
 
 struct OrientPair {
@@ -39,17 +42,19 @@ struct ResizeTap {
     int16_t c0, c1; // fixed-point weights (11 bits); x axis at d >= xmax: {2048, 0}
 };
 
-// ---- geometry of the fused tile kernel (tile_kernel.hip); the MIP sample table below bakes in kTileCW
+// ---- geometry of the fused tile kernel (tile_kernel.hip); the MIP sample table below bakes in kTileStagePitch
 constexpr int kTileW = 96, kTileH = 64;  // pixels a workgroup owns
 constexpr int kTileHalo = 48;            // FREAK: keypoints whose patternSizes[scale] <= kTileHalo take the tile path
-constexpr int kTileMipHalo = 8;          // MIP: ROI reach beyond the tile
-constexpr int kTileRW = kTileW + 2 * kTileHalo, kTileRH = kTileH + 2 * kTileHalo;           // integral region 192 x 160
-constexpr int kTileCW = kTileW + 2 * kTileMipHalo, kTileCH = kTileH + 2 * kTileMipHalo;     // gray tiles 112 x 80
+constexpr int kTileMipHalo = 8;          // MIP: ROI reach beyond the tile (the smallest halo, 24, covers it)
+constexpr int kTileRW = kTileW + 2 * kTileHalo, kTileRH = kTileH + 2 * kTileHalo;           // largest integral region 192 x 160
+// One LDS row of the tile kernel: first the staged gray bytes of a region row (current at byte 0, previous at byte
+// kTileRW), later, in place, the row of the u16 integral (kTileRW + 8 entries).
+constexpr int kTileStagePitch = 2 * (kTileRW + 8);
 constexpr int kTileMaxRoi = 16;          // largest ROI side the tile path samples
 constexpr int kP19Pad = 368;             // bytes reserved per 19x19 buffer
 
 // One of the 19x19 output pixels the MIP actually reads, for one ROI side L: the four source bytes (offsets from
-// the ROI's top-left inside a kTileCW-pitch gray tile) and the fixed-point weights of cv::resize.
+// the ROI's top-left inside the kTileStagePitch-pitch staged rows) and the fixed-point weights of cv::resize.
 struct MipSample {
     uint16_t off00, off01, off10, off11;
     int16_t c0x, c1x, c0y, c1y;
@@ -83,9 +88,10 @@ struct Tables {
     int max_abs_direction;                // bound on |direction0|, |direction1|
     // resize taps: [L][axis(0=x,1=y)][19], L = 0..kMaxRoiSide (row 0 unused)
     std::vector<ResizeTap> resize;
-    // The 19x19 positions motionInterchangePattern reads at the 8 patch centres (MoFREAKUtilities.cpp:56-70, 79-88,
-    // 308-316): current-frame positions first (mip_n_cur of them), then previous-frame positions; value =
-    // frame * kP19Pad + row * 19 + col.  mip_samples[L][j] is position j's MipSample for ROI side L (L <= kTileMaxRoi).
+    // The bytes of a (cur19 | prev19) buffer pair (kP19Pad bytes each) that the tile kernel resamples: every aligned
+    // dword holding a 19x19 position motionInterchangePattern reads at the 8 patch centres (MoFREAKUtilities.cpp:56-70,
+    // 79-88, 308-316).  mip_pos[64 * u + lane] for u < 4 is byte u of the lane's dword; the rest follow byte by byte.
+    // value = frame * kP19Pad + row * 19 + col.  mip_samples[L][j] is entry j's MipSample for ROI side L (L <= kTileMaxRoi).
     // thetaIdx steps (see device_helpers.h theta_index): found by bisection over float angles through the chain
     // angle = (float)(a * (180.0/CV_PI)); thetaIdx = int(256*angle*(1/360.0)+0.5)
     std::vector<ThetaBound> theta_bounds;

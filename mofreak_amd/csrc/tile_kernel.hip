@@ -2,17 +2,19 @@
 // frame pair and describes every keypoint whose pixel falls in it, entirely out of LDS.  Two workgroups share a CU
 // (75 KB of LDS each), so one workgroup's barriers and global-memory latencies are covered by the other's work.
 //
-//   stage 0  gray tiles: the tile + 8-px rim of `current` and `previous` (u8, 112x80 each) -> LDS
+//   stage 0  the gray bytes of the tile + halo of `current` and `previous` -> LDS, each region row into the LDS row
+//            that will hold its integral: the frames are fetched once, in one round trip to memory per tile
 //   stage 1  MIP (MoFREAKUtilities.cpp:288-325, 46-99), one wave per keypoint, no workgroup barrier: the ~280 pixels of
 //            the two 19x19 resamples that motionInterchangePattern actually reads (cv::resize fixed-point bilinear,
 //            host-built sample table per ROI side held in registers) -> the wave's own LDS buffer; then
 //            lane = 8*centre + offset, strip SSD, __ballot = the 8 motion bytes
-//   stage 2  integral image of |current - previous| over tile + halo, kept MODULO 2^16 (u16, two pixels per dword):
-//            the row pass scans inside a wave (v_sad_u8 inside a lane's 16 pixels, DPP row_shr across the 16 lanes
-//            of a region row), the column pass adds packed pairs (v_pk_add_u16).  A box sum is exact modulo 2^16 as
-//            long as the box holds at most 257 pixels (257 * 255 < 2^16); larger boxes are summed in horizontal
-//            slices of at most 257 pixels each.  Box sums are translation-invariant, so the tile-local integral gives
-//            the same box means as cv::integral of the whole frame -- which never exists in HBM.
+//   stage 2  integral image of |current - previous| over tile + halo, kept MODULO 2^16 (u16, two pixels per dword),
+//            built in place over the staged bytes: the row pass scans inside a wave (v_sad_u8 inside a lane's 16
+//            pixels, DPP row_shr across the 16 lanes of a region row), the column pass adds packed pairs
+//            (v_pk_add_u16).  A box sum is exact modulo 2^16 as long as the box holds at most 257 pixels
+//            (257 * 255 < 2^16); larger boxes are summed in horizontal slices of at most 257 pixels each.  Box sums
+//            are translation-invariant, so the tile-local integral gives the same box means as cv::integral of the
+//            whole frame -- which never exists in HBM.
 //            The halo is sized per call from the largest FREAK pattern among the call's tile-path keypoints
 //            (binning pass, device-resident word): 24, 32, 40 or 48 pixels.
 //   stage 3  FREAK (cv::FREAK::compute on the difference image, :427-428), one wave per group of four keypoints, no
@@ -22,8 +24,12 @@
 //
 // HBM traffic is the two frames (halo re-reads are served by L2 / Infinity Cache) + keypoints in + descriptors out.
 // Keypoints whose FREAK pattern does not fit the 48-px halo (patternSizes[scale] > 48, i.e. size >= ~14.9) or whose
-// ROI does not fit the rim are left to the gather path (describe_kernel over a global integral) by the binning pass.
+// ROI side exceeds 16 are left to the gather path (describe_kernel over a global integral) by the binning pass.
 #include "device_helpers.h"
+
+#ifndef MOFREAK_EXP_SKIP
+#define MOFREAK_EXP_SKIP 0   // kernel experiments only: bit mask of stages to leave out (1 MIP, 2 integral, 4 FREAK)
+#endif
 
 namespace mofreak {
 namespace {
@@ -33,77 +39,70 @@ constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kBatch = 96;                           // keypoints described per pass over a tile's list
 constexpr int kGroup = 4;                            // keypoints one wave describes together in stage 3
 constexpr int kMinHalo = 24;                         // smallest integral halo (patternSizes[0] = 23)
-constexpr int kIPitch = kTileRW + 8;                 // LDS integral pitch (u16); logical column c at physical c+7
+constexpr int kIPitch = kTileStagePitch / 2;         // LDS integral pitch (u16); logical column c at physical c+7
 constexpr int kIColOff = 7;
 constexpr int kIPitchDw = kIPitch / 2;
-constexpr int kIntegralBytes = (kTileRH + 1) * kIPitch * 2;
+constexpr int kIntegralBytes = (kTileRH + 1) * kTileStagePitch;
+constexpr int kStageTasks = 2 * kTileRH * (kTileRW / 16);                      // 16-byte pieces of the largest region
+constexpr int kStageIters = (kStageTasks + kTileThreads - 1) / kTileThreads;
 constexpr int kRowGroupIters = (kTileRH / 4 + kTileWaves - 1) / kTileWaves;   // 4-row groups per wave in the row pass
 constexpr int kColBlockRows = 16;
 constexpr int kMaxColBlocks = kTileRH / kColBlockRows;                         // 10
-constexpr int kMaxDcols = kTileRW / 2;                                         // 96 dword columns (pixel pairs)
-constexpr int kColIters = (kMaxColBlocks * kMaxDcols + kTileThreads - 1) / kTileThreads;
+constexpr int kMaxQcols = kTileRW / 4;                                         // 48 columns of four pixels (8 bytes of u16)
 constexpr int kVStride = 44;                         // bytes per keypoint in a wave's box-mean buffer (11 dwords: odd)
 constexpr int kMipIters = 5;                         // 64-lane passes over the <= 320 sampled 19x19 positions
 constexpr int kBoxIters = (kGroup * kNbPoints + 63) / 64;                       // 3
 constexpr int kBigPoints = 12;                       // points of the two outer rings: the boxes that may need slices
-constexpr int kGrayTasks = 2 * kTileCH * (kTileCW / 16);
-constexpr int kGrayIters = (kGrayTasks + kTileThreads - 1) / kTileThreads;
-constexpr int kP19Wave = 2 * 2 * kP19Pad;            // a wave's MIP buffers: two keypoints x (cur19, prev19)
+constexpr int kP19Wave = 2 * kP19Pad;                // a wave's MIP buffer: (cur19, prev19) of one keypoint
 
 // ---- LDS carve (bytes); every offset is a multiple of 16
-constexpr int kOffIntegral = 0;
-// stages 0-1 use the (not yet built) integral area: gray tiles and the waves' 19x19 buffers
-constexpr int kOffCur = 0;
-constexpr int kOffPrev = kOffCur + kTileCW * kTileCH;
-constexpr int kOffP19 = kOffPrev + kTileCW * kTileCH;
+constexpr int kOffIntegral = 0;                      // row 0: zeros; row r + 1: region row r (staged bytes, then integral)
 constexpr int kOffScratch = (kIntegralBytes + 15) / 16 * 16;
-constexpr int kScratchBytes = kMaxColBlocks * kMaxDcols * 4;   // column-block totals; stage-1 records; stage-3 box means
+constexpr int kScratchBytes = kTileWaves * kP19Wave;           // stage 1: 19x19 buffers; stage 2: column-block totals; stage 3: box means
 constexpr int kOffTheta = kOffScratch + kScratchBytes;
-constexpr int kOffKf = kOffTheta + kThetaBounds * (int)sizeof(ThetaBound);   // the batch's FREAK records
+constexpr int kOffKf = kOffTheta + kThetaBounds * (int)sizeof(ThetaBound);   // the batch's keypoint records
 constexpr int kOffMot = kOffKf + kBatch * 16;                                // motion bytes kept for the fused store
 constexpr int kOffStamps = kOffMot + kBatch * 8;                             // diagnostic build only: 32 x u64
 constexpr int kTileLdsBytes = kOffStamps + 256;
-static_assert(kOffP19 % 16 == 0 && kP19Wave % 16 == 0 && kOffScratch % 16 == 0 && kOffTheta % 16 == 0, "LDS carve alignment");
-static_assert(kOffP19 + kTileWaves * kP19Wave <= kIntegralBytes, "stage-1 buffers fit the integral area");
+static_assert(kP19Wave % 16 == 0 && kOffScratch % 16 == 0 && kOffTheta % 16 == 0, "LDS carve alignment");
 static_assert(2 * kTileLdsBytes <= 160 * 1024, "two workgroups per CU");
 static_assert(kTileRW % 16 == 0 && kTileRH % kColBlockRows == 0 && kTileRW / 16 <= 16, "region blocking");
-static_assert((kIPitch * 2) % 16 == 0, "integral rows start on 16 bytes");
+static_assert(kTileStagePitch % 16 == 0 && 2 * kTileRW <= kTileStagePitch, "a region row's staged bytes fit its integral row");
+static_assert(kMaxColBlocks * kMaxQcols * 8 <= kScratchBytes, "column-block totals fit the scratch area");
+static_assert(kMaxColBlocks * kMaxQcols <= kTileThreads, "one column task per thread");
 static_assert(kTileWaves * kGroup * kVStride <= kScratchBytes, "stage-3 box means fit the scratch area");
 static_assert(kBatch % (kGroup * kTileWaves) == 0, "whole groups per wave in a full batch");
+static_assert(kTileMipHalo + 1 <= kMinHalo, "a tile-path ROI stays inside the smallest staged region");
 
-struct KpFreak {   // stage 3 per-keypoint record
+struct KpRec {   // per-keypoint record of a batch
     float kx, ky;
     int32_t g;
-    int16_t idx, theta;
+    uint16_t pk;    // FREAK scale index | ROI side << 6 | ROI half << 11 (MoFREAKUtilities.cpp:293-295)
+    int16_t theta;  // written by the orientation pass
 };
-struct KpMip {     // stage 1 per-keypoint record
-    int32_t g;
-    uint16_t roi_off;
-    uint8_t L, pad;
-};
-static_assert(kBatch * (int)sizeof(KpMip) <= kScratchBytes, "stage-1 records fit the scratch area");
-static_assert(sizeof(KpFreak) == 16, "record size used by the LDS carve");
+static_assert(sizeof(KpRec) == 16, "record size used by the LDS carve");
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-typedef const volatile __attribute__((address_space(3))) uint8_t lds_vu8;   // byte loads the optimiser must not fuse
+
+// LDS accesses by integer byte address (the address of the dynamic LDS block is folded into the scalar bases once):
+// the per-lane address arithmetic stays 32-bit and the instruction's immediate offset takes the constant part.
+template <class T>
+__device__ __forceinline__ T lds_ld(uint32_t addr)
+{
+    return *(const __attribute__((address_space(3))) T *)(uintptr_t)addr;
+}
+template <class T>
+__device__ __forceinline__ void lds_st(uint32_t addr, T v)
+{
+    *(__attribute__((address_space(3))) T *)(uintptr_t)addr = v;
+}
+
+typedef uint32_t LdsU4 __attribute__((ext_vector_type(4)));
+typedef uint32_t LdsU2 __attribute__((ext_vector_type(2)));
 
 struct __attribute__((aligned(8))) Px16 {
     uint32_t w[4];
 };
-
-// 16 pixels of one row starting at image column gx (zero outside the image).  gx is a multiple of 8.
-__device__ __forceinline__ Px16 load_px16(const uint8_t *row, int gx, int W, bool row_ok, bool fast8)
-{
-    if (row_ok && fast8 && gx >= 0 && gx + 16 <= W) return *reinterpret_cast<const Px16 *>(row + gx);
-    Px16 r = {{0, 0, 0, 0}};
-    if (row_ok) {
-        for (int k = 0; k < 16; ++k) {
-            const int x = gx + k;
-            if (x >= 0 && x < W) r.w[k >> 2] |= (uint32_t)row[x] << (8 * (k & 3));
-        }
-    }
-    return r;
-}
 
 // (int)((double)a + 0.5) for a float 0.5 <= a < 2^22 with one float add: a + 0.5f is exact while it stays in a's
 // binade; when it crosses into the next one the sum lies in [2^k, 2^k + 0.5), so rounding it to the coarser grid cannot
@@ -153,7 +152,8 @@ __device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b)
 
 // FREAK::meanIntensity (box branch) on the tile-local integral modulo 2^16.  `ibase` = LDS byte address of logical
 // (row 0, column 0) minus the region origin: the u16 of image corner (y, x) sits at ibase + 2 * (y * kIPitch + x).
-__device__ __forceinline__ int mean_intensity_tile(const uint8_t *lds, int ibase, float kx, float ky, const PatternPoint P)
+// P.rows_per_slice (host): how many rows of this point's box are certain to hold at most 257 pixels.
+__device__ __forceinline__ int mean_intensity_tile(uint32_t ibase, float kx, float ky, const PatternPoint P)
 {
     const float xf = P.x + kx;
     const float yf = P.y + ky;
@@ -164,22 +164,20 @@ __device__ __forceinline__ int mean_intensity_tile(const uint8_t *lds, int ibase
     const int x_right = round_half_up_pos(xf + radius) + 1;
     const int y_bottom = round_half_up_pos(yf + radius) + 1;
     const int w = x_right - x_left, h = y_bottom - y_top;
-    const int w2 = 2 * w;
-    int addr = ibase + 2 * ((int)__umul24(y_top, kIPitch) + x_left);
-    // rows per slice: the largest count whose slice stays within 257 pixels (floor(257 / w); 257 is prime, so the
-    // quotient is never within 1/64 of an integer and the float reciprocal cannot land on the wrong side)
-    const int rps = max(1, (int)(257.0f * __builtin_amdgcn_rcpf((float)w)));
-    int prev = (int)*reinterpret_cast<const uint16_t *>(lds + addr + w2) - (int)*reinterpret_cast<const uint16_t *>(lds + addr);
+    const uint32_t w2 = 2u * (uint32_t)w;
+    const int rps = P.rows_per_slice;
+    uint32_t addr = ibase + 2u * (__umul24(y_top, kIPitch) + (uint32_t)x_left);
+    int prev = (int)lds_ld<uint16_t>(addr + w2) - (int)lds_ld<uint16_t>(addr);
     int step = min(rps, h);
-    addr += (int)__umul24(step, 2 * kIPitch);
-    int cur = (int)*reinterpret_cast<const uint16_t *>(lds + addr + w2) - (int)*reinterpret_cast<const uint16_t *>(lds + addr);
+    addr += __umul24(step, 2 * kIPitch);
+    int cur = (int)lds_ld<uint16_t>(addr + w2) - (int)lds_ld<uint16_t>(addr);
     int sum = (cur - prev) & 0xffff;
     int left = h - step;
     while (left > 0) {  // outer rings of the larger patterns only
         prev = cur;
         step = min(rps, left);
-        addr += (int)__umul24(step, 2 * kIPitch);
-        cur = (int)*reinterpret_cast<const uint16_t *>(lds + addr + w2) - (int)*reinterpret_cast<const uint16_t *>(lds + addr);
+        addr += __umul24(step, 2 * kIPitch);
+        cur = (int)lds_ld<uint16_t>(addr + w2) - (int)lds_ld<uint16_t>(addr);
         sum += (cur - prev) & 0xffff;
         left -= step;
     }
@@ -366,6 +364,7 @@ template <bool STAMPS>
 __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds;  // LDS address of the block
     unsigned long long *s_stamps = reinterpret_cast<unsigned long long *>(lds + kOffStamps);
     if (STAMPS && threadIdx.x == 0)
         for (int i = 0; i < kTileStampSlots; ++i) s_stamps[i] = 0;
@@ -383,17 +382,26 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     const int kp_begin = a.tile_start[key];
     const int n_tile_kp = a.tile_start[key + 1] - kp_begin;
     if (n_tile_kp == 0) return;
+#ifdef MOFREAK_EXP_STAGGER
+    // experiment: the second workgroup of every CU (dispatch order: 8 XCDs x 32 CUs first) starts half a tile later
+    if ((blockIdx.x >> 3) >= 32 && (blockIdx.x >> 3) < 64)
+        for (int i = 0; i < MOFREAK_EXP_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
 
     uint8_t *scratch = lds + kOffScratch;
-    lds_vu8 *ldsv = (lds_vu8 *)lds;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int W = a.f.W, H = a.f.H;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     // integral halo of this call: the largest pattern the binning pass met, in steps of 8 pixels
+#ifdef MOFREAK_EXP_HALO
+    const int halo = MOFREAK_EXP_HALO;
+#else
     const int halo = min(kTileHalo, max(kMinHalo, (*a.max_ps + 7) & ~7));
-    const int RW = kTileW + 2 * halo, RH = kTileH + 2 * halo;
-    const int ox = tx * kTileW - halo, oy = ty * kTileH - halo;                    // integral region origin
+#endif
+    const int halo_x = (halo + 15) & ~15;  // 16-byte pieces of a region row start on 16 bytes of the frame row
+    const int RW = kTileW + 2 * halo_x, RH = kTileH + 2 * halo;
+    const int ox = tx * kTileW - halo_x, oy = ty * kTileH - halo;                  // integral region origin
     const int cx0 = tx * kTileW - kTileMipHalo, cy0 = ty * kTileH - kTileMipHalo;  // gray tile origin
     const uint8_t *cur = a.f.cur + (int64_t)pair * a.f.pair_stride;
     const uint8_t *prev = a.f.prev + (int64_t)pair * a.f.pair_stride;
@@ -405,101 +413,198 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     const bool orientation_normalized = st->orientation_normalized != 0;
 
     ThetaBound *s_theta = reinterpret_cast<ThetaBound *>(lds + kOffTheta);
-    if (tid < kThetaBounds) s_theta[tid] = a.theta[tid];
 
     uint2 *s_mot = reinterpret_cast<uint2 *>(lds + kOffMot);
-    KpMip *km = reinterpret_cast<KpMip *>(scratch);            // stage-1 records (scratch area: gone once stage 2 starts)
-    KpFreak *kf = reinterpret_cast<KpFreak *>(lds + kOffKf);   // stage-3 records (outside the scratch area)
+    KpRec *kf = reinterpret_cast<KpRec *>(lds + kOffKf);
     const bool one_batch = n_tile_kp <= kBatch;
     // The binning pass recorded the smallest and largest ROI side of the tile: equal in the usual case.
     const int tile_L = (int)a.tile_lmin[key];
     const bool uniform = tile_L == (int)a.tile_lmax[key];
 
-    // Both stages' per-keypoint records from one binned record (ROI corner / side for the MIP; coordinates, scale
-    // index for FREAK).
     auto make_records = [&](int b0, int nb) {
         if (tid < nb) {
             const SortedKp kp = tile_kps[b0 + tid];
-            const int x_i = (int)kp.x, y_i = (int)kp.y;  // :460 float -> int parameters
-            const int L = (int)(kp.packed & 0xff), half = (int)((kp.packed >> 8) & 0xff);
-            KpMip m;
-            m.g = kp.g;
-            m.roi_off = (uint16_t)((y_i - half - cy0) * kTileCW + (x_i - half - cx0));
-            m.L = (uint8_t)L;
-            m.pad = 0;
-            km[tid] = m;
-            KpFreak k;
+            KpRec k;
             k.kx = kp.x;
             k.ky = kp.y;
             k.g = kp.g;
-            k.idx = (int16_t)(kp.packed >> 16);
+            k.pk = (uint16_t)((kp.packed >> 16) | (kp.packed & 0xff) << 6 | ((kp.packed >> 8) & 0xff) << 11);
             k.theta = 0;
             kf[tid] = k;
         }
     };
+    // where a keypoint's ROI starts in the staged rows (:293-295, :460 float -> int parameters)
+    auto roi_offset = [&](const KpRec &k) -> uint32_t {
+        const int half = k.pk >> 11;
+        return (uint32_t)(((int)k.ky - half - oy + 1) * kTileStagePitch + ((int)k.kx - half - ox));
+    };
 
-    // per-lane constants of the MIP sampling passes: where each sampled pixel goes, and (once the ROI side is known)
-    // the LDS byte offsets of its two source rows relative to the ROI origin, frame base included (the second byte of
-    // a row pair is the next one: where cv::resize clamps the column instead, its weight is zero).  Their loads are
-    // issued here, ahead of stage 0, so that the global latencies overlap.
-    int pos[kMipIters], a0[kMipIters], a1[kMipIters];
-    uint32_t cxp[kMipIters];                   // the two 11-bit x weights, packed as loaded (c0 | c1 << 16)
-    uint32_t c0ys[kMipIters], c1ys[kMipIters];  // the y weights << 12: (w * (t >> 4)) >> 16 == mul_hi_u24(t & ~15, w << 12)
+    // ================= stage 0: the region's gray bytes -> LDS, 16 per lane and step.  Region row r goes to LDS row
+    // r + 1: `current` at byte 0, `previous` at byte kTileRW.  All loads are issued before anything waits on one (a
+    // branch per load would make the compiler drain the memory queue at every join); the small tables and the first
+    // batch's keypoint records are fetched behind them.
+    const int runs = RW >> 4;
+    const int per_frame = RH * runs;
+    const uint32_t runs_m20 = (1u << 20) / (uint32_t)runs + 1;  // t / runs for t < 2^12 as (t * m20) >> 20
+    auto stage_rq = [&](int t, int &fr, int &r, int &q) {
+        fr = t >= per_frame ? 1 : 0;
+        const int tt = t - fr * per_frame;
+        r = (int)(((uint32_t)tt * runs_m20) >> 20);
+        q = tt - r * runs;
+    };
+    auto stage_dst = [&](int fr, int r, int q) -> uint8_t * { return lds + kOffIntegral + (r + 1) * kTileStagePitch + fr * kTileRW + 16 * q; };
+    const bool inside = ox >= 0 && oy >= 0 && ox + RW <= W && oy + RH <= H;  // the whole region lies in the image
+    Px16 v[kStageIters];
+    if (fast8 && (inside || (W & 7) == 0)) {
+        if (inside) {
 #pragma unroll
-    for (int u = 0; u < kMipIters; ++u) pos[u] = kOffP19 + wave * kP19Wave + a.mip_pos[min(lane + 64 * u, a.mip_stride - 1)];
+            for (int u = 0; u < kStageIters; ++u) {
+                const int t = min(tid + u * kTileThreads, 2 * per_frame - 1);
+                int fr, r, q;
+                stage_rq(t, fr, r, q);
+                v[u] = *reinterpret_cast<const Px16 *>((fr ? prev : cur) + (int64_t)(oy + r) * a.f.row_stride + (ox + 16 * q));
+            }
+        } else {
+            // a tile on the image border, W a multiple of 8: every 8-byte half of a piece is all inside or all outside
+            // the image.  Outside pixels are never read by a keypoint that passed the border tests: any value will do,
+            // so the loads are clamped into the image instead of branching.
+#pragma unroll
+            for (int u = 0; u < kStageIters; ++u) {
+                const int t = min(tid + u * kTileThreads, 2 * per_frame - 1);
+                int fr, r, q;
+                stage_rq(t, fr, r, q);
+                const int gy = min(max(oy + r, 0), H - 1), gx = ox + 16 * q;
+                const uint8_t *row = (fr ? prev : cur) + (int64_t)gy * a.f.row_stride;
+                const uint2 lo = *reinterpret_cast<const uint2 *>(row + min(max(gx, 0), W - 8));
+                const uint2 hi = *reinterpret_cast<const uint2 *>(row + min(max(gx + 8, 0), W - 8));
+                v[u].w[0] = lo.x;
+                v[u].w[1] = lo.y;
+                v[u].w[2] = hi.x;
+                v[u].w[3] = hi.y;
+            }
+        }
+    }
+    // per-lane constants of the MIP sampling passes: the LDS address each sampled pixel goes to, and -- once the ROI
+    // side is known -- the LDS addresses of its two source rows for a ROI at the region's origin, frame included (the
+    // second byte of a row pair is the next one: where cv::resize clamps the column instead, its weight is zero).
+    // Their loads are issued here, ahead of stage 0, so that the global latencies overlap.
+    struct MipLane {
+        uint32_t dst_dword, dst_tail;              // where the lane's packed four pixels / its last-pass pixel go
+        uint32_t a0[kMipIters], a1[kMipIters];
+        uint32_t cxp[kMipIters];                   // the two 11-bit x weights, packed as loaded (c0 | c1 << 16)
+        uint32_t c0ys[kMipIters], c1ys[kMipIters];  // the y weights << 12: (w * (t >> 4)) >> 16 == mul_hi_u24(t & ~15, w << 12)
+    } ml;
+    const uint32_t p19 = lds0 + kOffScratch + wave * kP19Wave;  // this wave's pair of 19x19 buffers
+    uint16_t mpos[kMipIters];
+#pragma unroll
+    for (int u = 0; u < kMipIters; ++u) mpos[u] = a.mip_pos[min(lane + 64 * u, a.mip_stride - 1)];
+    ml.dst_dword = p19 + mpos[0];  // byte 0 of the lane's dword (launch_tile's table check: passes 0..3 are its four bytes)
+    ml.dst_tail = p19 + mpos[kMipIters - 1];
     auto load_samples = [&](int L) {
         const MipSample *tab = a.mip_samples + (int64_t)L * a.mip_stride;
 #pragma unroll
         for (int u = 0; u < kMipIters; ++u) {
             const MipSample sm = tab[min(lane + 64 * u, a.mip_stride - 1)];
-            const int frame = (lane + 64 * u) < a.mip_n_cur ? kOffCur : kOffPrev;
-            a0[u] = frame + sm.off00;
-            a1[u] = frame + sm.off10;
-            cxp[u] = (uint32_t)(uint16_t)sm.c0x | (uint32_t)(uint16_t)sm.c1x << 16;
-            c0ys[u] = (uint32_t)(uint16_t)sm.c0y << 12;
-            c1ys[u] = (uint32_t)(uint16_t)sm.c1y << 12;
+            const uint32_t frame = lds0 + kOffIntegral + (mpos[u] < kP19Pad ? 0 : kTileRW);
+            ml.a0[u] = frame + sm.off00;
+            ml.a1[u] = frame + sm.off10;
+            ml.cxp[u] = (uint32_t)(uint16_t)sm.c0x | (uint32_t)(uint16_t)sm.c1x << 16;
+            ml.c0ys[u] = (uint32_t)(uint16_t)sm.c0y << 12;
+            ml.c1ys[u] = (uint32_t)(uint16_t)sm.c1y << 12;
         }
     };
-    int have_L = -1;
-    if (uniform) {  // one ROI side in the whole tile (the usual case): its samples stay in registers
-        have_L = tile_L;
-        load_samples(tile_L);
-    }
+    if (uniform) load_samples(tile_L);  // one ROI side in the whole tile (the usual case): its samples stay in registers
+    const bool tail_ok = lane + 64 * (kMipIters - 1) < a.mip_n;  // the last pass is a partial one (launch_tile checks mip_n)
 
-    // ================= stage 0: gray tiles (tile + 8-px rim), 16 bytes per lane; all loads first, then the stores.
-    // The first batch's keypoint records ride along.
-    {
-        Px16 v[kGrayIters];
+    make_records(0, min(kBatch, n_tile_kp));
+    if (tid < kThetaBounds) s_theta[tid] = a.theta[tid];
+    if (fast8 && (inside || (W & 7) == 0)) {
 #pragma unroll
-        for (int u = 0; u < kGrayIters; ++u) {
+        for (int u = 0; u < kStageIters; ++u) {
             const int t = tid + u * kTileThreads;
-            const int fr = t >= kGrayTasks / 2 ? 1 : 0, tt = t - fr * (kGrayTasks / 2);
-            const int r = tt / (kTileCW / 16), q = tt - r * (kTileCW / 16);
-            const int gy = cy0 + r, gx = cx0 + 16 * q;
-            const bool row_ok = t < kGrayTasks && gy >= 0 && gy < H;
-            const int64_t ro = (int64_t)gy * a.f.row_stride;
-            v[u] = load_px16((fr ? prev : cur) + ro, gx, W, row_ok, fast8);
+            if (t < 2 * per_frame) {
+                int fr, r, q;
+                stage_rq(t, fr, r, q);
+                *reinterpret_cast<uint4 *>(stage_dst(fr, r, q)) = make_uint4(v[u].w[0], v[u].w[1], v[u].w[2], v[u].w[3]);
+            }
         }
-        make_records(0, min(kBatch, n_tile_kp));
-#pragma unroll
-        for (int u = 0; u < kGrayIters; ++u) {
-            const int t = tid + u * kTileThreads;
-            if (t < kGrayTasks)  // cur tile, then prev tile: contiguous in LDS
-                reinterpret_cast<uint4 *>(lds + kOffCur)[t] = make_uint4(v[u].w[0], v[u].w[1], v[u].w[2], v[u].w[3]);
+    } else {  // unaligned frames or an odd width: byte by byte, zero outside the image
+        for (int t = tid; t < 2 * per_frame; t += kTileThreads) {
+            int fr, r, q;
+            stage_rq(t, fr, r, q);
+            const int gy = oy + r, gx = ox + 16 * q;
+            const uint8_t *row = (fr ? prev : cur) + (int64_t)gy * a.f.row_stride;
+            uint32_t w4[4] = {0, 0, 0, 0};
+            if (gy >= 0 && gy < H) {
+                for (int k = 0; k < 16; ++k) {
+                    const int x = gx + k;
+                    if (x >= 0 && x < W) w4[k >> 2] |= (uint32_t)row[x] << (8 * (k & 3));
+                }
+            }
+            *reinterpret_cast<uint4 *>(stage_dst(fr, r, q)) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
     }
     __syncthreads();  TILE_STAMP(0);
 
     // ================= stage 1: MIP
-    {
-        uint8_t *p19 = lds + kOffP19 + wave * kP19Wave;  // this wave's two pairs of 19x19 buffers
+    if (!(MOFREAK_EXP_SKIP & 1)) {
         // per-lane constants of the bit pass: lane = 8*centre + offset (MoFREAKUtilities.cpp:56-70, 308-316)
         const int mc = lane >> 3, mi = lane & 7;
         const int mcx = (0xDDD99555u >> (4 * mc)) & 15, mcy = (0xD95D5D95u >> (4 * mc)) & 15;
         const int mdx = (int)((0x14787410u >> (4 * mi)) & 15) - 4, mdy = (int)((0x10147874u >> (4 * mi)) & 15) - 4;
         const int base_c = (mcy - 1) * kPatch + (mcx - 1);
         const int base_p = kP19Pad + (mcy + mdy - 1) * kPatch + (mcx + mdx - 1);
-        const int cw = base_c >> 2, cs = base_c & 3, pw = base_p >> 2, ps = base_p & 3;  // covering dword, byte shift
+        const uint32_t cw = p19 + 4 * (base_c >> 2), pw = p19 + 4 * (base_p >> 2);  // covering dwords
+        const int cs = base_c & 3, ps = base_p & 3;                                // byte shifts
+
+        // one sampled pixel of one keypoint: four source bytes -> horizontal step as a packed dot product -> vertical step
+        auto sample = [&](const MipLane &c, int u, uint32_t roi) -> uint32_t {
+            const uint32_t b0 = c.a0[u] + roi, b1 = c.a1[u] + roi;
+            const uint32_t r0 = (uint32_t)lds_ld<uint8_t>(b0) | (uint32_t)lds_ld<uint8_t>(b0 + 1) << 16;
+            const uint32_t r1 = (uint32_t)lds_ld<uint8_t>(b1) | (uint32_t)lds_ld<uint8_t>(b1 + 1) << 16;
+            const u16x2 wx = __builtin_bit_cast(u16x2, c.cxp[u]);
+            const uint32_t t0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, r0), wx, 0u, false);
+            const uint32_t t1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, r1), wx, 0u, false);
+            return (uint32_t)resize_y(t0, t1, c.c0ys[u], c.c1ys[u]);
+        };
+        // lane = 8*centre + offset: the two 9-byte strips sit at arbitrary byte offsets: fetch the covering aligned
+        // dwords (a byte-wise formulation lets the compiler fuse the loads into misaligned ds_read_b64s, 64 cycles
+        // each) and shift the strips out; SSD = sum c^2 + sum p^2 - 2 sum c*p over the first eight bytes (packed u8
+        // dot products) + the ninth byte's squared difference
+        // a lane's five resampled pixels -> LDS: the first four are the bytes of one dword
+        auto put_pixels = [&](const MipLane &c, const uint32_t (&px)[kMipIters]) {
+            lds_st<uint32_t>(c.dst_dword, px[0] | px[1] << 8 | px[2] << 16 | px[3] << 24);
+            if (tail_ok) lds_st<uint8_t>(c.dst_tail, (uint8_t)px[4]);
+        };
+        struct Strips {
+            uint32_t cd[3], pd[3];
+        };
+        auto read_strips = [&]() -> Strips {
+            Strips t;
+#pragma unroll
+            for (int w3 = 0; w3 < 3; ++w3) {
+                t.cd[w3] = lds_ld<uint32_t>(cw + 4 * w3);
+                t.pd[w3] = lds_ld<uint32_t>(pw + 4 * w3);
+            }
+            return t;
+        };
+        auto strip_bits = [&](const Strips &t) -> uint64_t {
+            const uint32_t c0 = __builtin_amdgcn_alignbyte(t.cd[1], t.cd[0], cs), c1 = __builtin_amdgcn_alignbyte(t.cd[2], t.cd[1], cs);
+            const uint32_t p0 = __builtin_amdgcn_alignbyte(t.pd[1], t.pd[0], ps), p1 = __builtin_amdgcn_alignbyte(t.pd[2], t.pd[1], ps);
+            const int d8 = (int)((t.cd[2] >> (8 * cs)) & 0xffu) - (int)((t.pd[2] >> (8 * ps)) & 0xffu);
+            const uint32_t sq = __builtin_amdgcn_udot4(c0, c0, __builtin_amdgcn_udot4(c1, c1, (uint32_t)__mul24(d8, d8), false), false) +
+                                __builtin_amdgcn_udot4(p0, p0, __builtin_amdgcn_udot4(p1, p1, 0u, false), false);
+            const uint32_t cross = __builtin_amdgcn_udot4(c0, p0, __builtin_amdgcn_udot4(c1, p1, 0u, false), false);
+            return __ballot((int)(sq - 2u * cross) > mip_theta);
+        };
+        auto put_motion = [&](int kk, int g, uint64_t mot) {
+            const uint2 mv = make_uint2((uint32_t)mot, (uint32_t)(mot >> 32));
+            if (one_batch)  // kept for one 16-byte store per descriptor at the end of stage 3
+                s_mot[kk] = mv;
+            else  // a crowded tile (several batches) sends its motion bytes out now
+                *reinterpret_cast<uint2 *>(a.out_desc + (out_base + g) * 16 + 8) = mv;
+        };
+
         for (int b0 = 0; b0 < n_tile_kp; b0 += kBatch) {
             const int nb = min(kBatch, n_tile_kp - b0);
             if (b0 > 0) {  // further batches of a crowded tile: their records
@@ -507,115 +612,75 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                 make_records(b0, nb);
                 __syncthreads();
             }
-            // Per wave, two keypoints at a time (their LDS reads are issued together, so one's latency hides under
-            // the other's arithmetic): the sampled pixels of the two 19x19 resamples -> LDS, then -- same wave, so
-            // only a wave-level sync -- lane = 8*centre + offset, strip SSD, ballot.
-            for (int kk = wave; kk < nb; kk += 2 * kTileWaves) {
-                const int kk2 = kk + kTileWaves;
-                const bool two = kk2 < nb;
-                const KpMip m = km[kk], m2 = km[two ? kk2 : kk];
-                if (!uniform) {  // mixed ROI sides: rare; one keypoint at a time, reloading the samples when the side changes
-                    for (int h = 0; h < (two ? 2 : 1); ++h) {
-                        const KpMip mm = h ? m2 : m;
-                        if (mm.L != have_L) {
-                            have_L = mm.L;
-                            load_samples(mm.L);
-                        }
-#pragma unroll
-                        for (int u = 0; u < kMipIters; ++u) {
-                            const int b0a = a0[u] + mm.roi_off, b1a = a1[u] + mm.roi_off;
-                            u16x2 r0, r1;
-                            r0.x = ldsv[b0a];
-                            r0.y = ldsv[b0a + 1];
-                            r1.x = ldsv[b1a];
-                            r1.y = ldsv[b1a + 1];
-                            const u16x2 wx = __builtin_bit_cast(u16x2, cxp[u]);
-                            const uint32_t t0 = __builtin_amdgcn_udot2(r0, wx, 0u, false), t1 = __builtin_amdgcn_udot2(r1, wx, 0u, false);
-                            const int px = resize_y(t0, t1, c0ys[u], c1ys[u]);
-                            if (lane + 64 * u < a.mip_n) lds[pos[u] + h * (2 * kP19Pad)] = (uint8_t)px;
-                        }
-                    }
-                } else {
-                    u16x2 r0[2][kMipIters], r1[2][kMipIters];
+            if (uniform) {
+                // Per wave, two keypoints at a time (their LDS reads are issued together, so one's latency hides under
+                // the other's arithmetic): the sampled pixels of the two 19x19 resamples -> registers; then, one
+                // keypoint after the other through the wave's buffer -- same wave, so only wave-level syncs --
+                // pixels -> LDS, strips back, SSDs, ballot.  A last odd keypoint is simply done twice.
+                const MipLane c = ml;  // never changes inside this loop
+                for (int kk = wave; kk < nb; kk += 2 * kTileWaves) {
+                    const int kk2 = kk + kTileWaves;
+                    const bool two = kk2 < nb;
+                    const KpRec m = kf[kk], m2 = kf[two ? kk2 : kk];
+                    const uint32_t roi = roi_offset(m), roi2 = roi_offset(m2);
+                    uint32_t px[2][kMipIters];
 #pragma unroll
                     for (int u = 0; u < kMipIters; ++u) {
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const int roi = h ? m2.roi_off : m.roi_off;
-                            const int b0a = a0[u] + roi, b1a = a1[u] + roi;
-                            r0[h][u].x = ldsv[b0a];
-                            r0[h][u].y = ldsv[b0a + 1];
-                            r1[h][u].x = ldsv[b1a];
-                            r1[h][u].y = ldsv[b1a + 1];
-                        }
+                        px[0][u] = sample(c, u, roi);
+                        px[1][u] = sample(c, u, roi2);
                     }
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                        for (int u = 0; u < kMipIters; ++u) {
-                            const u16x2 wx = __builtin_bit_cast(u16x2, cxp[u]);
-                            const uint32_t t0 = __builtin_amdgcn_udot2(r0[h][u], wx, 0u, false);
-                            const uint32_t t1 = __builtin_amdgcn_udot2(r1[h][u], wx, 0u, false);
-                            const int px = resize_y(t0, t1, c0ys[u], c1ys[u]);
-                            if ((h == 0 || two) && lane + 64 * u < a.mip_n) lds[pos[u] + h * (2 * kP19Pad)] = (uint8_t)px;
-                        }
+                    put_pixels(c, px[0]);
+                    wave_lds_sync();
+                    const Strips s1 = read_strips();
+                    wave_lds_sync();
+                    put_pixels(c, px[1]);
+                    wave_lds_sync();
+                    const Strips s2 = read_strips();
+                    const uint64_t mot = strip_bits(s1), mot2 = strip_bits(s2);
+                    if (lane == 0) {
+                        put_motion(kk, m.g, mot);
+                        if (two) put_motion(kk2, m2.g, mot2);
                     }
+                    wave_lds_sync();  // the next pair of keypoints overwrites the 19x19 buffers
                 }
-                wave_lds_sync();
-                // the two 9-byte strips sit at arbitrary byte offsets: fetch the covering aligned dwords (a byte-wise
-                // formulation lets the compiler fuse the loads into misaligned ds_read_b64s, 64 cycles each) and
-                // shift the strips out; SSD = sum c^2 + sum p^2 - 2 sum c*p over the first eight bytes (packed u8
-                // dot products) + the ninth byte's squared difference
-                uint32_t cd[2][3], pd[2][3];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const uint32_t *b32 = reinterpret_cast<const uint32_t *>(p19 + ((h && two) ? 2 * kP19Pad : 0));
-#pragma unroll
-                    for (int w3 = 0; w3 < 3; ++w3) {
-                        cd[h][w3] = b32[cw + w3];
-                        pd[h][w3] = b32[pw + w3];
+            } else {
+                // mixed ROI sides: rare; one keypoint at a time, reloading the samples when the side changes
+                int have_L = -1;
+                for (int kk = wave; kk < nb; kk += kTileWaves) {
+                    const KpRec m = kf[kk];
+                    const int L = (m.pk >> 6) & 31;
+                    if (L != have_L) {
+                        have_L = L;
+                        load_samples(L);
                     }
-                }
+                    const uint32_t roi = roi_offset(m);
+                    uint32_t px[kMipIters];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const uint32_t c0 = __builtin_amdgcn_alignbyte(cd[h][1], cd[h][0], cs), c1 = __builtin_amdgcn_alignbyte(cd[h][2], cd[h][1], cs);
-                    const uint32_t p0 = __builtin_amdgcn_alignbyte(pd[h][1], pd[h][0], ps), p1 = __builtin_amdgcn_alignbyte(pd[h][2], pd[h][1], ps);
-                    const int d8 = (int)((cd[h][2] >> (8 * cs)) & 0xffu) - (int)((pd[h][2] >> (8 * ps)) & 0xffu);
-                    const uint32_t sq = __builtin_amdgcn_udot4(c0, c0, __builtin_amdgcn_udot4(c1, c1, (uint32_t)__mul24(d8, d8), false), false) +
-                                        __builtin_amdgcn_udot4(p0, p0, __builtin_amdgcn_udot4(p1, p1, 0u, false), false);
-                    const uint32_t cross = __builtin_amdgcn_udot4(c0, p0, __builtin_amdgcn_udot4(c1, p1, 0u, false), false);
-                    const int ssd = (int)(sq - 2u * cross);
-                    const uint64_t mot = __ballot(ssd > mip_theta);
-                    if (lane == 0 && (h == 0 || two)) {
-                        const uint2 mv = make_uint2((uint32_t)mot, (uint32_t)(mot >> 32));
-                        if (one_batch)  // kept for one 16-byte store per descriptor at the end of stage 3
-                            s_mot[h ? kk2 : kk] = mv;
-                        else  // a crowded tile (several batches) sends its motion bytes out now
-                            *reinterpret_cast<uint2 *>(a.out_desc + (out_base + (h ? m2.g : m.g)) * 16 + 8) = mv;
-                    }
+                    for (int u = 0; u < kMipIters; ++u) px[u] = sample(ml, u, roi);
+                    put_pixels(ml, px);
+                    wave_lds_sync();
+                    const uint64_t mot = strip_bits(read_strips());
+                    if (lane == 0) put_motion(kk, m.g, mot);
+                    wave_lds_sync();
                 }
-                wave_lds_sync();  // the next pair of keypoints overwrites the 19x19 buffers
             }
         }
     }
     __syncthreads();  TILE_STAMP(1);
 
     // ================= stage 2: integral of |cur - prev| over tile + halo, modulo 2^16, in LDS
-    {
+    if (!(MOFREAK_EXP_SKIP & 2)) {
         // 2a: row pass, no workgroup barrier.  The 16 lanes of a DPP row share one region row: a lane owns 16 pixels,
         //     |cur - prev| and the running sum inside them come from v_sad_u8 on masked dwords, the lane totals are
         //     scanned across the row with four DPP adds.  A wave takes four region rows per step.
-        const int runs = RW >> 4;
         const int rr = lane >> 4, q = lane & 15;
-        Px16 c[kRowGroupIters], p[kRowGroupIters];
+        LdsU4 c[kRowGroupIters], p[kRowGroupIters];
 #pragma unroll
-        for (int u = 0; u < kRowGroupIters; ++u) {
-            const int r = 4 * (wave + kTileWaves * u) + rr;
-            const int gy = oy + r, gx = ox + 16 * q;
-            const bool row_ok = r < RH && q < runs && gy >= 0 && gy < H;
-            const int64_t ro = (int64_t)gy * a.f.row_stride;
-            c[u] = load_px16(cur + ro, gx, W, row_ok, fast8);
-            p[u] = load_px16(prev + ro, gx, W, row_ok, fast8);
+        for (int u = 0; u < kRowGroupIters; ++u) {  // all of a wave's rows are read before any is overwritten
+            const int r = min(4 * (wave + kTileWaves * u) + rr, RH - 1);
+            const uint32_t row = lds0 + kOffIntegral + (r + 1) * kTileStagePitch + 16 * min(q, runs - 1);
+            c[u] = lds_ld<LdsU4>(row);
+            p[u] = lds_ld<LdsU4>(row + kTileRW);
         }
         for (int i = tid; i < kIPitchDw; i += kTileThreads) reinterpret_cast<uint32_t *>(lds + kOffIntegral)[i] = 0;  // integral row 0
 #pragma unroll
@@ -625,7 +690,8 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             uint32_t acc = 0;
 #pragma unroll
             for (int w4 = 0; w4 < 4; ++w4) {
-                const uint32_t x = c[u].w[w4], y = p[u].w[w4];
+                const uint32_t x = w4 == 0 ? c[u].x : w4 == 1 ? c[u].y : w4 == 2 ? c[u].z : c[u].w;
+                const uint32_t y = w4 == 0 ? p[u].x : w4 == 1 ? p[u].y : w4 == 2 ? p[u].z : p[u].w;
                 const uint32_t s0 = __builtin_amdgcn_sad_u8(x & 0xffu, y & 0xffu, acc);
                 const uint32_t s1 = __builtin_amdgcn_sad_u8(x & 0xffffu, y & 0xffffu, acc);
                 const uint32_t s2 = __builtin_amdgcn_sad_u8(x & 0xffffffu, y & 0xffffffu, acc);
@@ -641,7 +707,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             const uint32_t excl = (uint32_t)incl - acc;
             const uint32_t carry2 = __builtin_amdgcn_perm(excl, excl, 0x05040504u);  // low half in both halves
             if (r < RH && q < runs) {
-                uint8_t *row = lds + kOffIntegral + (r + 1) * (kIPitch * 2);
+                uint8_t *row = lds + kOffIntegral + (r + 1) * kTileStagePitch;
                 uint4 *dst = reinterpret_cast<uint4 *>(row + (8 + 16 * q) * 2);
                 dst[0] = make_uint4(pk_add_u16(pk[0], carry2), pk_add_u16(pk[1], carry2), pk_add_u16(pk[2], carry2), pk_add_u16(pk[3], carry2));
                 dst[1] = make_uint4(pk_add_u16(pk[4], carry2), pk_add_u16(pk[5], carry2), pk_add_u16(pk[6], carry2), pk_add_u16(pk[7], carry2));
@@ -649,53 +715,48 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             }
         }
         __syncthreads();  TILE_STAMP(2);
-        // 2b: column pass.  A thread owns a 16-row segment of one dword column (two pixels): running packed sums in
-        //     registers, segment total -> LDS; after the barrier it adds the totals of the segments above.
-        const int n_dcols = RW >> 1, n_blocks = RH / kColBlockRows;
-        const uint32_t m20 = (1u << 20) / (uint32_t)n_dcols + 1;  // t / n_dcols for t < 2^10 as (t * m20) >> 20
-        uint32_t *carry = reinterpret_cast<uint32_t *>(scratch);  // [block][kMaxDcols]
-        uint32_t cv[kColIters][kColBlockRows];
+        // 2b: column pass.  A thread owns a 16-row segment of two adjacent dword columns (four pixels, 8-byte LDS
+        //     accesses): running packed sums in registers, segment totals -> LDS; after the barrier it adds the totals
+        //     of the segments above.
+        const int n_qcols = RW >> 2, n_blocks = RH / kColBlockRows;
+        const uint32_t m20 = (1u << 20) / (uint32_t)n_qcols + 1;  // t / n_qcols for t < 2^9 as (t * m20) >> 20
+        const bool col_ok = tid < n_blocks * n_qcols;
+        const int cj = col_ok ? (int)(((uint32_t)tid * m20) >> 20) : 0, cc = col_ok ? tid - cj * n_qcols : 0;
+        const uint32_t col0 = lds0 + kOffIntegral + (cj * kColBlockRows + 1) * kTileStagePitch + (kIColOff + 1) * 2 + 8 * cc;
+        const uint32_t carry = lds0 + kOffScratch;  // uint2 [block][kMaxQcols]
+        LdsU2 cv[kColBlockRows];
 #pragma unroll
-        for (int u = 0; u < kColIters; ++u) {
-            const int t = tid + u * kTileThreads;
-            const bool ok = t < n_blocks * n_dcols;
-            const int j = ok ? (int)(((uint32_t)t * m20) >> 20) : 0, cc = ok ? t - j * n_dcols : 0;
-            const uint32_t *e = reinterpret_cast<const uint32_t *>(lds + kOffIntegral) + (j * kColBlockRows + 1) * kIPitchDw + (kIColOff + 1) / 2 + cc;
+        for (int r = 0; r < kColBlockRows; ++r) cv[r] = lds_ld<LdsU2>(col0 + r * kTileStagePitch);
+        LdsU2 acc = {0, 0};
 #pragma unroll
-            for (int r = 0; r < kColBlockRows; ++r) cv[u][r] = e[r * kIPitchDw];
-            uint32_t acc = 0;
-#pragma unroll
-            for (int r = 0; r < kColBlockRows; ++r) {
-                acc = pk_add_u16(acc, cv[u][r]);
-                cv[u][r] = acc;
-            }
-            if (ok) carry[j * kMaxDcols + cc] = acc;
+        for (int r = 0; r < kColBlockRows; ++r) {
+            acc.x = pk_add_u16(acc.x, cv[r].x);
+            acc.y = pk_add_u16(acc.y, cv[r].y);
+            cv[r] = acc;
         }
+        if (col_ok) lds_st<LdsU2>(carry + (cj * kMaxQcols + cc) * 8, acc);
         __syncthreads();  TILE_STAMP(3);
+        if (col_ok) {
+            LdsU2 add = {0, 0};
 #pragma unroll
-        for (int u = 0; u < kColIters; ++u) {
-            const int t = tid + u * kTileThreads;
-            if (t < n_blocks * n_dcols) {
-                const int j = (int)(((uint32_t)t * m20) >> 20), cc = t - j * n_dcols;
-                uint32_t tot[kMaxColBlocks - 1];
-#pragma unroll
-                for (int jj = 0; jj < kMaxColBlocks - 1; ++jj) tot[jj] = carry[jj * kMaxDcols + cc];
-                uint32_t add = 0;
-#pragma unroll
-                for (int jj = 0; jj < kMaxColBlocks - 1; ++jj) add = pk_add_u16(add, jj < j ? tot[jj] : 0u);
-                uint32_t *e = reinterpret_cast<uint32_t *>(lds + kOffIntegral) + (j * kColBlockRows + 1) * kIPitchDw + (kIColOff + 1) / 2 + cc;
-#pragma unroll
-                for (int r = 0; r < kColBlockRows; ++r) e[r * kIPitchDw] = pk_add_u16(cv[u][r], add);
+            for (int jj = 0; jj < kMaxColBlocks - 1; ++jj) {
+                const LdsU2 tot = lds_ld<LdsU2>(carry + (jj * kMaxQcols + cc) * 8);
+                add.x = pk_add_u16(add.x, jj < cj ? tot.x : 0u);
+                add.y = pk_add_u16(add.y, jj < cj ? tot.y : 0u);
             }
+#pragma unroll
+            for (int r = 0; r < kColBlockRows; ++r)
+                lds_st<LdsU2>(col0 + r * kTileStagePitch, LdsU2{pk_add_u16(cv[r].x, add.x), pk_add_u16(cv[r].y, add.y)});
         }
         __syncthreads();  TILE_STAMP(4);
     }
 
     // ================= stage 3: FREAK on the difference image, one wave per group of four keypoints
-    {
-        uint8_t *vv = scratch + wave * (kGroup * kVStride);   // this wave's box means [kGroup][kVStride]
-        const int ibase = kOffIntegral + 2 * (kIColOff - oy * kIPitch - ox);
-        // box-mean tasks of a group: the outer two rings (whose boxes may need slices) of all four keypoints first
+    if (!(MOFREAK_EXP_SKIP & 4)) {
+        const uint32_t vv = lds0 + kOffScratch + wave * (kGroup * kVStride);   // this wave's box means [kGroup][kVStride]
+        const uint32_t ibase = lds0 + kOffIntegral + 2 * (kIColOff - oy * kIPitch - ox);
+        // box-mean tasks of a group: the outer two rings (whose boxes may need slices) of all four keypoints first.
+        // Tasks past the group's 172 recompute keypoint 0's point 42 (same value, same address: harmless).
         int task_kq[kBoxIters], task_p[kBoxIters];
 #pragma unroll
         for (int u = 0; u < kBoxIters; ++u) {
@@ -703,106 +764,124 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             if (t < kGroup * kBigPoints) {
                 task_kq[u] = t / kBigPoints;
                 task_p[u] = t % kBigPoints;
-            } else {
+            } else if (t < kGroup * kNbPoints) {
                 const int t2 = t - kGroup * kBigPoints;
                 task_kq[u] = t2 / (kNbPoints - kBigPoints);
                 task_p[u] = kBigPoints + t2 % (kNbPoints - kBigPoints);
+            } else {
+                task_kq[u] = 0;
+                task_p[u] = kNbPoints - 1;
             }
-            if (t >= kGroup * kNbPoints) task_kq[u] = -1;
         }
         // orientation pass: 16 lanes per keypoint, three of the 45 pairs each; weights as floats (w / 2048 is exact, and
         // so is its product with a difference of two bytes), truncated like the reference's integer division
         const int oq = lane >> 4, osub = lane & 15;
-        int opi[3], opj[3];
+        uint32_t opi[3], opj[3];
         float owx[3], owy[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int m = osub + 16 * k;
             const OrientPair op = st->orient[min(m, kNbOrientPairs - 1)];
-            opi[k] = op.i;
-            opj[k] = op.j;
+            opi[k] = vv + oq * kVStride + op.i;
+            opj[k] = vv + oq * kVStride + op.j;
             owx[k] = m < kNbOrientPairs ? (float)op.weight_dx * (1.0f / 2048.0f) : 0.0f;
             owy[k] = m < kNbOrientPairs ? (float)op.weight_dy * (1.0f / 2048.0f) : 0.0f;
         }
-        const int pi = st->bit_pair_i[lane], pj = st->bit_pair_j[lane];
+        const uint32_t pi = vv + st->bit_pair_i[lane], pj = vv + st->bit_pair_j[lane];
         PatternPoint P0[kBoxIters];   // un-rotated pattern points of this lane's tasks, cached per scale index
         int have_idx = -1;
 
         for (int b0 = 0; b0 < n_tile_kp; b0 += kBatch) {
             const int nb = min(kBatch, n_tile_kp - b0);
-            if (!one_batch) {  // crowded tile: the records of this batch (a single batch still has them from stage 0;
-                __syncthreads();  // km is rewritten too, harmlessly: the scratch area's head is free between batches)
+            if (!one_batch) {  // crowded tile: the records of this batch (a single batch still has them from stage 0)
+                __syncthreads();
                 make_records(b0, nb);
                 __syncthreads();
             }
-            for (int kbase = wave * kGroup; kbase < nb; kbase += kGroup * kTileWaves) {
-                KpFreak rec[kBoxIters];
-                bool t_ok[kBoxIters];
+            // a group's last keypoints may be missing: their tasks redo the group's last real keypoint
+            auto group_records = [&](int kbase, KpRec (&rec)[kBoxIters], int (&sidx)[kBoxIters], uint32_t (&vdst)[kBoxIters]) {
+                const int last = min(kGroup, nb - kbase) - 1;
 #pragma unroll
                 for (int u = 0; u < kBoxIters; ++u) {
-                    t_ok[u] = task_kq[u] >= 0 && kbase + task_kq[u] < nb;
-                    rec[u] = kf[t_ok[u] ? kbase + task_kq[u] : kbase];
+                    const int kq = min(task_kq[u], last);
+                    rec[u] = kf[kbase + kq];
+                    sidx[u] = rec[u].pk & 63;
+                    vdst[u] = vv + kq * kVStride + task_p[u];
                 }
-                if (orientation_normalized) {
-                    // F1: un-rotated box means
+            };
+            // ---- pass A over the wave's groups: un-rotated box means, orientation sums, theta -> the records
+            if (orientation_normalized) {
+                for (int kbase = wave * kGroup; kbase < nb; kbase += kGroup * kTileWaves) {
+                    const int last = min(kGroup, nb - kbase) - 1;
+                    KpRec rec[kBoxIters];
+                    int sidx[kBoxIters];
+                    uint32_t vdst[kBoxIters];
+                    group_records(kbase, rec, sidx, vdst);
 #pragma unroll
                     for (int u = 0; u < kBoxIters; ++u) {
-                        if (rec[u].idx != have_idx)  // (per lane: all of a lane's tasks see the same scale in the usual case)
-                            P0[u] = a.lut[(int64_t)rec[u].idx * kNbOrientation * kNbPoints + task_p[u]];
+                        if (sidx[u] != have_idx)  // (all of a lane's tasks see the same scale in the usual case)
+                            P0[u] = a.lut[(int64_t)sidx[u] * kNbOrientation * kNbPoints + task_p[u]];
                     }
-                    have_idx = rec[kBoxIters - 1].idx == rec[0].idx && rec[1].idx == rec[0].idx ? rec[0].idx : -1;
+                    have_idx = sidx[kBoxIters - 1] == sidx[0] && sidx[1] == sidx[0] ? sidx[0] : -1;
 #pragma unroll
-                    for (int u = 0; u < kBoxIters; ++u) {
-                        if (t_ok[u])
-                            vv[task_kq[u] * kVStride + task_p[u]] = (uint8_t)mean_intensity_tile(lds, ibase, rec[u].kx, rec[u].ky, P0[u]);
-                    }
+                    for (int u = 0; u < kBoxIters; ++u)
+                        lds_st<uint8_t>(vdst[u], (uint8_t)mean_intensity_tile(ibase, rec[u].kx, rec[u].ky, P0[u]));
                     wave_lds_sync();
-                    // F2: orientation sums, theta
-                    {
-                        const uint8_t *v = vv + oq * kVStride;
-                        int direction0 = 0, direction1 = 0;
+                    int direction0 = 0, direction1 = 0;
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const float delta = (float)((int)v[opi[k]] - (int)v[opj[k]]);
-                            direction0 += (int)(delta * owx[k]);  // C division by 2048: truncates toward zero, per term
-                            direction1 += (int)(delta * owy[k]);
-                        }
-                        direction0 = row16_sum(direction0);
-                        direction1 = row16_sum(direction1);
-                        const int theta = theta_index(s_theta, direction0, direction1);
-                        if (osub == 0 && kbase + oq < nb) {
-                            kf[kbase + oq].theta = (int16_t)theta;
-                            if (a.out_info)
-                                *reinterpret_cast<int4 *>(a.out_info + (out_base + kf[kbase + oq].g) * 4) =
-                                    make_int4(kf[kbase + oq].idx, theta, direction0, direction1);
-                        }
+                    for (int k = 0; k < 3; ++k) {
+                        const float delta = (float)((int)lds_ld<uint8_t>(opi[k]) - (int)lds_ld<uint8_t>(opj[k]));
+                        direction0 += (int)(delta * owx[k]);  // C division by 2048: truncates toward zero, per term
+                        direction1 += (int)(delta * owy[k]);
                     }
-                    wave_lds_sync();
-                } else if (a.out_info && lane < kGroup && kbase + lane < nb) {
-                    *reinterpret_cast<int4 *>(a.out_info + (out_base + kf[kbase + lane].g) * 4) = make_int4(kf[kbase + lane].idx, 0, 0, 0);
+                    direction0 = row16_sum(direction0);
+                    direction1 = row16_sum(direction1);
+                    const int theta = theta_index(s_theta, direction0, direction1);
+                    if (osub == 0 && oq <= last) {
+                        kf[kbase + oq].theta = (int16_t)theta;
+                        if (a.out_info)
+                            *reinterpret_cast<int4 *>(a.out_info + (out_base + kf[kbase + oq].g) * 4) =
+                                make_int4(kf[kbase + oq].pk & 63, theta, direction0, direction1);
+                    }
+                    wave_lds_sync();  // the next group overwrites the box means; pass B reads the thetas
                 }
-                // F3: box means of the rotated pattern
-                {
-                    PatternPoint P[kBoxIters];
+            } else if (a.out_info) {
+                for (int kbase = wave * kGroup; kbase < nb; kbase += kGroup * kTileWaves)
+                    if (lane < min(kGroup, nb - kbase))
+                        *reinterpret_cast<int4 *>(a.out_info + (out_base + kf[kbase + lane].g) * 4) = make_int4(kf[kbase + lane].pk & 63, 0, 0, 0);
+            }
+            // ---- pass B: box means of the rotated pattern, bits, store.  The pattern points of the next group are
+            //      fetched (L2) while the current group's boxes are summed.
+            auto load_rotated = [&](int kbase, PatternPoint (&P)[kBoxIters]) {
+                const int last = min(kGroup, nb - kbase) - 1;
 #pragma unroll
-                    for (int u = 0; u < kBoxIters; ++u) {
-                        const int theta = kf[t_ok[u] ? kbase + task_kq[u] : kbase].theta;
-                        P[u] = a.lut[((int64_t)rec[u].idx * kNbOrientation + theta) * kNbPoints + task_p[u]];
-                    }
-#pragma unroll
-                    for (int u = 0; u < kBoxIters; ++u) {
-                        if (t_ok[u])
-                            vv[task_kq[u] * kVStride + task_p[u]] = (uint8_t)mean_intensity_tile(lds, ibase, rec[u].kx, rec[u].ky, P[u]);
-                    }
+                for (int u = 0; u < kBoxIters; ++u) {
+                    const KpRec r = kf[kbase + min(task_kq[u], last)];
+                    P[u] = a.lut[((int64_t)(r.pk & 63) * kNbOrientation + r.theta) * kNbPoints + task_p[u]];
                 }
+            };
+            PatternPoint Pc[kBoxIters];
+            if (wave * kGroup < nb) load_rotated(wave * kGroup, Pc);
+            for (int kbase = wave * kGroup; kbase < nb; kbase += kGroup * kTileWaves) {
+                const int last = min(kGroup, nb - kbase) - 1;
+                const int knext = kbase + kGroup * kTileWaves;
+                PatternPoint Pn[kBoxIters];
+                load_rotated(knext < nb ? knext : kbase, Pn);
+                KpRec rec[kBoxIters];
+                int sidx[kBoxIters];
+                uint32_t vdst[kBoxIters];
+                group_records(kbase, rec, sidx, vdst);
+#pragma unroll
+                for (int u = 0; u < kBoxIters; ++u)
+                    lds_st<uint8_t>(vdst[u], (uint8_t)mean_intensity_tile(ibase, rec[u].kx, rec[u].ky, Pc[u]));
                 wave_lds_sync();
-                // F4: lane = descriptor bit; lane q stores keypoint q's descriptor
+                // lane = descriptor bit; lane q stores keypoint q's descriptor
                 {
                     int va[kGroup], vb[kGroup];
 #pragma unroll
                     for (int qq = 0; qq < kGroup; ++qq) {
-                        va[qq] = vv[qq * kVStride + pi];
-                        vb[qq] = vv[qq * kVStride + pj];
+                        va[qq] = lds_ld<uint8_t>(pi + qq * kVStride);
+                        vb[qq] = lds_ld<uint8_t>(pj + qq * kVStride);
                     }
                     uint2 app = make_uint2(0, 0);
 #pragma unroll
@@ -817,7 +896,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                         const uint64_t bits = __ballot(bit);
                         if (lane == qq) app = make_uint2((uint32_t)bits, (uint32_t)(bits >> 32));
                     }
-                    if (lane < kGroup && kbase + lane < nb) {  // descriptor and validity flag out, side by side
+                    if (lane <= last) {  // descriptor and validity flag out, side by side
                         const int64_t out_idx = out_base + kf[kbase + lane].g;
                         if (one_batch) {
                             const uint2 mot = s_mot[kbase + lane];
@@ -829,6 +908,8 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                     }
                 }
                 wave_lds_sync();  // the next group overwrites the box means
+#pragma unroll
+                for (int u = 0; u < kBoxIters; ++u) Pc[u] = Pn[u];
             }
         }
     }
@@ -864,7 +945,7 @@ int launch_bin(const BinArgs &a, void *stream)
 
 int launch_tile(const TileArgs &a, void *stream)
 {
-    if (a.mip_n > 64 * kMipIters || a.mip_stride < a.mip_n) return (int)hipErrorInvalidValue;
+    if (a.mip_n > 64 * kMipIters || a.mip_n <= 64 * (kMipIters - 1) || a.mip_stride < a.mip_n) return (int)hipErrorInvalidValue;
     const void *fn = a.stamps ? reinterpret_cast<const void *>(&tile_kernel<true>) : reinterpret_cast<const void *>(&tile_kernel<false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kTileLdsBytes);
     if (e != hipSuccess) return (int)e;
