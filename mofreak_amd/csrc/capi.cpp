@@ -48,6 +48,7 @@ struct mofreak_ctx {
     unsigned long long *d_stamps = nullptr;  // MOFREAK_TILE_STAMPS=1: per-phase tick sums of the diagnostic tile kernel
     MipSample *d_mip_samples = nullptr;
     uint16_t *d_mip_pos = nullptr;
+    TileLane *d_tile_lanes = nullptr;
     int path_mode = MOFREAK_PATH_AUTO;
     int chunk_pairs_hint = 0;
     // optional per-launch timing (mofreak_set_profiling): events around the integral group and the describe launch
@@ -329,6 +330,7 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
             t.theta = ctx->d_theta;
             t.mip_samples = ctx->d_mip_samples;
             t.mip_pos = ctx->d_mip_pos;
+            t.lanes = ctx->d_tile_lanes;
             t.mip_n_cur = ctx->tables.mip_n_cur;
             t.mip_n = ctx->tables.mip_n;
             t.mip_stride = ctx->tables.mip_stride;
@@ -523,6 +525,40 @@ int mofreak_create(int device_id, const mofreak_params *params, mofreak_ctx **ou
     CREATE_TRY(hipMalloc((void **)&ctx->d_mip_pos, t.mip_pos.size() * sizeof(uint16_t)));
     CREATE_TRY(hipMemcpy(ctx->d_mip_samples, t.mip_samples.data(), t.mip_samples.size() * sizeof(MipSample), hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(ctx->d_mip_pos, t.mip_pos.data(), t.mip_pos.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    {
+        // the tile kernel's per-lane constants: task order of a group's 4 x 43 box means (the two outer rings of all
+        // four keypoints first: those boxes may need slices), the lane's descriptor pair and orientation pairs
+        TileLane lanes[64];
+        std::memset(lanes, 0, sizeof(lanes));
+        const int big = 12, group = 4;
+        for (int lane = 0; lane < 64; ++lane) {
+            for (int u = 0; u < 3; ++u) {
+                const int tk = lane + 64 * u;
+                int kq = 0, pt = kNbPoints - 1;  // past the group's 172 tasks: keypoint 0's last point once more
+                if (tk < group * big) {
+                    kq = tk / big;
+                    pt = tk % big;
+                } else if (tk < group * kNbPoints) {
+                    kq = (tk - group * big) / (kNbPoints - big);
+                    pt = big + (tk - group * big) % (kNbPoints - big);
+                }
+                lanes[lane].task[u] = static_cast<uint16_t>(kq | pt << 8);
+            }
+            lanes[lane].pair_i = t.bit_pair_i[lane];
+            lanes[lane].pair_j = t.bit_pair_j[lane];
+            for (int k = 0; k < 3; ++k) {
+                const int m = (lane & 15) + 16 * k;
+                if (m < kNbOrientPairs) {
+                    lanes[lane].opi[k] = static_cast<uint8_t>(t.orient[m].i);
+                    lanes[lane].opj[k] = static_cast<uint8_t>(t.orient[m].j);
+                    lanes[lane].owx[k] = static_cast<float>(t.orient[m].weight_dx) * (1.0f / 2048.0f);
+                    lanes[lane].owy[k] = static_cast<float>(t.orient[m].weight_dy) * (1.0f / 2048.0f);
+                }
+            }
+        }
+        CREATE_TRY(hipMalloc((void **)&ctx->d_tile_lanes, sizeof(lanes)));
+        CREATE_TRY(hipMemcpy(ctx->d_tile_lanes, lanes, sizeof(lanes), hipMemcpyHostToDevice));
+    }
     SmallTables st;
     std::memset(&st, 0, sizeof(st));
     std::memcpy(st.pattern_sizes, t.pattern_sizes, sizeof(st.pattern_sizes));
@@ -561,6 +597,7 @@ void mofreak_destroy(mofreak_ctx *ctx)
     if (ctx->d_stamps) (void)hipFree(ctx->d_stamps);
     if (ctx->d_mip_samples) (void)hipFree(ctx->d_mip_samples);
     if (ctx->d_mip_pos) (void)hipFree(ctx->d_mip_pos);
+    if (ctx->d_tile_lanes) (void)hipFree(ctx->d_tile_lanes);
     release(ctx->kp_key);
     release(ctx->sorted_idx);
     release(ctx->slow_list);

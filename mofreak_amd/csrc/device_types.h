@@ -107,6 +107,16 @@ struct BinArgs {
     int64_t n_keys;
 };
 
+// Per-lane constants of the tile kernel (64 entries, host-built): one lane's share of the tables of stage 3.
+struct TileLane {
+    uint16_t task[4];        // box-mean tasks of a group of four keypoints, passes 0..2: keypoint-in-group | point << 8
+    uint8_t pair_i, pair_j;  // the description pair of descriptor bit `lane`
+    uint8_t opi[3], opj[3];  // orientation pairs (lane & 15) + 16 k, k < 3 (the 45 pairs over 16 lanes; unused ones: 0, 0)
+    float owx[3], owy[3];    // their weights / 2048 (exact in float); 0 for unused slots
+    uint32_t pad[2];
+};
+static_assert(sizeof(TileLane) == 48, "three dwordx4 per lane");
+
 struct TileArgs {
     FrameArgs f;
     int32_t n_pairs;
@@ -116,6 +126,7 @@ struct TileArgs {
     const ThetaBound *theta;
     const MipSample *mip_samples;
     const uint16_t *mip_pos;
+    const TileLane *lanes;
     int32_t mip_n_cur, mip_n, mip_stride;
     const int64_t *kp_offsets;  // nullptr: shared list (tile lists are the same for every pair)
     int64_t n_kp;

@@ -339,24 +339,21 @@ void build_tables(const FreakParams &p, Tables &t)
         for (int v : t.mip_pos) t.mip_n_cur += v < kP19Pad ? 1 : 0;
         t.mip_stride = (t.mip_n + 63) / 64 * 64;
         t.mip_pos.resize(t.mip_stride, t.mip_pos.back());
-        t.mip_samples.assign(static_cast<size_t>(kTileMaxRoi + 1) * t.mip_stride, MipSample{0, 0, 0, 0, 0, 0, 0, 0});
+        t.mip_samples.assign(static_cast<size_t>(kTileMaxRoi + 1) * t.mip_stride, MipSample{0, 0, 0, 0, 0});
         for (int L = 1; L <= kTileMaxRoi; ++L) {
             const ResizeTap *tx = &t.resize[(static_cast<size_t>(L) * 2 + 0) * kPatch];
             const ResizeTap *ty = &t.resize[(static_cast<size_t>(L) * 2 + 1) * kPatch];
-            for (int j = 0; j < t.mip_n; ++j) {
+            for (int j = 0; j < t.mip_stride; ++j) {
+                const int frame = t.mip_pos[j] / kP19Pad;  // 0: current, 1: previous (staged kTileRW bytes further)
                 const int pos = std::min(t.mip_pos[j] % kP19Pad, kPatch * kPatch - 1), dy = pos / kPatch, dx = pos % kPatch;
                 MipSample &m = t.mip_samples[static_cast<size_t>(L) * t.mip_stride + j];
-                m.off00 = static_cast<uint16_t>(ty[dy].ofs * kTileStagePitch + tx[dx].ofs);
-                m.off01 = static_cast<uint16_t>(ty[dy].ofs * kTileStagePitch + tx[dx].ofs1);
-                m.off10 = static_cast<uint16_t>(ty[dy].ofs1 * kTileStagePitch + tx[dx].ofs);
-                m.off11 = static_cast<uint16_t>(ty[dy].ofs1 * kTileStagePitch + tx[dx].ofs1);
-                m.c0x = tx[dx].c0;
-                m.c1x = tx[dx].c1;
                 // the tile kernel reads a row pair as (off, off + 1): a clamped column has to carry a zero weight
-                if (m.off01 != m.off00 + 1 && m.c1x != 0) std::abort();
-                if (m.off11 != m.off10 + 1 && m.c1x != 0) std::abort();
-                m.c0y = ty[dy].c0;
-                m.c1y = ty[dy].c1;
+                if (tx[dx].ofs1 != tx[dx].ofs + 1 && tx[dx].c1 != 0) std::abort();
+                m.off_row0 = static_cast<uint16_t>(frame * kTileRW + ty[dy].ofs * kTileStagePitch + tx[dx].ofs);
+                m.off_row1 = static_cast<uint16_t>(frame * kTileRW + ty[dy].ofs1 * kTileStagePitch + tx[dx].ofs);
+                m.cx = static_cast<uint32_t>(static_cast<uint16_t>(tx[dx].c0)) | static_cast<uint32_t>(static_cast<uint16_t>(tx[dx].c1)) << 16;
+                m.c0y_s12 = static_cast<uint32_t>(static_cast<uint16_t>(ty[dy].c0)) << 12;
+                m.c1y_s12 = static_cast<uint32_t>(static_cast<uint16_t>(ty[dy].c1)) << 12;
             }
         }
     }

@@ -55,9 +55,10 @@ constexpr int kP19Pad = 368;             // bytes reserved per 19x19 buffer
 
 // One of the 19x19 output pixels the MIP actually reads, for one ROI side L: the four source bytes (offsets from
 // the ROI's top-left inside the kTileStagePitch-pitch staged rows) and the fixed-point weights of cv::resize.
-struct MipSample {
-    uint16_t off00, off01, off10, off11;
-    int16_t c0x, c1x, c0y, c1y;
+struct MipSample {   // 16 bytes: one dwordx4 per lane and pass
+    uint16_t off_row0, off_row1;  // first source byte of the two rows; the frame's offset inside a staged row is included
+    uint32_t cx;                  // x weights, c0 | c1 << 16 (11-bit fixed point); the second byte of a row is the next one
+    uint32_t c0y_s12, c1y_s12;    // y weights << 12: (w * (t >> 4)) >> 16 == mul_hi_u24(t & ~15, w << 12)
 };
 
 // One step of the thetaIdx staircase: the direction (cos, sin) of the exact angle at which the index changes.

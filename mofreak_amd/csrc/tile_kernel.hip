@@ -43,8 +43,7 @@ constexpr int kIPitch = kTileStagePitch / 2;         // LDS integral pitch (u16)
 constexpr int kIColOff = 7;
 constexpr int kIPitchDw = kIPitch / 2;
 constexpr int kIntegralBytes = (kTileRH + 1) * kTileStagePitch;
-constexpr int kStageTasks = 2 * kTileRH * (kTileRW / 16);                      // 16-byte pieces of the largest region
-constexpr int kStageIters = (kStageTasks + kTileThreads - 1) / kTileThreads;
+constexpr int kStageIters = (kTileRH + 31) / 32;                               // 32-row steps over the largest region
 constexpr int kRowGroupIters = (kTileRH / 4 + kTileWaves - 1) / kTileWaves;   // 4-row groups per wave in the row pass
 constexpr int kColBlockRows = 16;
 constexpr int kMaxColBlocks = kTileRH / kColBlockRows;                         // 10
@@ -66,7 +65,8 @@ constexpr int kOffStamps = kOffMot + kBatch * 8;                             // 
 constexpr int kTileLdsBytes = kOffStamps + 256;
 static_assert(kP19Wave % 16 == 0 && kOffScratch % 16 == 0 && kOffTheta % 16 == 0, "LDS carve alignment");
 static_assert(2 * kTileLdsBytes <= 160 * 1024, "two workgroups per CU");
-static_assert(kTileRW % 16 == 0 && kTileRH % kColBlockRows == 0 && kTileRW / 16 <= 16, "region blocking");
+static_assert(kTileRW % 16 == 0 && kTileRH % kColBlockRows == 0 && kTileRW / 16 <= 16 && kTileThreads == 32 * 16, "region blocking");
+static_assert(kTileH + 2 * kMinHalo >= 32, "a last partial staging step can be shifted up to a full one");
 static_assert(kTileStagePitch % 16 == 0 && 2 * kTileRW <= kTileStagePitch, "a region row's staged bytes fit its integral row");
 static_assert(kMaxColBlocks * kMaxQcols * 8 <= kScratchBytes, "column-block totals fit the scratch area");
 static_assert(kMaxColBlocks * kMaxQcols <= kTileThreads, "one column task per thread");
@@ -440,77 +440,71 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     };
 
     // ================= stage 0: the region's gray bytes -> LDS, 16 per lane and step.  Region row r goes to LDS row
-    // r + 1: `current` at byte 0, `previous` at byte kTileRW.  All loads are issued before anything waits on one (a
-    // branch per load would make the compiler drain the memory queue at every join); the small tables and the first
-    // batch's keypoint records are fetched behind them.
+    // r + 1: `current` at byte 0, `previous` at byte kTileRW.  The 16 lanes of a lane row share a region row (as in
+    // the row pass), a workgroup takes 32 rows per step: per-lane offsets are computed once, a step moves the scalar
+    // base.  All loads are issued before anything waits on one (a branch per load would make the compiler drain the
+    // memory queue at every join); the small tables and the first batch's keypoint records are fetched behind them.
     const int runs = RW >> 4;
-    const int per_frame = RH * runs;
-    const uint32_t runs_m20 = (1u << 20) / (uint32_t)runs + 1;  // t / runs for t < 2^12 as (t * m20) >> 20
-    auto stage_rq = [&](int t, int &fr, int &r, int &q) {
-        fr = t >= per_frame ? 1 : 0;
-        const int tt = t - fr * per_frame;
-        r = (int)(((uint32_t)tt * runs_m20) >> 20);
-        q = tt - r * runs;
-    };
-    auto stage_dst = [&](int fr, int r, int q) -> uint8_t * { return lds + kOffIntegral + (r + 1) * kTileStagePitch + fr * kTileRW + 16 * q; };
+    const int sq = tid & 15, sr = tid >> 4;
     const bool inside = ox >= 0 && oy >= 0 && ox + RW <= W && oy + RH <= H;  // the whole region lies in the image
-    Px16 v[kStageIters];
-    if (fast8 && (inside || (W & 7) == 0)) {
+    const bool wide = fast8 && (inside || (W & 7) == 0);
+    const uint32_t stage_lds = lds0 + kOffIntegral + (sr + 1) * kTileStagePitch + 16 * sq;
+    Px16 v[2][kStageIters];
+    if (wide) {
         if (inside) {
+            const uint32_t voff = (uint32_t)sr * (uint32_t)a.f.row_stride + 16u * (uint32_t)min(sq, runs - 1);
 #pragma unroll
             for (int u = 0; u < kStageIters; ++u) {
-                const int t = min(tid + u * kTileThreads, 2 * per_frame - 1);
-                int fr, r, q;
-                stage_rq(t, fr, r, q);
-                v[u] = *reinterpret_cast<const Px16 *>((fr ? prev : cur) + (int64_t)(oy + r) * a.f.row_stride + (ox + 16 * q));
+                const int64_t base = (int64_t)(oy + min(32 * u, RH - 32)) * a.f.row_stride + ox;  // (a last partial step re-reads rows)
+                v[0][u] = *reinterpret_cast<const Px16 *>(cur + base + voff);
+                v[1][u] = *reinterpret_cast<const Px16 *>(prev + base + voff);
             }
         } else {
             // a tile on the image border, W a multiple of 8: every 8-byte half of a piece is all inside or all outside
             // the image.  Outside pixels are never read by a keypoint that passed the border tests: any value will do,
             // so the loads are clamped into the image instead of branching.
+            const int gx = ox + 16 * min(sq, runs - 1);
+            const uint32_t xlo = (uint32_t)min(max(gx, 0), W - 8), xhi = (uint32_t)min(max(gx + 8, 0), W - 8);
 #pragma unroll
             for (int u = 0; u < kStageIters; ++u) {
-                const int t = min(tid + u * kTileThreads, 2 * per_frame - 1);
-                int fr, r, q;
-                stage_rq(t, fr, r, q);
-                const int gy = min(max(oy + r, 0), H - 1), gx = ox + 16 * q;
-                const uint8_t *row = (fr ? prev : cur) + (int64_t)gy * a.f.row_stride;
-                const uint2 lo = *reinterpret_cast<const uint2 *>(row + min(max(gx, 0), W - 8));
-                const uint2 hi = *reinterpret_cast<const uint2 *>(row + min(max(gx + 8, 0), W - 8));
-                v[u].w[0] = lo.x;
-                v[u].w[1] = lo.y;
-                v[u].w[2] = hi.x;
-                v[u].w[3] = hi.y;
+                const int gy = min(max(oy + min(32 * u, RH - 32) + sr, 0), H - 1);
+                const int64_t ro = (int64_t)gy * a.f.row_stride;
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const uint8_t *row = (f ? prev : cur) + ro;
+                    const uint2 lo = *reinterpret_cast<const uint2 *>(row + xlo);
+                    const uint2 hi = *reinterpret_cast<const uint2 *>(row + xhi);
+                    v[f][u].w[0] = lo.x;
+                    v[f][u].w[1] = lo.y;
+                    v[f][u].w[2] = hi.x;
+                    v[f][u].w[3] = hi.y;
+                }
             }
         }
     }
-    // per-lane constants of the MIP sampling passes: the LDS address each sampled pixel goes to, and -- once the ROI
-    // side is known -- the LDS addresses of its two source rows for a ROI at the region's origin, frame included (the
-    // second byte of a row pair is the next one: where cv::resize clamps the column instead, its weight is zero).
-    // Their loads are issued here, ahead of stage 0, so that the global latencies overlap.
+
+    // per-lane constants of the MIP sampling passes: the LDS address the lane's pixels go to, and -- once the ROI side
+    // is known -- the LDS addresses of each pixel's two source rows for a ROI at the region's origin (the second byte
+    // of a row pair is the next one: where cv::resize clamps the column instead, its weight is zero) and its weights.
     struct MipLane {
         uint32_t dst_dword, dst_tail;              // where the lane's packed four pixels / its last-pass pixel go
         uint32_t a0[kMipIters], a1[kMipIters];
-        uint32_t cxp[kMipIters];                   // the two 11-bit x weights, packed as loaded (c0 | c1 << 16)
-        uint32_t c0ys[kMipIters], c1ys[kMipIters];  // the y weights << 12: (w * (t >> 4)) >> 16 == mul_hi_u24(t & ~15, w << 12)
+        uint32_t cxp[kMipIters];                   // the two 11-bit x weights, c0 | c1 << 16
+        uint32_t c0ys[kMipIters], c1ys[kMipIters];  // the y weights << 12
     } ml;
     const uint32_t p19 = lds0 + kOffScratch + wave * kP19Wave;  // this wave's pair of 19x19 buffers
-    uint16_t mpos[kMipIters];
-#pragma unroll
-    for (int u = 0; u < kMipIters; ++u) mpos[u] = a.mip_pos[min(lane + 64 * u, a.mip_stride - 1)];
-    ml.dst_dword = p19 + mpos[0];  // byte 0 of the lane's dword (launch_tile's table check: passes 0..3 are its four bytes)
-    ml.dst_tail = p19 + mpos[kMipIters - 1];
+    ml.dst_dword = p19 + a.mip_pos[lane];  // byte 0 of the lane's dword: passes 0..3 are its four bytes (tables.cpp)
+    ml.dst_tail = p19 + a.mip_pos[lane + 64 * (kMipIters - 1)];
     auto load_samples = [&](int L) {
-        const MipSample *tab = a.mip_samples + (int64_t)L * a.mip_stride;
+        const MipSample *tab = a.mip_samples + (int64_t)L * a.mip_stride + lane;
 #pragma unroll
         for (int u = 0; u < kMipIters; ++u) {
-            const MipSample sm = tab[min(lane + 64 * u, a.mip_stride - 1)];
-            const uint32_t frame = lds0 + kOffIntegral + (mpos[u] < kP19Pad ? 0 : kTileRW);
-            ml.a0[u] = frame + sm.off00;
-            ml.a1[u] = frame + sm.off10;
-            ml.cxp[u] = (uint32_t)(uint16_t)sm.c0x | (uint32_t)(uint16_t)sm.c1x << 16;
-            ml.c0ys[u] = (uint32_t)(uint16_t)sm.c0y << 12;
-            ml.c1ys[u] = (uint32_t)(uint16_t)sm.c1y << 12;
+            const MipSample sm = tab[64 * u];
+            ml.a0[u] = lds0 + kOffIntegral + sm.off_row0;
+            ml.a1[u] = lds0 + kOffIntegral + sm.off_row1;
+            ml.cxp[u] = sm.cx;
+            ml.c0ys[u] = sm.c0y_s12;
+            ml.c1ys[u] = sm.c1y_s12;
         }
     };
     if (uniform) load_samples(tile_L);  // one ROI side in the whole tile (the usual case): its samples stay in registers
@@ -518,20 +512,21 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
 
     make_records(0, min(kBatch, n_tile_kp));
     if (tid < kThetaBounds) s_theta[tid] = a.theta[tid];
-    if (fast8 && (inside || (W & 7) == 0)) {
+    if (wide) {
+        if (sq < runs) {
 #pragma unroll
-        for (int u = 0; u < kStageIters; ++u) {
-            const int t = tid + u * kTileThreads;
-            if (t < 2 * per_frame) {
-                int fr, r, q;
-                stage_rq(t, fr, r, q);
-                *reinterpret_cast<uint4 *>(stage_dst(fr, r, q)) = make_uint4(v[u].w[0], v[u].w[1], v[u].w[2], v[u].w[3]);
+            for (int u = 0; u < kStageIters; ++u) {
+                if (32 * u < RH) {  // a last partial step: the rows it re-read are written again, with the same bytes
+                    const uint32_t d = stage_lds + min(32 * u, RH - 32) * kTileStagePitch;
+                    lds_st<LdsU4>(d, LdsU4{v[0][u].w[0], v[0][u].w[1], v[0][u].w[2], v[0][u].w[3]});
+                    lds_st<LdsU4>(d + kTileRW, LdsU4{v[1][u].w[0], v[1][u].w[1], v[1][u].w[2], v[1][u].w[3]});
+                }
             }
         }
     } else {  // unaligned frames or an odd width: byte by byte, zero outside the image
-        for (int t = tid; t < 2 * per_frame; t += kTileThreads) {
-            int fr, r, q;
-            stage_rq(t, fr, r, q);
+        for (int t = tid; t < 2 * RH * runs; t += kTileThreads) {
+            const int fr = t >= RH * runs ? 1 : 0, tt = t - fr * RH * runs;
+            const int r = tt / runs, q = tt - r * runs;
             const int gy = oy + r, gx = ox + 16 * q;
             const uint8_t *row = (fr ? prev : cur) + (int64_t)gy * a.f.row_stride;
             uint32_t w4[4] = {0, 0, 0, 0};
@@ -541,7 +536,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                     if (x >= 0 && x < W) w4[k >> 2] |= (uint32_t)row[x] << (8 * (k & 3));
                 }
             }
-            *reinterpret_cast<uint4 *>(stage_dst(fr, r, q)) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            lds_st<LdsU4>(lds0 + kOffIntegral + (r + 1) * kTileStagePitch + fr * kTileRW + 16 * q, LdsU4{w4[0], w4[1], w4[2], w4[3]});
         }
     }
     __syncthreads();  TILE_STAMP(0);
@@ -755,39 +750,29 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     if (!(MOFREAK_EXP_SKIP & 4)) {
         const uint32_t vv = lds0 + kOffScratch + wave * (kGroup * kVStride);   // this wave's box means [kGroup][kVStride]
         const uint32_t ibase = lds0 + kOffIntegral + 2 * (kIColOff - oy * kIPitch - ox);
-        // box-mean tasks of a group: the outer two rings (whose boxes may need slices) of all four keypoints first.
-        // Tasks past the group's 172 recompute keypoint 0's point 42 (same value, same address: harmless).
+        // per-lane constants (host-built, TileLane): the box-mean tasks of a group -- the outer two rings (whose boxes may
+        // need slices) of all four keypoints first; tasks past the group's 172 recompute keypoint 0's point 42 (same
+        // value, same address: harmless) -- the lane's description pair, and for the orientation pass (16 lanes per
+        // keypoint, three of the 45 pairs each) the pairs and their weights as floats: w / 2048 is exact, and so is its
+        // product with a difference of two bytes; truncated like the reference's integer division.
+        const TileLane tl = a.lanes[lane];
         int task_kq[kBoxIters], task_p[kBoxIters];
 #pragma unroll
         for (int u = 0; u < kBoxIters; ++u) {
-            const int t = lane + 64 * u;
-            if (t < kGroup * kBigPoints) {
-                task_kq[u] = t / kBigPoints;
-                task_p[u] = t % kBigPoints;
-            } else if (t < kGroup * kNbPoints) {
-                const int t2 = t - kGroup * kBigPoints;
-                task_kq[u] = t2 / (kNbPoints - kBigPoints);
-                task_p[u] = kBigPoints + t2 % (kNbPoints - kBigPoints);
-            } else {
-                task_kq[u] = 0;
-                task_p[u] = kNbPoints - 1;
-            }
+            task_kq[u] = tl.task[u] & 0xff;
+            task_p[u] = tl.task[u] >> 8;
         }
-        // orientation pass: 16 lanes per keypoint, three of the 45 pairs each; weights as floats (w / 2048 is exact, and
-        // so is its product with a difference of two bytes), truncated like the reference's integer division
         const int oq = lane >> 4, osub = lane & 15;
         uint32_t opi[3], opj[3];
         float owx[3], owy[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const int m = osub + 16 * k;
-            const OrientPair op = st->orient[min(m, kNbOrientPairs - 1)];
-            opi[k] = vv + oq * kVStride + op.i;
-            opj[k] = vv + oq * kVStride + op.j;
-            owx[k] = m < kNbOrientPairs ? (float)op.weight_dx * (1.0f / 2048.0f) : 0.0f;
-            owy[k] = m < kNbOrientPairs ? (float)op.weight_dy * (1.0f / 2048.0f) : 0.0f;
+            opi[k] = vv + oq * kVStride + tl.opi[k];
+            opj[k] = vv + oq * kVStride + tl.opj[k];
+            owx[k] = tl.owx[k];
+            owy[k] = tl.owy[k];
         }
-        const uint32_t pi = vv + st->bit_pair_i[lane], pj = vv + st->bit_pair_j[lane];
+        const uint32_t pi = vv + tl.pair_i, pj = vv + tl.pair_j;
         PatternPoint P0[kBoxIters];   // un-rotated pattern points of this lane's tasks, cached per scale index
         int have_idx = -1;
 
