@@ -49,6 +49,7 @@ struct mofreak_ctx {
     MipSample *d_mip_samples = nullptr;
     uint16_t *d_mip_pos = nullptr;
     TileLane *d_tile_lanes = nullptr;
+    BoxInt *d_lut_int = nullptr;
     int path_mode = MOFREAK_PATH_AUTO;
     int chunk_pairs_hint = 0;
     // optional per-launch timing (mofreak_set_profiling): events around the integral group and the describe launch
@@ -326,6 +327,14 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
             t.tiles_x = tiles_x;
             t.tiles_y = tiles_y;
             t.lut = ctx->d_lut;
+            t.lut_int = ctx->d_lut_int;
+            // coordinates below 2^11 / 2^12 / 2^13 (pattern reach included): two float roundings of at most 2^-14 /
+            // 2^-13 / 2^-12 each; twice their sum as the margin
+            {
+                const int reach = std::max(g.W, g.H) + kTileHalo;
+                t.box_margin = reach < 2048 ? 1.0f / 4096 : reach < 4096 ? 1.0f / 2048 : reach < 8192 ? 1.0f / 1024 : 2.0f;
+                if (const char *ev = std::getenv("MOFREAK_EXP_BOX_MARGIN")) t.box_margin = (float)std::atof(ev);
+            }
             t.small = ctx->d_small;
             t.theta = ctx->d_theta;
             t.mip_samples = ctx->d_mip_samples;
@@ -512,6 +521,8 @@ int mofreak_create(int device_id, const mofreak_params *params, mofreak_ctx **ou
 
     const Tables &t = ctx->tables;
     CREATE_TRY(hipMalloc((void **)&ctx->d_lut, t.lut.size() * sizeof(PatternPoint)));
+    CREATE_TRY(hipMalloc((void **)&ctx->d_lut_int, t.lut_int.size() * sizeof(BoxInt)));
+    CREATE_TRY(hipMemcpy(ctx->d_lut_int, t.lut_int.data(), t.lut_int.size() * sizeof(BoxInt), hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc((void **)&ctx->d_resize, t.resize.size() * sizeof(ResizeTap)));
     CREATE_TRY(hipMalloc((void **)&ctx->d_small, sizeof(SmallTables)));
     CREATE_TRY(hipMalloc((void **)&ctx->d_status, sizeof(int32_t)));
@@ -598,6 +609,7 @@ void mofreak_destroy(mofreak_ctx *ctx)
     if (ctx->d_mip_samples) (void)hipFree(ctx->d_mip_samples);
     if (ctx->d_mip_pos) (void)hipFree(ctx->d_mip_pos);
     if (ctx->d_tile_lanes) (void)hipFree(ctx->d_tile_lanes);
+    if (ctx->d_lut_int) (void)hipFree(ctx->d_lut_int);
     release(ctx->kp_key);
     release(ctx->sorted_idx);
     release(ctx->slow_list);

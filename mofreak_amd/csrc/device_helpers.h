@@ -123,12 +123,13 @@ __device__ __forceinline__ int theta_index(const ThetaBound *__restrict__ tb, in
     const int n = upper ? 128 : 127;
     const ThetaBound *t = upper ? tb : tb + 128;
     const int c0 = min(max((int)(upper ? pos + 0.5f : pos), 1), n - 1);  // the suggested count: within one of the true one
-    const double y = (double)(upper ? direction1 : -direction1), x = (double)direction0;
+    // upper half plane: step passed <=> cross = y * c - x * s >= 0 with y = direction1.  Lower half plane, y = -direction1:
+    // passed <=> cross > 0; with both components negated instead the same expression is -cross, and "-cross >= 0" is
+    // "not passed" (negation commutes with the roundings, and -0 >= 0 holds like 0 <= 0).
+    const double y = (double)direction1, x = (double)(upper ? direction0 : -direction0);
     const ThetaBound b0 = t[c0 - 1], b1 = t[c0];   // steps number c0 and c0 + 1
-    const double cross0 = y * b0.c - x * b0.s, cross1 = y * b1.c - x * b1.s;
-    const bool p0 = upper ? (cross0 >= 0.0) : (cross0 > 0.0);
-    const bool p1 = upper ? (cross1 >= 0.0) : (cross1 > 0.0);
-    const int count = c0 - 1 + (p0 ? 1 : 0) + (p1 ? 1 : 0);  // steps are ordered: passing step c0 + 1 implies passing step c0
+    const int ge = ((y * b0.c - x * b0.s >= 0.0) ? 1 : 0) + ((y * b1.c - x * b1.s >= 0.0) ? 1 : 0);
+    const int count = upper ? c0 - 1 + ge : c0 + 1 - ge;  // steps are ordered: passing step c0 + 1 implies passing step c0
     return upper ? count : (count == 0 ? 0 : kNbOrientation - count);
 }
 

@@ -122,6 +122,8 @@ struct TileArgs {
     int32_t n_pairs;
     int32_t tiles_x, tiles_y;
     const PatternPoint *lut;
+    const BoxInt *lut_int;      // boxes of lut for keypoints at integer coordinates
+    float box_margin;           // BoxInt entries with a larger margin are exact for this frame size (2.0: none)
     const SmallTables *small;
     const ThetaBound *theta;
     const MipSample *mip_samples;

@@ -230,6 +230,36 @@ void build_tables(const FreakParams &p, Tables &t)
         }
     }
 
+    // ---- the same boxes for keypoints at integer coordinates (BoxInt)
+    t.lut_int.assign(t.lut.size(), BoxInt{0, 0, 0, 0, 1, 0.0f, 0.0f});
+    for (size_t i = 0; i < t.lut.size(); ++i) {
+        const PatternPoint &P = t.lut[i];
+        const double args[4] = {static_cast<double>(P.x) - P.sigma + 0.5, static_cast<double>(P.y) - P.sigma + 0.5,
+                                static_cast<double>(P.x) + P.sigma + 0.5, static_cast<double>(P.y) + P.sigma + 0.5};
+        double margin = 1.0;
+        int fl[4];
+        for (int k = 0; k < 4; ++k) {
+            const double f = std::floor(args[k]);
+            fl[k] = static_cast<int>(f);
+            margin = std::min(margin, std::min(args[k] - f, f + 1.0 - args[k]));
+        }
+        const int dxl = fl[0], dyt = fl[1], w = fl[2] + 1 - fl[0], h = fl[3] + 1 - fl[1];
+        BoxInt &b = t.lut_int[i];
+        const int off = 2 * (dyt * (kTileStagePitch / 2) + dxl);
+        if (w < 1 || h < 1 || w > 127 || h > 127 || off < -32768 || off > 32767) {
+            b.margin = 0.0f;  // never taken: the float path handles it (patterns far beyond the tile path's reach)
+            continue;
+        }
+        const int rps = std::max(1, 257 / w), first = std::min(rps, h);
+        b.off_tl = static_cast<int16_t>(off);
+        b.w2 = static_cast<uint16_t>(2 * w);
+        b.step1 = static_cast<uint16_t>(first * kTileStagePitch);
+        b.left = static_cast<uint8_t>(h - first);
+        b.rps = static_cast<uint8_t>(std::min(rps, 255));
+        b.inv_area = 1.0f / static_cast<float>(w * h);
+        b.margin = static_cast<float>(margin);
+    }
+
     // ---- orientation pairs and their fixed-point weights (from scale 0, orientation 0)
     int ij[kNbOrientPairs][2];
     orientation_pair_indices(ij);

@@ -31,6 +31,21 @@ struct PatternPoint {  // 16 bytes on the device so a lane fetches one point wit
     int32_t rows_per_slice;
 };
 
+// The sampling box of one pattern point for a keypoint at INTEGER coordinates, where the box is a fixed offset from the
+// keypoint: meanIntensity's corners are int(fl(fl(P.x + kx) - r) + 0.5) etc., and for an integral kx the two float
+// roundings move the argument by at most one ulp of the coordinate's binade, so the corner is kx + floor(P.x - r + 0.5)
+// whenever that argument is further than `margin` from a rounding boundary (the tile kernel compares margin with the
+// bound that goes with the frame size and falls back to the float expressions otherwise).
+struct BoxInt {
+    int16_t off_tl;           // byte offset of the top-left corner from the keypoint's own corner in the u16 integral rows
+    uint16_t w2;              // 2 * box width: byte distance of the right corners
+    uint16_t step1;           // byte distance to the bottom corners of the first slice (min(rows_per_slice, h) rows)
+    uint8_t left, rps;        // rows after the first slice; rows per slice
+    float inv_area;           // 1 / (w * h), correctly rounded
+    float margin;             // smallest distance of the four corner arguments from a rounding boundary
+};
+static_assert(sizeof(BoxInt) == 16, "one dwordx4 per lane");
+
 struct OrientPair {
     int32_t i, j, weight_dx, weight_dy;
 };
@@ -77,6 +92,7 @@ struct FreakParams {
 
 struct Tables {
     std::vector<PatternPoint> lut;        // [64][256][43]
+    std::vector<BoxInt> lut_int;          // same indexing: the boxes of lut for integer keypoint coordinates
     int32_t pattern_sizes[kNbScales];
     OrientPair orient[kNbOrientPairs];
     // The 64 description pairs that land in descriptor bytes 0..7, indexed by output bit

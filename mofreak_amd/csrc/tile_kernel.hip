@@ -61,7 +61,8 @@ constexpr int kScratchBytes = kTileWaves * kP19Wave;           // stage 1: 19x19
 constexpr int kOffTheta = kOffScratch + kScratchBytes;
 constexpr int kOffKf = kOffTheta + kThetaBounds * (int)sizeof(ThetaBound);   // the batch's keypoint records
 constexpr int kOffMot = kOffKf + kBatch * 16;                                // motion bytes kept for the fused store
-constexpr int kOffStamps = kOffMot + kBatch * 8;                             // diagnostic build only: 32 x u64
+constexpr int kOffKint = kOffMot + kBatch * 8;                               // keypoints at integer coordinates: their corner in the integral
+constexpr int kOffStamps = kOffKint + kBatch * 4;                            // diagnostic build only: 32 x u64
 constexpr int kTileLdsBytes = kOffStamps + 256;
 static_assert(kP19Wave % 16 == 0 && kOffScratch % 16 == 0 && kOffTheta % 16 == 0, "LDS carve alignment");
 static_assert(2 * kTileLdsBytes <= 160 * 1024, "two workgroups per CU");
@@ -182,6 +183,29 @@ __device__ __forceinline__ int mean_intensity_tile(uint32_t ibase, float kx, flo
         left -= step;
     }
     return div_box_small(sum, (int)__umul24(w, h)) & 0xff;
+}
+
+// The same box mean for a keypoint at integer coordinates whose box is a fixed offset from it (BoxInt, tables.h):
+// `kaddr` = LDS byte address of the keypoint's own corner in the integral.
+__device__ __forceinline__ int mean_intensity_int(uint32_t kaddr, const BoxInt b)
+{
+    const uint32_t a0 = kaddr + (uint32_t)(int)b.off_tl, a1 = a0 + b.step1;
+    int prev = (int)lds_ld<uint16_t>(a0 + b.w2) - (int)lds_ld<uint16_t>(a0);
+    int cur = (int)lds_ld<uint16_t>(a1 + b.w2) - (int)lds_ld<uint16_t>(a1);
+    int sum = (cur - prev) & 0xffff;
+    if (b.left) {  // outer rings of the larger patterns only
+        uint32_t addr = a1;
+        int left = b.left;
+        do {
+            prev = cur;
+            const int step = min((int)b.rps, left);
+            addr += __umul24(step, kTileStagePitch);
+            cur = (int)lds_ld<uint16_t>(addr + b.w2) - (int)lds_ld<uint16_t>(addr);
+            sum += (cur - prev) & 0xffff;
+            left -= step;
+        } while (left > 0);
+    }
+    return (int)__builtin_fmaf((float)sum, b.inv_area, 0.5f * b.inv_area) & 0xff;  // div_box_small with the host's reciprocal
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -416,6 +440,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
 
     uint2 *s_mot = reinterpret_cast<uint2 *>(lds + kOffMot);
     KpRec *kf = reinterpret_cast<KpRec *>(lds + kOffKf);
+    uint32_t *kint = reinterpret_cast<uint32_t *>(lds + kOffKint);
     const bool one_batch = n_tile_kp <= kBatch;
     // The binning pass recorded the smallest and largest ROI side of the tile: equal in the usual case.
     const int tile_L = (int)a.tile_lmin[key];
@@ -431,6 +456,10 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             k.pk = (uint16_t)((kp.packed >> 16) | (kp.packed & 0xff) << 6 | ((kp.packed >> 8) & 0xff) << 11);
             k.theta = 0;
             kf[tid] = k;
+            // a keypoint at integer coordinates: LDS address of its own corner (ky, kx) in the integral; else the top bit
+            const int xi = (int)kp.x, yi = (int)kp.y;
+            const bool integral = (float)xi == kp.x && (float)yi == kp.y;
+            kint[tid] = integral ? lds0 + kOffIntegral + 2 * (kIColOff + (yi - oy) * kIPitch + (xi - ox)) : 0x80000000u;
         }
     };
     // where a keypoint's ROI starts in the staged rows (:293-295, :460 float -> int parameters)
@@ -773,8 +802,21 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             owy[k] = tl.owy[k];
         }
         const uint32_t pi = vv + tl.pair_i, pj = vv + tl.pair_j;
-        PatternPoint P0[kBoxIters];   // un-rotated pattern points of this lane's tasks, cached per scale index
-        int have_idx = -1;
+        // constant per lane: where a full group's tasks find their keypoint's record and put their box mean
+        uint32_t rec_full[kBoxIters], kint_full[kBoxIters], vdst_full[kBoxIters];
+#pragma unroll
+        for (int u = 0; u < kBoxIters; ++u) {
+            rec_full[u] = lds0 + kOffKf + task_kq[u] * 16;
+            kint_full[u] = lds0 + kOffKint + task_kq[u] * 4;
+            vdst_full[u] = vv + task_kq[u] * kVStride + task_p[u];
+        }
+        struct Task {       // one box-mean task of a group
+            uint32_t c0, c1;    // (kx, ky) as bits -- or, when every keypoint of the batch has integer coordinates, the LDS
+                                // addresses of its corner in the integral and of its record
+            uint32_t pk_theta;  // scale index | ROI bits << 6 | theta << 16
+            uint32_t vdst;      // where the box mean goes
+        };
+        const float box_margin = a.box_margin;
 
         for (int b0 = 0; b0 < n_tile_kp; b0 += kBatch) {
             const int nb = min(kBatch, n_tile_kp - b0);
@@ -783,34 +825,77 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                 make_records(b0, nb);
                 __syncthreads();
             }
+            // What the batch's keypoints have in common (every wave works it out for itself from the records): one
+            // FREAK scale -- then a lane's un-rotated pattern points are loop invariants -- and integer coordinates --
+            // then boxes are fixed offsets from the keypoint (BoxInt) and no float arithmetic is needed to place them.
+            bool one_scale, all_int;
+            {
+                const int k1 = min(lane, nb - 1), k2 = min(lane + 64, nb - 1);
+                const uint32_t s0 = kf[0].pk & 63;
+                one_scale = __all((kf[k1].pk & 63) == s0 && (kf[k2].pk & 63) == s0);
+                all_int = __all((int)(kint[k1] | kint[k2]) >= 0) && box_margin < 1.0f;
+            }
             // a group's last keypoints may be missing: their tasks redo the group's last real keypoint
-            auto group_records = [&](int kbase, KpRec (&rec)[kBoxIters], int (&sidx)[kBoxIters], uint32_t (&vdst)[kBoxIters]) {
+            auto group_tasks = [&](int kbase, Task (&t)[kBoxIters]) {
                 const int last = min(kGroup, nb - kbase) - 1;
 #pragma unroll
                 for (int u = 0; u < kBoxIters; ++u) {
-                    const int kq = min(task_kq[u], last);
-                    rec[u] = kf[kbase + kq];
-                    sidx[u] = rec[u].pk & 63;
-                    vdst[u] = vv + kq * kVStride + task_p[u];
+                    uint32_t ra = rec_full[u] + kbase * 16, ka = kint_full[u] + kbase * 4;
+                    t[u].vdst = vdst_full[u];
+                    if (last != kGroup - 1) {  // (wave-uniform)
+                        const int kq = min(task_kq[u], last);
+                        ra = lds0 + kOffKf + (kbase + kq) * 16;
+                        ka = lds0 + kOffKint + (kbase + kq) * 4;
+                        t[u].vdst = vv + kq * kVStride + task_p[u];
+                    }
+                    t[u].pk_theta = lds_ld<uint32_t>(ra + 12);
+                    if (all_int) {
+                        t[u].c0 = lds_ld<uint32_t>(ka);
+                        t[u].c1 = ra;
+                    } else {
+                        const LdsU2 xy = lds_ld<LdsU2>(ra);
+                        t[u].c0 = xy.x;
+                        t[u].c1 = xy.y;
+                    }
                 }
             };
+            // entry: the task's BoxInt (all_int) or PatternPoint, as loaded; e: its index in the tables
+            auto box = [&](const Task t, const LdsU4 entry, int64_t e) -> int {
+                if (all_int) {
+                    const BoxInt B = __builtin_bit_cast(BoxInt, entry);
+                    if (B.margin > box_margin) return mean_intensity_int(t.c0, B);
+                    // a corner too close to a rounding boundary (rare): the float expressions
+                    return mean_intensity_tile(ibase, lds_ld<float>(t.c1), lds_ld<float>(t.c1 + 4), a.lut[e]);
+                }
+                return mean_intensity_tile(ibase, __builtin_bit_cast(float, t.c0), __builtin_bit_cast(float, t.c1), __builtin_bit_cast(PatternPoint, entry));
+            };
+            auto load_entry = [&](int64_t e) -> LdsU4 {
+                return all_int ? *reinterpret_cast<const LdsU4 *>(a.lut_int + e) : *reinterpret_cast<const LdsU4 *>(a.lut + e);
+            };
+
             // ---- pass A over the wave's groups: un-rotated box means, orientation sums, theta -> the records
             if (orientation_normalized) {
+                LdsU4 E0[kBoxIters];   // the lane's un-rotated entries, kept across groups of one scale
+                int have_idx = -1;
+                if (one_scale) {
+                    have_idx = kf[0].pk & 63;
+#pragma unroll
+                    for (int u = 0; u < kBoxIters; ++u) E0[u] = load_entry((int64_t)have_idx * kNbOrientation * kNbPoints + task_p[u]);
+                }
                 for (int kbase = wave * kGroup; kbase < nb; kbase += kGroup * kTileWaves) {
                     const int last = min(kGroup, nb - kbase) - 1;
-                    KpRec rec[kBoxIters];
-                    int sidx[kBoxIters];
-                    uint32_t vdst[kBoxIters];
-                    group_records(kbase, rec, sidx, vdst);
+                    Task t[kBoxIters];
+                    group_tasks(kbase, t);
+                    if (!one_scale) {
 #pragma unroll
-                    for (int u = 0; u < kBoxIters; ++u) {
-                        if (sidx[u] != have_idx)  // (all of a lane's tasks see the same scale in the usual case)
-                            P0[u] = a.lut[(int64_t)sidx[u] * kNbOrientation * kNbPoints + task_p[u]];
+                        for (int u = 0; u < kBoxIters; ++u)
+                            if ((int)(t[u].pk_theta & 63) != have_idx) E0[u] = load_entry((int64_t)(t[u].pk_theta & 63) * kNbOrientation * kNbPoints + task_p[u]);
+                        const int s0 = t[0].pk_theta & 63;
+                        have_idx = (int)(t[1].pk_theta & 63) == s0 && (int)(t[kBoxIters - 1].pk_theta & 63) == s0 ? s0 : -1;
                     }
-                    have_idx = sidx[kBoxIters - 1] == sidx[0] && sidx[1] == sidx[0] ? sidx[0] : -1;
 #pragma unroll
                     for (int u = 0; u < kBoxIters; ++u)
-                        lds_st<uint8_t>(vdst[u], (uint8_t)mean_intensity_tile(ibase, rec[u].kx, rec[u].ky, P0[u]));
+                        lds_st<uint8_t>(t[u].vdst, (uint8_t)box(t[u], E0[u], (int64_t)(t[u].pk_theta & 63) * kNbOrientation * kNbPoints + task_p[u]));
                     wave_lds_sync();
                     int direction0 = 0, direction1 = 0;
 #pragma unroll
@@ -835,30 +920,32 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                     if (lane < min(kGroup, nb - kbase))
                         *reinterpret_cast<int4 *>(a.out_info + (out_base + kf[kbase + lane].g) * 4) = make_int4(kf[kbase + lane].pk & 63, 0, 0, 0);
             }
-            // ---- pass B: box means of the rotated pattern, bits, store.  The pattern points of the next group are
-            //      fetched (L2) while the current group's boxes are summed.
-            auto load_rotated = [&](int kbase, PatternPoint (&P)[kBoxIters]) {
-                const int last = min(kGroup, nb - kbase) - 1;
-#pragma unroll
-                for (int u = 0; u < kBoxIters; ++u) {
-                    const KpRec r = kf[kbase + min(task_kq[u], last)];
-                    P[u] = a.lut[((int64_t)(r.pk & 63) * kNbOrientation + r.theta) * kNbPoints + task_p[u]];
-                }
+            // ---- pass B: box means of the rotated pattern, bits, store.  The pattern points (or boxes) of the next
+            //      group are fetched (L2) while the current group's boxes are summed.
+            auto rotated_index = [&](const Task t, int u) -> int64_t {
+                return ((int64_t)(t.pk_theta & 63) * kNbOrientation + (t.pk_theta >> 16)) * kNbPoints + task_p[u];
             };
-            PatternPoint Pc[kBoxIters];
-            if (wave * kGroup < nb) load_rotated(wave * kGroup, Pc);
+            LdsU4 ec[kBoxIters];
+            if (wave * kGroup < nb) {
+                Task t0[kBoxIters];
+                group_tasks(wave * kGroup, t0);
+#pragma unroll
+                for (int u = 0; u < kBoxIters; ++u) ec[u] = load_entry(rotated_index(t0[u], u));
+            }
             for (int kbase = wave * kGroup; kbase < nb; kbase += kGroup * kTileWaves) {
                 const int last = min(kGroup, nb - kbase) - 1;
                 const int knext = kbase + kGroup * kTileWaves;
-                PatternPoint Pn[kBoxIters];
-                load_rotated(knext < nb ? knext : kbase, Pn);
-                KpRec rec[kBoxIters];
-                int sidx[kBoxIters];
-                uint32_t vdst[kBoxIters];
-                group_records(kbase, rec, sidx, vdst);
+                LdsU4 en[kBoxIters];
+                {
+                    Task tn[kBoxIters];
+                    group_tasks(knext < nb ? knext : kbase, tn);
 #pragma unroll
-                for (int u = 0; u < kBoxIters; ++u)
-                    lds_st<uint8_t>(vdst[u], (uint8_t)mean_intensity_tile(ibase, rec[u].kx, rec[u].ky, Pc[u]));
+                    for (int u = 0; u < kBoxIters; ++u) en[u] = load_entry(rotated_index(tn[u], u));
+                }
+                Task tc[kBoxIters];
+                group_tasks(kbase, tc);
+#pragma unroll
+                for (int u = 0; u < kBoxIters; ++u) lds_st<uint8_t>(tc[u].vdst, (uint8_t)box(tc[u], ec[u], rotated_index(tc[u], u)));
                 wave_lds_sync();
                 // lane = descriptor bit; lane q stores keypoint q's descriptor
                 {
@@ -894,7 +981,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                 }
                 wave_lds_sync();  // the next group overwrites the box means
 #pragma unroll
-                for (int u = 0; u < kBoxIters; ++u) Pc[u] = Pn[u];
+                for (int u = 0; u < kBoxIters; ++u) ec[u] = en[u];
             }
         }
     }
