@@ -333,7 +333,6 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
             {
                 const int reach = std::max(g.W, g.H) + kTileHalo;
                 t.box_margin = reach < 2048 ? 1.0f / 4096 : reach < 4096 ? 1.0f / 2048 : reach < 8192 ? 1.0f / 1024 : 2.0f;
-                if (const char *ev = std::getenv("MOFREAK_EXP_BOX_MARGIN")) t.box_margin = (float)std::atof(ev);
             }
             t.small = ctx->d_small;
             t.theta = ctx->d_theta;

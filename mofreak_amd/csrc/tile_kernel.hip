@@ -28,7 +28,7 @@
 #include "device_helpers.h"
 
 #ifndef MOFREAK_EXP_SKIP
-#define MOFREAK_EXP_SKIP 0   // kernel experiments only: bit mask of stages to leave out (1 MIP, 2 integral, 4 FREAK)
+#define MOFREAK_EXP_SKIP 0   // stage ablation builds only (profiles/): bit mask of stages to leave out (1 MIP, 2 integral, 4 FREAK)
 #endif
 
 namespace mofreak {
@@ -51,7 +51,6 @@ constexpr int kMaxQcols = kTileRW / 4;                                         /
 constexpr int kVStride = 44;                         // bytes per keypoint in a wave's box-mean buffer (11 dwords: odd)
 constexpr int kMipIters = 5;                         // 64-lane passes over the <= 320 sampled 19x19 positions
 constexpr int kBoxIters = (kGroup * kNbPoints + 63) / 64;                       // 3
-constexpr int kBigPoints = 12;                       // points of the two outer rings: the boxes that may need slices
 constexpr int kP19Wave = 2 * kP19Pad;                // a wave's MIP buffer: (cur19, prev19) of one keypoint
 
 // ---- LDS carve (bytes); every offset is a multiple of 16
@@ -406,27 +405,16 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     const int kp_begin = a.tile_start[key];
     const int n_tile_kp = a.tile_start[key + 1] - kp_begin;
     if (n_tile_kp == 0) return;
-#ifdef MOFREAK_EXP_STAGGER
-    // experiment: the second workgroup of every CU (dispatch order: 8 XCDs x 32 CUs first) starts half a tile later
-    if ((blockIdx.x >> 3) >= 32 && (blockIdx.x >> 3) < 64)
-        for (int i = 0; i < MOFREAK_EXP_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
 
-    uint8_t *scratch = lds + kOffScratch;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int W = a.f.W, H = a.f.H;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     // integral halo of this call: the largest pattern the binning pass met, in steps of 8 pixels
-#ifdef MOFREAK_EXP_HALO
-    const int halo = MOFREAK_EXP_HALO;
-#else
     const int halo = min(kTileHalo, max(kMinHalo, (*a.max_ps + 7) & ~7));
-#endif
     const int halo_x = (halo + 15) & ~15;  // 16-byte pieces of a region row start on 16 bytes of the frame row
     const int RW = kTileW + 2 * halo_x, RH = kTileH + 2 * halo;
     const int ox = tx * kTileW - halo_x, oy = ty * kTileH - halo;                  // integral region origin
-    const int cx0 = tx * kTileW - kTileMipHalo, cy0 = ty * kTileH - kTileMipHalo;  // gray tile origin
     const uint8_t *cur = a.f.cur + (int64_t)pair * a.f.pair_stride;
     const uint8_t *prev = a.f.prev + (int64_t)pair * a.f.pair_stride;
     const bool fast8 = (((uintptr_t)cur | (uintptr_t)prev | (uintptr_t)a.f.row_stride) & 7) == 0;

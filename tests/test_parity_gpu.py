@@ -381,6 +381,36 @@ def test_crowded_tiles_and_tile_borders(gpu_ctx, oracle):
     assert valid.all() and np.array_equal(valid, want_v) and np.array_equal(desc, want_d)
 
 
+@pytest.mark.parametrize("sizes", [(7.0,), (7.0, 7.7), (9.0, 9.9), (12.0,), (7.0, 9.0, 12.0, 14.5)])
+def test_integer_keypoints_every_halo_and_scale(gpu_ctx, oracle, sizes):
+    """Keypoints at integer coordinates take the tile kernel's fixed-offset boxes (BoxInt) -- one scale per tile or
+    several, every halo size the pattern sizes select (24, 32, 40, 48), tiles cut by the image border, groups of
+    four that do not fill up, a frame width that is not a multiple of 8 (byte-wise staging) -- and must give the
+    float expressions' bits, including the pattern points that sit too close to a rounding boundary."""
+    for W, H in ((417, 301), (640, 200)):
+        fr = synth.synth_stack(7, W, H)
+        rng = np.random.default_rng(len(sizes) * 1000 + W)
+        kps = synth.random_keypoints(rng, 3001, W, H, sizes=sizes, integer_xy=True)
+        cur, prev = fr[5:], fr[:2]
+        desc, valid = gpu_ctx.extract_pairs_host(cur, prev, kps)
+        want_d, want_v = oracle_pairs(oracle, cur, prev, kps)
+        assert np.array_equal(valid, want_v) and np.array_equal(desc, want_d)
+        assert valid.sum() > 2000
+    gpu_ctx.check_status()
+
+
+def test_integer_keypoints_on_a_frame_wider_than_2048(gpu_ctx, oracle):
+    """The rounding margin of the fixed-offset boxes depends on the coordinate range (one more bit of float error
+    per binade): a 4200-px-wide frame uses the wider margin, a dense integer grid over all of it stays bit-exact."""
+    W, H = 4200, 150
+    fr = synth.synth_stack(6, W, H)
+    xs, ys = np.meshgrid(np.arange(40, W - 40, 7), np.arange(40, H - 40, 9))
+    kps = np.stack([xs.ravel(), ys.ravel(), np.full(xs.size, 12.0)], 1).astype(np.float32)
+    desc, valid = gpu_ctx.extract_pairs_host(fr[5:6], fr[0:1], kps)
+    want_d, want_v = oracle_pairs(oracle, fr[5:6], fr[0:1], kps)
+    assert valid.all() and np.array_equal(valid, want_v) and np.array_equal(desc, want_d)
+
+
 # ------------------------------------------------------------------ frame preparation (SURVEY 8(f) row 2)
 @pytest.mark.parametrize("W,H", [(320, 240), (1920, 1080), (37, 5), (4099, 3), (641, 2)])
 def test_bgr_to_gray_matches_oracle(gpu_ctx, oracle, W, H):
