@@ -61,7 +61,8 @@ constexpr int kOffTheta = kOffScratch + kScratchBytes;
 constexpr int kOffKf = kOffTheta + kThetaBounds * (int)sizeof(ThetaBound);   // the batch's keypoint records
 constexpr int kOffMot = kOffKf + kBatch * 16;                                // motion bytes kept for the fused store
 constexpr int kOffKint = kOffMot + kBatch * 8;                               // keypoints at integer coordinates: their corner in the integral
-constexpr int kOffStamps = kOffKint + kBatch * 4;                            // diagnostic build only: 32 x u64
+constexpr int kOffDirs = kOffKint + kBatch * 4;                              // orientation sums, until a wave turns its keypoints' into thetas
+constexpr int kOffStamps = kOffDirs + kBatch * 8;                            // diagnostic build only: 32 x u64
 constexpr int kTileLdsBytes = kOffStamps + 256;
 static_assert(kP19Wave % 16 == 0 && kOffScratch % 16 == 0 && kOffTheta % 16 == 0, "LDS carve alignment");
 static_assert(2 * kTileLdsBytes <= 160 * 1024, "two workgroups per CU");
@@ -429,6 +430,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     uint2 *s_mot = reinterpret_cast<uint2 *>(lds + kOffMot);
     KpRec *kf = reinterpret_cast<KpRec *>(lds + kOffKf);
     uint32_t *kint = reinterpret_cast<uint32_t *>(lds + kOffKint);
+    int2 *s_dirs = reinterpret_cast<int2 *>(lds + kOffDirs);
     const bool one_batch = n_tile_kp <= kBatch;
     // The binning pass recorded the smallest and largest ROI side of the tile: equal in the usual case.
     const int tile_L = (int)a.tile_lmin[key];
@@ -894,14 +896,20 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                     }
                     direction0 = row16_sum(direction0);
                     direction1 = row16_sum(direction1);
-                    const int theta = theta_index(s_theta, direction0, direction1);
-                    if (osub == 0 && oq <= last) {
-                        kf[kbase + oq].theta = (int16_t)theta;
+                    if (osub == 0 && oq <= last) s_dirs[kbase + oq] = make_int2(direction0, direction1);
+                    wave_lds_sync();  // the next group overwrites the box means
+                }
+                // thetas of all the wave's keypoints in one go: lane = keypoint (group lane / 4, slot lane % 4)
+                {
+                    const int kp = (wave + kTileWaves * (lane >> 2)) * kGroup + (lane & 3);
+                    if (kp < nb) {
+                        const int2 d = s_dirs[kp];
+                        const int theta = theta_index(s_theta, d.x, d.y);
+                        kf[kp].theta = (int16_t)theta;
                         if (a.out_info)
-                            *reinterpret_cast<int4 *>(a.out_info + (out_base + kf[kbase + oq].g) * 4) =
-                                make_int4(kf[kbase + oq].pk & 63, theta, direction0, direction1);
+                            *reinterpret_cast<int4 *>(a.out_info + (out_base + kf[kp].g) * 4) = make_int4(kf[kp].pk & 63, theta, d.x, d.y);
                     }
-                    wave_lds_sync();  // the next group overwrites the box means; pass B reads the thetas
+                    wave_lds_sync();  // pass B reads the thetas
                 }
             } else if (a.out_info) {
                 for (int kbase = wave * kGroup; kbase < nb; kbase += kGroup * kTileWaves)
