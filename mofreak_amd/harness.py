@@ -8,6 +8,8 @@
   compute_mofreak_files computeMoFREAKFiles() (src/MoFREAK/main.cpp:854-924): walk a directory of videos, one
                         .mofreak file each -- sharded one-video-per-GPU across ranks (no data-path collective)
   gather_rows           the only exchange step: variable-length gather of 32-byte rows to rank 0
+  run_dataset           the whole of BASELINE config 4: shard -> per-rank extraction -> gather -> rank 0 writes every
+                        video's .mofreak text in (video, frame, keypoint) order, byte-identical to a 1-rank run
 
 PyTorch is plumbing here (device tensors, torch.distributed); the compute is libmofreak_hip.so.
 """
@@ -208,17 +210,97 @@ def gather_rows(rows, n_rows: int, dst: int = 0, group=None):
 
 
 def compute_mofreak_files(video_paths: Sequence[str], out_dir: str, mofreak: MoFREAKUtilities, rank: int = 0,
-                          world_size: int = 1, costs: Sequence[float] | None = None) -> list[str]:
-    """computeMoFREAKFiles (main.cpp:854-924) for this rank's shard: <video> -> <out_dir>/<video>.mofreak."""
+                          world_size: int = 1, costs: Sequence[float] | None = None, skip_existing: bool = False) -> list[str]:
+    """computeMoFREAKFiles (main.cpp:854-924) for this rank's shard: <video> -> <out_dir>/<video>.mofreak.
+
+    skip_existing: a video whose .mofreak file is already there is not computed again -- the per-video file is the
+    pipeline's checkpoint; the reference itself always recomputes."""
     costs = costs if costs is not None else [os.path.getsize(p) for p in video_paths]
     mine = shard_videos(costs, world_size)[rank]
     os.makedirs(out_dir, exist_ok=True)
     written = []
     for i in mine:
         out = os.path.join(out_dir, os.path.basename(video_paths[i]) + ".mofreak")
+        if skip_existing and os.path.exists(out):
+            continue
         mofreak.computeMoFREAKFromFile(video_paths[i], out, True)
         written.append(out)
     return written
+
+
+def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mofreak: MoFREAKUtilities, rank: int = 0,
+                world_size: int = 1, costs: Sequence[float] | None = None, group=None, on_device: bool = False) -> dict:
+    """BASELINE config 4 end to end (main.cpp:854-924 over a whole dataset).
+
+    videos[i]: a (T, H, W) uint8 gray stack or the path of a .npy file holding one; names[i]: its output stem.
+    1. shard: longest-processing-time-first over `costs` (default: frame counts), one video per GPU at a time;
+    2. every rank extracts its videos' rows (no collective on the data path);
+    3. the one exchange: counts per video (all_gather) + gather_rows of the 32-byte rows to rank 0;
+    4. rank 0 writes <out_dir>/<name>.mofreak for every video, rows in (video, frame, keypoint) order -- the bytes a
+       1-rank run writes (out_dir None: nothing is written, the gathered rows are still returned on rank 0).
+    Returns timings and, on rank 0, `rows_per_video`.
+    """
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    def stack_of(v):
+        return np.load(v, mmap_mode="r") if isinstance(v, str) else v
+
+    n = len(videos)
+    if costs is None:
+        costs = [stack_of(v).shape[0] for v in videos]
+    mine = shard_videos(costs, world_size)[rank]
+    t0 = time.perf_counter()
+    parts, counts = [], np.zeros(n, np.int64)
+    for i in mine:
+        rows = mofreak.extract_rows(np.ascontiguousarray(stack_of(videos[i])))
+        counts[i] = len(rows)
+        parts.append(rows)
+    local = np.concatenate(parts) if parts else np.zeros(0, api.ROW_DTYPE)
+    t_compute = time.perf_counter() - t0
+
+    t1 = time.perf_counter()
+    if world_size > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu")
+        c = torch.from_numpy(counts).to(dev)
+        dist.all_reduce(c, group=group)  # every video belongs to exactly one rank: the sum is the per-video count
+        counts = c.cpu().numpy()
+        buf = torch.from_numpy(local.view(np.uint8).reshape(-1).copy()).to(dev)
+        gathered, per_rank = gather_rows(buf, len(local), dst=0, group=group)
+        if on_device:
+            torch.cuda.synchronize()
+        all_rows = gathered.cpu().numpy().view(api.ROW_DTYPE).reshape(-1) if rank == 0 else None
+    else:
+        all_rows, per_rank = local, [len(local)]
+    t_gather = time.perf_counter() - t1
+
+    out = {"compute_s": t_compute, "gather_s": t_gather, "videos_here": len(mine), "rows_here": int(len(local))}
+    if rank == 0:
+        # rank r's rows sit at offset sum(per_rank[:r]), its videos in ascending index order
+        shards = shard_videos(costs, world_size)
+        start = {}
+        off = 0
+        for r in range(world_size):
+            for i in shards[r]:
+                start[i] = off
+                off += int(counts[i])
+        assert off == len(all_rows) == sum(per_rank)
+        t2 = time.perf_counter()
+        rows_per_video = {}
+        if out_dir is not None:
+            os.makedirs(out_dir, exist_ok=True)
+        for i in range(n):
+            seg = all_rows[start[i]: start[i] + int(counts[i])]
+            rows_per_video[i] = seg
+            if out_dir is not None:
+                with open(os.path.join(out_dir, names[i] + ".mofreak"), "wb") as f:
+                    f.write(api.format_rows(seg))
+        out["write_s"] = time.perf_counter() - t2
+        out["rows_per_video"] = rows_per_video
+        out["total_rows"] = int(len(all_rows))
+    return out
 
 
 # ------------------------------------------------------------------ .mofreak file utilities (SURVEY.md 8(f) row 3)

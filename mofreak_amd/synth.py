@@ -88,6 +88,19 @@ CONFIGS = {
 }
 
 
+def clip_lengths(n_clips: int, seed: int = 0x4D6F4652, median: float = 80.0, sigma: float = 0.6, lo: int = 20, hi: int = 650) -> np.ndarray:
+    """Frame counts of an HMDB51-shaped batch (BASELINE config 4): seeded log-normal, median 80 frames,
+    clamped to [20, 650] -- uneven on purpose, to exercise the load balance of the one-video-per-GPU sharding."""
+    rng = np.random.default_rng(seed)
+    return np.clip(np.exp(rng.normal(np.log(median), sigma, n_clips)), lo, hi).astype(np.int64)
+
+
+def clip_pool(n_distinct: int, max_len: int, W: int, H: int) -> list[np.ndarray]:
+    """A few distinct synthetic clips of max_len frames; clip i of a batch is pool[i % n][:length_i] (generating
+    thousands of distinct clips on the host would dominate a benchmark run; the device work does not depend on it)."""
+    return [np.stack([synth_frame(10_000 * k + t, W, H) for t in range(max_len)]) for k in range(n_distinct)]
+
+
 def config_grid(name: str) -> np.ndarray:
     c = CONFIGS[name]
     return dense_grid(c["W"], c["H"], c["step"], c["size"], c["lo"])

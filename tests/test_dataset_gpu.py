@@ -1,0 +1,93 @@
+"""BASELINE config 4 on its own workload (HMDB51-shaped: 320x240 clips of uneven length, dense 16-px grid of 150
+size-12 keypoints per pair): harness.run_dataset = shard -> extract -> gather -> rank 0 writes ordered .mofreak text
+(main.cpp:854-924).  Needs a GPU; the two-rank case shares device 0 over gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import mofreak_amd as M
+from mofreak_amd import harness, synth
+
+pytestmark = pytest.mark.gpu
+
+N_CLIPS = 44
+
+
+def _clips():
+    c = synth.CONFIGS["C4"]
+    lengths = np.minimum(synth.clip_lengths(N_CLIPS, seed=404), 140)  # seeded log-normal lengths, capped to keep the oracle quick
+    pool = synth.clip_pool(4, int(lengths.max()), c["W"], c["H"])
+    return [pool[i % 4][: lengths[i]] for i in range(N_CLIPS)], [f"clip{i:03d}.avi" for i in range(N_CLIPS)], lengths
+
+
+def _mofreak(device=0):
+    c = synth.CONFIGS["C4"]
+    return harness.MoFREAKUtilities(harness.HMDB51, device=device, keypoint_provider=harness.dense_grid_provider(c["step"], c["size"], c["lo"]))
+
+
+def test_c4_dataset_rows_match_the_oracle_and_files_are_ordered(oracle, tmp_path):
+    clips, names, lengths = _clips()
+    assert len(synth.config_grid("C4")) == 150 and lengths.min() >= 20 and len(set(lengths.tolist())) > 20
+    mo = _mofreak()
+    try:
+        res = harness.run_dataset(clips, names, str(tmp_path), mo)
+    finally:
+        mo.close()
+    f = oracle.Freak()
+    kps = synth.config_grid("C4")
+    total = 0
+    for i, clip in enumerate(clips):
+        n_pairs = len(clip) - 5
+        offs = np.arange(n_pairs + 1, dtype=np.int64) * len(kps)
+        want = f.extract_stream(clip, np.tile(kps, (n_pairs, 1)), offs)
+        got = res["rows_per_video"][i]
+        assert got.tobytes() == want.tobytes(), f"clip {i}"
+        assert np.all(np.diff(got["frame_number"]) >= 0) and got["frame_number"].min() == 4
+        with open(tmp_path / (names[i] + ".mofreak"), "rb") as fh:
+            assert fh.read() == oracle.format_rows(want)
+        total += len(want)
+    assert res["total_rows"] == total == int(((lengths - 5) * 150).sum())
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        clips, names, _ = _clips()
+        mo = _mofreak(0)  # both ranks on device 0: the one-GPU box's rehearsal of one-video-per-GPU
+        try:
+            res = harness.run_dataset(clips, names, out_dir, mo, rank=rank, world_size=world)
+        finally:
+            mo.close()
+        assert 0 < res["videos_here"] < len(clips)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c4_two_ranks_write_the_bytes_of_one_rank(tmp_path):
+    clips, names, _ = _clips()
+    one, two = tmp_path / "one", tmp_path / "two"
+    mo = _mofreak()
+    try:
+        harness.run_dataset(clips, names, str(one), mo)
+    finally:
+        mo.close()
+    mp.spawn(_worker, args=(2, _free_port(), str(two)), nprocs=2, join=True)
+    for name in names:
+        a, b = (one / (name + ".mofreak")).read_bytes(), (two / (name + ".mofreak")).read_bytes()
+        assert a == b and len(a) > 0, name
+    assert sorted(os.listdir(one)) == sorted(os.listdir(two))

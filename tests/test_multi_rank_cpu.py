@@ -77,3 +77,75 @@ def test_shard_videos_lpt():
         assert shards == harness.shard_videos(lengths, world)  # deterministic
     assert harness.shard_videos([5, 1], 4) == [[0], [1], [], []]
     assert harness.shard_videos([], 2) == [[], []]
+
+
+# ------------------------------------------------------------------ run_dataset: shard -> extract -> gather -> ordered files
+class _FakeMoFREAK:
+    """Stands in for MoFREAKUtilities where there is no GPU: rows are a deterministic function of the clip's bytes, so
+    that the sharding, the exchange and rank 0's ordering can be checked against a one-rank run on the CPU."""
+
+    def extract_rows(self, frames):
+        T = frames.shape[0]
+        n = max(T - 5, 0) * 3
+        rows = np.zeros(n, api.ROW_DTYPE)
+        rows["frame_number"] = 4 + np.arange(n) // 3
+        rows["x"] = frames[:n % 7 + 1].sum() % 1000
+        rows["y"] = np.arange(n) % 3
+        rows["scale"] = 12.0
+        rows["appearance"][:, 0] = frames[0, 0, 0]
+        rows["motion"][:, 0] = T % 256
+        return rows
+
+
+def _clips(n=23):
+    rng = np.random.default_rng(5)
+    lengths = np.clip(np.exp(rng.normal(np.log(20), 0.7, n)), 3, 90).astype(int)  # some shorter than the gap: no rows
+    return [rng.integers(0, 256, (t, 4, 6), dtype=np.uint8) for t in lengths], [f"v{i:02d}.avi" for i in range(n)]
+
+
+def _dataset_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        clips, names = _clips()
+        res = harness.run_dataset(clips, names, outdir, _FakeMoFREAK(), rank=rank, world_size=world)
+        assert (rank == 0) == ("rows_per_video" in res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_run_dataset_files_equal_the_one_rank_run(tmp_path, world):
+    clips, names = _clips()
+    one, many = tmp_path / "one", tmp_path / "many"
+    res = harness.run_dataset(clips, names, str(one), _FakeMoFREAK())
+    assert res["total_rows"] == sum(max(len(c) - 5, 0) * 3 for c in clips)
+    mp.spawn(_dataset_worker, args=(world, _free_port(), str(many)), nprocs=world, join=True)
+    assert sorted(os.listdir(one)) == sorted(os.listdir(many)) == sorted(n + ".mofreak" for n in names)
+    for n in names:
+        assert (one / (n + ".mofreak")).read_bytes() == (many / (n + ".mofreak")).read_bytes()
+    assert any((one / (n + ".mofreak")).stat().st_size == 0 for n in names)  # clips shorter than the frame gap
+
+
+def test_compute_mofreak_files_skips_existing(tmp_path):
+    class Rec(_FakeMoFREAK):
+        def __init__(self):
+            self.calls = []
+
+        def computeMoFREAKFromFile(self, video, out, clear):
+            self.calls.append(video)
+            open(out, "wb").write(b"x")
+
+    vids = []
+    for i in range(4):
+        p = tmp_path / f"a{i}.npy"
+        np.save(p, np.zeros((3 + i, 2, 2), np.uint8))
+        vids.append(str(p))
+    out = tmp_path / "out"
+    m = Rec()
+    assert len(harness.compute_mofreak_files(vids, str(out), m)) == 4
+    os.remove(out / "a2.npy.mofreak")
+    m2 = Rec()
+    assert harness.compute_mofreak_files(vids, str(out), m2, skip_existing=True) == [str(out / "a2.npy.mofreak")]
+    assert m2.calls == [vids[2]]
