@@ -175,6 +175,23 @@ int mofreak_extract_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W
                            mofreak_row *rows_out, int64_t rows_capacity, int64_t *n_rows_out,
                            unsigned flags);
 
+/*
+ * The same frame loop for a long host-resident stream (BASELINE config 5: hour-long 720x576 streams), pipelined:
+ * the stack is walked in chunks of chunk_frames frames (consecutive chunks overlap by `gap` frames, the depth of the
+ * reference's frame queue, MoFREAKUtilities.cpp:391-399, 485-487), and chunk k+1's host-to-device copy runs on its
+ * own HIP stream under chunk k's kernels while chunk k-1's rows travel back on a third.  frames, kps (one shared
+ * list of n_kp keypoints for every processed frame) and rows_out are HOST pointers; frames / rows_out in memory
+ * from mofreak_host_alloc (page-locked) are copied by DMA straight from / to the caller's buffer, any other host
+ * memory goes through the library's own page-locked staging buffers (one more host copy).  Rows are those of
+ * mofreak_extract_stream on the whole stack, byte for byte.  chunk_frames <= gap selects a default (256).
+ */
+int mofreak_extract_stream_pipelined(mofreak_ctx *ctx, const uint8_t *frames, int T, int W, int H, int chunk_frames,
+                                     const mofreak_keypoint *kps, int64_t n_kp, mofreak_row *rows_out,
+                                     int64_t rows_capacity, int64_t *n_rows_out);
+/* Page-locked host memory for frames decoded by the caller and for rows (hipHostMalloc / hipHostFree). */
+int mofreak_host_alloc(mofreak_ctx *ctx, size_t bytes, void **out);
+int mofreak_host_free(mofreak_ctx *ctx, void *ptr);
+
 /* ------------------------------------------------------------------ frame preparation */
 /* cv::cvtColor(frame, frame, CV_BGR2GRAY) on 8UC3 frames (MoFREAKUtilities.cpp:395, :410): interleaved B,G,R bytes,
  * rows row_stride bytes apart, frames frame_stride bytes apart -> n_frames contiguous W x H gray frames, ready for
@@ -223,6 +240,7 @@ int mofreak_compute_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W
  * described against the frame gap pushes ago, labelled gap - 1, gap, ... (:401, :488).  For throughput use
  * mofreak_compute_stream / mofreak_extract_stream on whole stacks; this interface is for callers that decode as
  * they go.  frame / kps / rows_out are host or device pointers according to flags; *n_rows_out is a host integer.
+ * A stream holds a pointer to its context: close it (mofreak_stream_close) before mofreak_destroy.
  */
 typedef struct mofreak_stream mofreak_stream;
 int mofreak_stream_open(mofreak_ctx *ctx, int W, int H, int use_detector, int threshold, int octaves,

@@ -33,6 +33,7 @@ EXPORTS = [
     "mofreak_set_stream", "mofreak_synchronize", "mofreak_reserve", "mofreak_check_status",
     "mofreak_set_profiling", "mofreak_get_profile", "mofreak_set_path", "mofreak_get_tile_stamps", "mofreak_bgr_to_gray", "mofreak_bow_assign", "mofreak_bow_histogram",
     "mofreak_extract_pairs", "mofreak_compact_rows", "mofreak_extract_stream", "mofreak_format_rows",
+    "mofreak_extract_stream_pipelined", "mofreak_host_alloc", "mofreak_host_free",
     "mofreak_parse_rows", "mofreak_diff_integral", "mofreak_mip19", "mofreak_roi19", "mofreak_freak_info",
     "mofreak_theta_index", "mofreak_pattern_sizes", "mofreak_scale_index", "mofreak_table_pattern",
     "mofreak_table_orientation", "mofreak_table_bit_pairs", "mofreak_table_resize",
@@ -110,6 +111,9 @@ def load() -> C.CDLL:
     L.mofreak_brisk_pyramid.argtypes = [vp, vp, i32, i32, i64, i32, vp, vp, vp, vp, C.POINTER(C.c_int), C.c_uint]
     L.mofreak_compact_rows.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, i64, C.POINTER(i64), C.c_uint]
     L.mofreak_extract_stream.argtypes = [vp, vp, i32, i32, i32, vp, vp, i64, vp, i64, C.POINTER(i64), C.c_uint]
+    L.mofreak_extract_stream_pipelined.argtypes = [vp, vp, i32, i32, i32, i32, vp, i64, vp, i64, C.POINTER(i64)]
+    L.mofreak_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.mofreak_host_free.argtypes = [vp, vp]
     L.mofreak_format_rows.argtypes = [vp, i64, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.mofreak_parse_rows.argtypes = [C.c_char_p, C.c_size_t, vp, i64, C.POINTER(i64)]
     L.mofreak_diff_integral.argtypes = [vp, vp, vp, i32, i32, i64, i64, i32, vp, C.c_uint]
@@ -184,10 +188,18 @@ class Context:
             raise MoFREAKError(rc, (self._lib.mofreak_last_error(None) or b"").decode())
         self._h = h
         self.device = device
+        self._pinned: dict[int, int] = {}   # numpy data address -> page-locked allocation (host_alloc)
+        self._streams: list = []            # open FrameStreams: they hold a pointer into this context
+        self._det_cand_cap = 131072         # the library's default candidate capacity per pair (capi.cpp)
 
     # ---- lifetime
     def close(self):
         if getattr(self, "_h", None):
+            for st in list(self._streams):  # a stream must be closed before its context (mofreak_hip.h)
+                st.close()
+            for p in list(self._pinned.values()):
+                self._lib.mofreak_host_free(self._h, C.c_void_p(p))
+            self._pinned.clear()
             self._lib.mofreak_destroy(self._h)
             self._h = None
 
@@ -303,15 +315,26 @@ class Context:
         frames = np.ascontiguousarray(frames, np.uint8)
         T, H, W = frames.shape
         capacity = max(1, T) * 8192 if capacity is None else capacity
-        while True:
+        for _attempt in range(4):
             rows = np.zeros(capacity, ROW_DTYPE)
-            try:
-                n, _ = self.compute_stream(frames, T, W, H, rows, threshold, octaves)
-                return rows[:n].copy()
-            except MoFREAKError as e:
-                if e.code != ERR_CAPACITY or capacity > (1 << 28):
-                    raise
-                capacity *= 4
+            n_rows, n_kp = C.c_int64(0), C.c_int64(0)
+            rc = self._lib.mofreak_compute_stream(self._h, _ptr(frames), T, W, H, threshold, octaves, _ptr(rows), capacity,
+                                                  C.byref(n_rows), C.byref(n_kp), MEM_HOST)
+            if rc == OK:
+                return rows[:n_rows.value].copy()
+            if rc != ERR_CAPACITY:
+                self._check(rc)
+            # Two different things run out with this code: the rows buffer -- then the call says how many rows there
+            # are, and exactly that many are asked for again -- or the detector's candidate list of some frame pair,
+            # which a larger rows buffer cannot help: raise that capacity instead.
+            if n_rows.value > capacity:
+                capacity = int(n_rows.value)
+            else:
+                self._det_cand_cap *= 4
+                if self._det_cand_cap > (1 << 24):
+                    break
+                self.set_detect_capacity(self._det_cand_cap)
+        self._check(rc)
 
     def open_stream(self, W: int, H: int, use_detector: bool = True, threshold: int = 30, octaves: int = 3) -> "FrameStream":
         """Frame-at-a-time interface over a device ring of gap + 1 frames (mofreak_stream_*)."""
@@ -319,6 +342,7 @@ class Context:
 
     def set_detect_capacity(self, candidates_per_pair: int):
         self._check(self._lib.mofreak_detect_set_capacity(self._h, candidates_per_pair))
+        self._det_cand_cap = int(candidates_per_pair)
 
     def brisk_pyramid_host(self, img: np.ndarray, octaves=3, scores=True):
         """-> list of (layer image, score map or None, scale, offset) per pyramid layer."""
@@ -440,6 +464,38 @@ class Context:
         n = self.extract_stream(frames, T, W, H, kps, rows, kp_offsets=kp_offsets, n_kp=kps.shape[0])
         return rows[:n].copy()
 
+    def host_alloc(self, shape, dtype=np.uint8) -> np.ndarray:
+        """A page-locked host array (mofreak_host_alloc): frames decoded into it, or rows received into it, move by DMA
+        straight from / to it in extract_stream_pipelined.  Free it with host_free (or let the context's close do it)."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        self._check(self._lib.mofreak_host_alloc(self._h, n, C.byref(p)))
+        buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr: np.ndarray) -> None:
+        p = self._pinned.pop(arr.ctypes.data, None)
+        if p is not None and self._h:
+            self._check(self._lib.mofreak_host_free(self._h, C.c_void_p(p)))
+
+    def extract_stream_pipelined_host(self, frames: np.ndarray, kps: np.ndarray, chunk_frames: int = 256,
+                                      rows_out: np.ndarray | None = None) -> np.ndarray:
+        """A long host-resident gray stack (T,H,W) u8 through the chunked, copy/compute-overlapped frame loop; the
+        rows of extract_stream_host(frames, kps).  frames / rows_out from host_alloc() are copied by DMA in place."""
+        assert frames.dtype == np.uint8 and frames.flags.c_contiguous and frames.ndim == 3
+        T, H, W = frames.shape
+        kps = np.ascontiguousarray(kps, np.float32).reshape(-1, 3)
+        cap = max(T - self.params.gap_for_frame_difference, 0) * kps.shape[0]
+        rows = rows_out if rows_out is not None else np.zeros(max(cap, 1), ROW_DTYPE)
+        assert rows.dtype == ROW_DTYPE and rows.flags.c_contiguous
+        n = C.c_int64(0)
+        self._check(self._lib.mofreak_extract_stream_pipelined(self._h, _ptr(frames), T, W, H, chunk_frames, _ptr(kps),
+                                                               kps.shape[0], _ptr(rows), rows.shape[0], C.byref(n)))
+        return rows[:n.value] if rows_out is not None else rows[:n.value].copy()
+
     # ---- component entry points
     def diff_integral_host(self, cur: np.ndarray, prev: np.ndarray) -> np.ndarray:
         cur = np.ascontiguousarray(cur, np.uint8)
@@ -551,11 +607,16 @@ class FrameStream:
         self._h = C.c_void_p()
         ctx._check(ctx._lib.mofreak_stream_open(ctx._h, W, H, int(use_detector), threshold, octaves, C.byref(self._h)))
         self.W, self.H = W, H
+        ctx._streams.append(self)
 
     def push(self, frame: np.ndarray, kps: np.ndarray | None = None, capacity: int = 1 << 16) -> np.ndarray:
         """frame: (H, W) gray or (H, W, 3) BGR uint8 host array; kps: (n, 3) float32 when the stream has no detector."""
         frame = np.ascontiguousarray(frame, np.uint8)
         channels = 1 if frame.ndim == 2 else int(frame.shape[2])
+        if frame.ndim not in (2, 3) or frame.shape[:2] != (self.H, self.W) or channels not in (1, 3):
+            raise ValueError(f"frame of shape {frame.shape}: expected ({self.H}, {self.W}) gray or ({self.H}, {self.W}, 3) BGR")
+        if not self._h:
+            raise MoFREAKError(ERR_BAD_ARG, "stream is closed")
         k = None if kps is None else np.ascontiguousarray(kps, np.float32).reshape(-1, 3)
         rows = np.zeros(capacity, ROW_DTYPE)
         n = C.c_int64(0)
@@ -572,6 +633,8 @@ class FrameStream:
         if self._h:
             self._ctx._lib.mofreak_stream_close(self._h)
             self._h = C.c_void_p()
+            if self in self._ctx._streams:
+                self._ctx._streams.remove(self)
 
     def __enter__(self):
         return self

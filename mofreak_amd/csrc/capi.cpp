@@ -50,6 +50,16 @@ struct mofreak_ctx {
     uint16_t *d_mip_pos = nullptr;
     TileLane *d_tile_lanes = nullptr;
     BoxInt *d_lut_int = nullptr;
+    // mofreak_extract_stream_pipelined: two slots of staging buffers, copy streams and events (created on first use)
+    struct Pipe {
+        hipStream_t s_in = nullptr, s_out = nullptr;
+        hipEvent_t ev_in[2]{}, ev_comp[2]{}, ev_out[2]{};
+        void *h_frames[2]{}, *h_rows[2]{};
+        int64_t *h_count[2]{};
+        size_t h_frames_bytes = 0, h_rows_bytes = 0;
+        DeviceBuffer d_frames[2], d_rows[2];
+        bool ready = false;
+    } pipe;
     int path_mode = MOFREAK_PATH_AUTO;
     int chunk_pairs_hint = 0;
     // optional per-launch timing (mofreak_set_profiling): events around the integral group and the describe launch
@@ -609,6 +619,22 @@ void mofreak_destroy(mofreak_ctx *ctx)
     if (ctx->d_mip_pos) (void)hipFree(ctx->d_mip_pos);
     if (ctx->d_tile_lanes) (void)hipFree(ctx->d_tile_lanes);
     if (ctx->d_lut_int) (void)hipFree(ctx->d_lut_int);
+    if (ctx->pipe.ready) {
+        (void)hipStreamSynchronize(ctx->pipe.s_in);
+        (void)hipStreamSynchronize(ctx->pipe.s_out);
+        for (int b = 0; b < 2; ++b) {
+            (void)hipEventDestroy(ctx->pipe.ev_in[b]);
+            (void)hipEventDestroy(ctx->pipe.ev_comp[b]);
+            (void)hipEventDestroy(ctx->pipe.ev_out[b]);
+            (void)hipHostFree(ctx->pipe.h_count[b]);
+            if (ctx->pipe.h_frames[b]) (void)hipHostFree(ctx->pipe.h_frames[b]);
+            if (ctx->pipe.h_rows[b]) (void)hipHostFree(ctx->pipe.h_rows[b]);
+            release(ctx->pipe.d_frames[b]);
+            release(ctx->pipe.d_rows[b]);
+        }
+        (void)hipStreamDestroy(ctx->pipe.s_in);
+        (void)hipStreamDestroy(ctx->pipe.s_out);
+    }
     release(ctx->kp_key);
     release(ctx->sorted_idx);
     release(ctx->slow_list);
@@ -882,6 +908,170 @@ int mofreak_extract_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W
     if (rc) return rc;
     if (host && total)
         HIP_TRY(ctx, hipMemcpy(rows_out, d_rows, (size_t)total * sizeof(mofreak_row), hipMemcpyDeviceToHost));
+    return MOFREAK_OK;
+}
+
+static bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();  // an ordinary malloc'd pointer: not an error for us
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+int mofreak_host_alloc(mofreak_ctx *ctx, size_t bytes, void **out)
+{
+    if (!ctx || !out) return MOFREAK_ERR_BAD_ARG;
+    NEED_DEVICE(ctx);
+    *out = nullptr;
+    HIP_TRY(ctx, hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault));
+    return MOFREAK_OK;
+}
+
+int mofreak_host_free(mofreak_ctx *ctx, void *ptr)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    NEED_DEVICE(ctx);
+    if (ptr) HIP_TRY(ctx, hipHostFree(ptr));
+    return MOFREAK_OK;
+}
+
+int mofreak_extract_stream_pipelined(mofreak_ctx *ctx, const uint8_t *frames, int T, int W, int H, int chunk_frames,
+                                     const mofreak_keypoint *kps, int64_t n_kp, mofreak_row *rows_out,
+                                     int64_t rows_capacity, int64_t *n_rows_out)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    if (n_rows_out) *n_rows_out = 0;
+    if (T < 0 || n_kp < 0 || rows_capacity < 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "negative count");
+    const int gap = ctx->params.gap_for_frame_difference;
+    if (T - gap <= 0 || n_kp == 0) return MOFREAK_OK;
+    const int64_t fsz = (int64_t)W * H;
+    int rc = validate_frames(ctx, frames, frames, W, H, W, fsz, T - gap);
+    if (rc) return rc;
+    if (!kps || !rows_out) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null pointer");
+    NEED_DEVICE(ctx);
+    if (chunk_frames <= gap) chunk_frames = 256;
+    chunk_frames = std::min(chunk_frames, T);
+    const int chunk_pairs = chunk_frames - gap;
+    const int n_chunks = (T - gap + chunk_pairs - 1) / chunk_pairs;
+    const Geometry g{W, H, W, fsz};
+    const bool frames_pinned = is_pinned_host(frames), rows_pinned = is_pinned_host(rows_out);
+    mofreak_ctx::Pipe &P = ctx->pipe;
+    if (!P.ready) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&P.s_in, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&P.s_out, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(ctx, hipEventCreateWithFlags(&P.ev_in[b], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&P.ev_comp[b], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&P.ev_out[b], hipEventDisableTiming));
+            HIP_TRY(ctx, hipHostMalloc((void **)&P.h_count[b], sizeof(int64_t), hipHostMallocDefault));
+        }
+        P.ready = true;
+    }
+    const size_t chunk_bytes = (size_t)chunk_frames * fsz, rows_bytes = (size_t)chunk_pairs * n_kp * sizeof(mofreak_row);
+    for (int b = 0; b < 2; ++b) {
+        if ((rc = ensure(ctx, P.d_frames[b], chunk_bytes))) return rc;
+        if ((rc = ensure(ctx, P.d_rows[b], rows_bytes))) return rc;
+    }
+    if (!frames_pinned && P.h_frames_bytes < chunk_bytes) {
+        for (int b = 0; b < 2; ++b) {
+            if (P.h_frames[b]) HIP_TRY(ctx, hipHostFree(P.h_frames[b]));
+            HIP_TRY(ctx, hipHostMalloc(&P.h_frames[b], chunk_bytes, hipHostMallocDefault));
+        }
+        P.h_frames_bytes = chunk_bytes;
+    }
+    if (!rows_pinned && P.h_rows_bytes < rows_bytes) {
+        for (int b = 0; b < 2; ++b) {
+            if (P.h_rows[b]) HIP_TRY(ctx, hipHostFree(P.h_rows[b]));
+            HIP_TRY(ctx, hipHostMalloc(&P.h_rows[b], rows_bytes, hipHostMallocDefault));
+        }
+        P.h_rows_bytes = rows_bytes;
+    }
+    if ((rc = upload(ctx, ctx->stage[2], kps, (size_t)n_kp * sizeof(mofreak_keypoint)))) return rc;
+    const mofreak_keypoint *d_kps = static_cast<const mofreak_keypoint *>(ctx->stage[2].ptr);
+    const int64_t items_max = (int64_t)chunk_pairs * n_kp;
+    if ((rc = ensure(ctx, ctx->scratch_desc, (size_t)items_max * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->scratch_valid, (size_t)items_max))) return rc;
+    if ((rc = ensure(ctx, ctx->compact_offsets, ((size_t)(items_max + kCompactItemsPerBlock - 1) / kCompactItemsPerBlock + 1) * sizeof(int64_t)))) return rc;
+    uint8_t *desc = static_cast<uint8_t *>(ctx->scratch_desc.ptr);
+    uint8_t *valid = static_cast<uint8_t *>(ctx->scratch_valid.ptr);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the uploads above; from here on nothing below allocates
+
+    int64_t total_rows = 0;          // rows handed back so far
+    int64_t chunk_total[2] = {0, 0};  // row count of the chunk in each slot, once known
+    int64_t chunk_dst[2] = {0, 0};    // where its rows go in rows_out
+    int state[2] = {0, 0};            // 0 free, 1 computing (count unknown), 2 rows on their way back
+    // hand chunk `b`'s rows over: count known -> D2H issued; D2H done -> (copied to the caller)
+    auto advance = [&](int b, bool finish) -> int {
+        if (state[b] == 1) {
+            HIP_TRY(ctx, hipEventSynchronize(P.ev_comp[b]));
+            chunk_total[b] = *P.h_count[b];
+            chunk_dst[b] = total_rows;
+            total_rows += chunk_total[b];
+            if (total_rows > rows_capacity) return fail(ctx, MOFREAK_ERR_CAPACITY, "rows_out too small: need at least " + std::to_string(total_rows));
+            if (chunk_total[b]) {
+                void *dst = rows_pinned ? static_cast<void *>(rows_out + chunk_dst[b]) : P.h_rows[b];
+                HIP_TRY(ctx, hipMemcpyAsync(dst, P.d_rows[b].ptr, (size_t)chunk_total[b] * sizeof(mofreak_row), hipMemcpyDeviceToHost, P.s_out));
+            }
+            HIP_TRY(ctx, hipEventRecord(P.ev_out[b], P.s_out));
+            state[b] = 2;
+        }
+        if (state[b] == 2 && finish) {
+            HIP_TRY(ctx, hipEventSynchronize(P.ev_out[b]));
+            if (!rows_pinned && chunk_total[b]) std::memcpy(rows_out + chunk_dst[b], P.h_rows[b], (size_t)chunk_total[b] * sizeof(mofreak_row));
+            state[b] = 0;
+        }
+        return MOFREAK_OK;
+    };
+
+    for (int k = 0; k < n_chunks; ++k) {
+        const int b = k & 1;
+        const int f0 = k * chunk_pairs, nf = std::min(chunk_frames, T - f0), np = nf - gap;
+        if ((rc = advance(b, true))) return rc;  // slot b: chunk k-2 is through (its buffers are free again)
+        const uint8_t *src = frames + (int64_t)f0 * fsz;
+        if (!frames_pinned) {
+            HIP_TRY(ctx, hipEventSynchronize(P.ev_in[b]));  // chunk k-2's copy out of this staging buffer
+            std::memcpy(P.h_frames[b], src, (size_t)nf * fsz);
+            src = static_cast<const uint8_t *>(P.h_frames[b]);
+        }
+        HIP_TRY(ctx, hipStreamWaitEvent(P.s_in, P.ev_comp[b], 0));  // the device frames of chunk k-2 are no longer read
+        HIP_TRY(ctx, hipMemcpyAsync(P.d_frames[b].ptr, src, (size_t)nf * fsz, hipMemcpyHostToDevice, P.s_in));
+        HIP_TRY(ctx, hipEventRecord(P.ev_in[b], P.s_in));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, P.ev_in[b], 0));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, P.ev_out[b], 0));  // the device rows of chunk k-2 have left
+        const uint8_t *d_fr = static_cast<const uint8_t *>(P.d_frames[b].ptr);
+        rc = extract_device(ctx, d_fr + (int64_t)gap * fsz, d_fr, g, np, d_kps, nullptr, nullptr, n_kp, desc, valid, nullptr, nullptr);
+        if (rc) return rc;
+        {
+            const int64_t n_items = (int64_t)np * n_kp;
+            const int n_blocks = (int)((n_items + kCompactItemsPerBlock - 1) / kCompactItemsPerBlock);
+            CompactArgs c;
+            c.kps = d_kps;
+            c.kp_offsets = nullptr;
+            c.n_kp = n_kp;
+            c.n_items = n_items;
+            c.n_pairs = np;
+            c.first_frame_number = gap - 1 + f0;  // frame labels run on across chunks (:401, :488)
+            c.desc = desc;
+            c.valid = valid;
+            c.rows = static_cast<mofreak_row *>(P.d_rows[b].ptr);
+            c.capacity = n_items;
+            c.block_offsets = static_cast<int64_t *>(ctx->compact_offsets.ptr);
+            c.n_blocks = n_blocks;
+            const int e = launch_compact(c, ctx->stream);
+            if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("compact launch: ") + hipGetErrorString((hipError_t)e));
+            HIP_TRY(ctx, hipMemcpyAsync(P.h_count[b], c.block_offsets + n_blocks, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIP_TRY(ctx, hipEventRecord(P.ev_comp[b], ctx->stream));
+        state[b] = 1;
+        if ((rc = advance(b ^ 1, false))) return rc;  // chunk k-1: its count is in (or we wait for it) -> rows start travelling
+    }
+    for (int k = n_chunks; k < n_chunks + 2; ++k)
+        if ((rc = advance(k & 1, true))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_rows_out) *n_rows_out = total_rows;
     return MOFREAK_OK;
 }
 

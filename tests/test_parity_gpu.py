@@ -411,6 +411,41 @@ def test_integer_keypoints_on_a_frame_wider_than_2048(gpu_ctx, oracle):
     assert valid.all() and np.array_equal(valid, want_v) and np.array_equal(desc, want_d)
 
 
+# ------------------------------------------------------------------ pipelined long streams (BASELINE config 5)
+@pytest.mark.parametrize("pinned", [False, True])
+def test_pipelined_stream_rows_equal_the_whole_stack_call(gpu_ctx, oracle, pinned):
+    """TRECVID-shaped (720x576) stream walked in chunks with copy/compute overlap: rows byte-identical to
+    mofreak_extract_stream on the whole stack (and so to the oracle), for chunk sizes that do and do not divide the
+    stream, page-locked or ordinary host memory, and a stream shorter than one chunk."""
+    c = synth.CONFIGS["C5"]
+    W, H, T = c["W"], c["H"], 47
+    kps = synth.config_grid("C5")
+    assert len(kps) == 5103
+    src = synth.synth_stack(T, W, H)
+    frames = gpu_ctx.host_alloc((T, H, W)) if pinned else src
+    if pinned:
+        frames[:] = src
+    want = gpu_ctx.extract_stream_host(src, kps)
+    assert len(want) == (T - 5) * len(kps)
+    for chunk in (12, 16, 47, 256):
+        rows_buf = gpu_ctx.host_alloc(((T - 5) * len(kps),), M.api.ROW_DTYPE) if pinned else None
+        got = gpu_ctx.extract_stream_pipelined_host(frames, kps, chunk_frames=chunk, rows_out=rows_buf)
+        assert got.tobytes() == want.tobytes(), f"chunk {chunk}"
+        if pinned:
+            gpu_ctx.host_free(rows_buf)
+    if pinned:
+        gpu_ctx.host_free(frames)
+    f = oracle.Freak()
+    n_pairs = 6
+    offs = np.arange(n_pairs + 1, dtype=np.int64) * len(kps)
+    assert want[: n_pairs * len(kps)].tobytes() == f.extract_stream(src[: n_pairs + 5], np.tile(kps, (n_pairs, 1)), offs).tobytes()
+    # too small a rows buffer is reported, not overrun
+    small = np.zeros(1000, M.api.ROW_DTYPE)
+    with pytest.raises(M.api.MoFREAKError) as e:
+        gpu_ctx.extract_stream_pipelined_host(src, kps, chunk_frames=16, rows_out=small)
+    assert e.value.code == M.api.ERR_CAPACITY
+
+
 # ------------------------------------------------------------------ frame preparation (SURVEY 8(f) row 2)
 @pytest.mark.parametrize("W,H", [(320, 240), (1920, 1080), (37, 5), (4099, 3), (641, 2)])
 def test_bgr_to_gray_matches_oracle(gpu_ctx, oracle, W, H):
