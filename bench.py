@@ -8,11 +8,19 @@ GPU, every rank its own stack (weak scaling), no data-path collective; the final
 timed separately and reported as gather_ms.
 
 Prints ONE JSON line (rank 0).  See DESIGN.md section "Measurement" for how roofline.achieved is defined.
+
+Other workloads of BASELINE.json (each prints its own single JSON line; the metric's line is the default one):
+  --config C2                 640x480, 16-px grid, 1000 resident pairs (the bit-exactness configuration), same line shape
+  --config C4 [--gpus N]      HMDB51-shaped batch: clips of uneven length, one video per GPU at a time, rows gathered to
+                              rank 0 (harness.run_dataset): clips/s, descriptors/s, gather_ms
+  --config C5 --stream        TRECVID-shaped 720x576 stream from page-locked host memory through the pipelined frame
+                              loop: sustained descriptors/s INCLUDING the host-to-device copies and the rows' way back
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -24,6 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+PCIE_GBS = 63.0        # host link, same guide
+METRIC = "MoFREAK descriptors/sec on dense 1080p frames; achieved HBM GB/s vs peak"
 
 
 def make_stack(T, W, H, t0, workers):
@@ -38,8 +48,10 @@ def make_stack(T, W, H, t0, workers):
     return out
 
 
-def cpu_baseline(frames, kps, n_pairs, cores):
-    """The CPU oracle (a port, not the reference binary) on a bounded sample of the same workload."""
+def cpu_baselines(frames, kps, n_pairs, cores, shape):
+    """The CPU oracle (a port, not the reference binary) on bounded samples of the same workload: all host cores, one
+    thread, and one thread with the FREAK pattern tables rebuilt for every frame pair as the reference does by
+    constructing cv::FREAK inside its frame loop (MoFREAKUtilities.cpp:427)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     f = oracle_lib.Freak()
@@ -49,13 +61,44 @@ def cpu_baseline(frames, kps, n_pairs, cores):
         d, v = f.extract_pair(frames[p + 5], frames[p], kps)  # ctypes releases the GIL
         return int(v.sum())
 
+    def one_ref(p):
+        g = oracle_lib.Freak()  # pattern LUT, orientation weights, pair tables: rebuilt per pair
+        d, v = g.extract_pair(frames[p + 5], frames[p], kps)
+        return int(v.sum())
+
+    what = f"the workload's {shape} pairs x {len(kps)} keypoints, oracle/mofreak_oracle.c (gcc -O2, strict FP)"
     t = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
         n = sum(ex.map(one, range(n_pairs)))
     dt = time.perf_counter() - t
-    return {"value": n / dt, "unit": "descriptors/s", "cores": cores, "kind": "port",
-            "sample": f"{n_pairs} of the workload's 1920x1080 pairs x {len(kps)} keypoints, oracle/mofreak_oracle.c "
-                      f"(gcc -O2, strict FP), {cores} threads over pairs, {dt:.1f} s wall"}
+    out = {"cpu_baseline": {"value": n / dt, "unit": "descriptors/s", "cores": cores, "kind": "port",
+                            "sample": f"{n_pairs} of {what}, {cores} threads over pairs, {dt:.1f} s wall"}}
+    # one thread: a sample sized from the rate just measured, about 4 s each
+    per_pair_1t = dt * cores / max(n_pairs, 1)
+    n1 = int(min(n_pairs, max(2, round(4.0 / max(per_pair_1t, 1e-3)))))
+    for key, fn, note in (("cpu_baseline_1t", one, "tables built once"),
+                          ("cpu_baseline_ref_faithful", one_ref, "cv::FREAK tables rebuilt for every pair (MoFREAKUtilities.cpp:427)")):
+        t = time.perf_counter()
+        n = sum(fn(p) for p in range(n1))
+        dt1 = time.perf_counter() - t
+        out[key] = {"value": n / dt1, "unit": "descriptors/s", "cores": 1, "kind": "port",
+                    "sample": f"{n1} of {what}, 1 thread, {note}, {dt1:.1f} s wall"}
+    return out
+
+
+def copy_ceiling_gbs(torch, mib=2048, reps=5):
+    """Device-to-device copy rate (read + write bytes per second) measured in this run: what a streaming kernel reaches."""
+    a = torch.empty(mib << 20, dtype=torch.uint8, device="cuda")
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * a.numel() * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def detector_figures(ctx, torch, synth, W, H, pairs=32, steps=3, with_cpu=True):
@@ -81,9 +124,20 @@ def detector_figures(ctx, torch, synth, W, H, pairs=32, steps=3, with_cpu=True):
         ctx.extract_pairs(cur, prev, W, H, pairs, kps, desc, valid, kp_offsets=offs, n_kp=n)
     ctx.synchronize()
     t2 = time.perf_counter()
+    # algorithmic bytes per pair (SURVEY.md 8(d) reading for this row): the two frames in + 12 bytes per keypoint out for
+    # the detector; the two frames + 28 bytes per keypoint for the descriptors behind it
+    kpp = n / pairs
+    det_bytes, desc_bytes = 2 * W * H + 12 * kpp, 2 * W * H + 28 * kpp
+    det_s, both_s = (t1 - t0) / (pairs * steps), (t2 - t1) / (pairs * steps)
     out = {"workload": f"{W}x{H} moving-object frame pairs, BriskFeatureDetector(30, 3 octaves) on |cur - prev|, {pairs} pairs/call",
-           "keypoints_per_pair": n / pairs, "pairs_per_s": pairs * steps / (t1 - t0),
-           "detect_and_describe_pairs_per_s": pairs * steps / (t2 - t1)}
+           "keypoints_per_pair": kpp, "pairs_per_s": 1.0 / det_s, "detect_and_describe_pairs_per_s": 1.0 / both_s,
+           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                        "detect_algorithmic_bytes_per_pair": det_bytes, "detect_achieved": det_bytes / det_s / 1e9,
+                        "detect_frac": det_bytes / det_s / 1e9 / HBM_PEAK_GBS,
+                        "detect_and_describe_algorithmic_bytes_per_pair": det_bytes + desc_bytes,
+                        "detect_and_describe_achieved": (det_bytes + desc_bytes) / both_s / 1e9,
+                        "detect_and_describe_frac": (det_bytes + desc_bytes) / both_s / 1e9 / HBM_PEAK_GBS,
+                        "note": "host-timed calls (launch gaps included), wall clock around synchronising calls"}}
     if with_cpu:  # part of the cpu_baseline leg: the oracle as a reported baseline, never as the product
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
@@ -95,27 +149,9 @@ def detector_figures(ctx, torch, synth, W, H, pairs=32, steps=3, with_cpu=True):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=256, help="resident frame pairs per GPU")
-    ap.add_argument("--config", default="C3", help="synthetic config (C3 = the metric's: 1080p, 8-px grid)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=192, help="pairs of the workload the CPU oracle is timed on (about 25 core-seconds)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL); 'gloo' + "
-                    "--share-device rehearses the N > 1 control flow on a one-GPU box")
-    ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
-    ap.add_argument("--no-detector", action="store_true", help="skip the (untimed-region) keypoint detector figures")
-    args = ap.parse_args()
-
+def dist_setup(args):
     import torch
     import torch.distributed as dist
-
-    import mofreak_amd as M
-    from mofreak_amd import harness, synth
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,11 +165,35 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+    return torch, dist, rank, local_rank, world, on_device
+
+
+def fence(torch, dist, world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(torch, dist, world, on_device, seconds):
+    if world > 1:
+        t = torch.tensor([seconds], dtype=torch.float64, device="cuda" if on_device else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    return seconds
+
+
+# ------------------------------------------------------------------------------------------------ C3 (the metric), C2
+def bench_resident(args):
+    torch, dist, rank, local_rank, world, on_device = dist_setup(args)
+    import mofreak_amd as M
+    from mofreak_amd import harness, synth
 
     cfg = synth.CONFIGS[args.config]
     W, H = cfg["W"], cfg["H"]
     kps = synth.config_grid(args.config)
-    n_kp, n_pairs, gap = len(kps), args.pairs, synth.GAP_FOR_FRAME_DIFFERENCE
+    n_pairs = args.pairs if args.pairs else (1000 if args.config == "C2" else 256)
+    n_kp, gap = len(kps), synth.GAP_FOR_FRAME_DIFFERENCE
     T = n_pairs + gap
     ncpu = len(os.sched_getaffinity(0))
     workers = max(1, min(16, ncpu // max(1, world)))
@@ -146,6 +206,7 @@ def main():
     desc = torch.empty((n_desc, 16), dtype=torch.uint8, device="cuda")
     valid = torch.empty(n_desc, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
+    copy_gbs = copy_ceiling_gbs(torch) if rank == 0 else None
     stream = torch.cuda.Stream()  # a real (non-null) stream shared by torch and the library
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
@@ -154,29 +215,28 @@ def main():
     def step():
         ctx.extract_pairs(d_frames[gap:], d_frames[:n_pairs], W, H, n_pairs, d_kps, desc, valid)
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
-    fence()
+    fence(torch, dist, world)
+    steps = args.steps
+    if steps is None:  # no --steps: enough of them for a timed region of about 3 s (an external sampler sees the run)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        fence(torch, dist, world)
+        per = max_over_ranks(torch, dist, world, on_device, (time.perf_counter() - t0) / 3)
+        steps = int(min(5000, max(10, math.ceil(3.0 / per))))
     ctx.set_profiling(True)  # HIP events around every kernel group, on the stream the kernels run on
     ctx.get_profile(reset=True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
-    fence()
+    fence(torch, dist, world)
     elapsed = time.perf_counter() - t0
     prof = ctx.get_profile(reset=True)
     ctx.set_profiling(False)
     ctx.check_status()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_device else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(torch, dist, world, on_device, elapsed)
     n_valid = int(valid.sum().item())
     if os.environ.get("MOFREAK_BENCH_ABLATION") != "1":  # ablation builds of the kernel skip stages on purpose
         assert n_valid == n_desc, f"{n_desc - n_valid} keypoints were erased: the grid is supposed to be border-safe"
@@ -186,16 +246,16 @@ def main():
     n_rows = ctx.compact_rows(d_kps, n_pairs, gap - 1, desc, valid, rows)
     gather_ms = None
     if world > 1:
-        fence()
+        fence(torch, dist, world)
         tg = time.perf_counter()
         allrows, counts = harness.gather_rows(rows if on_device else rows.cpu(), n_rows, dst=0)
-        fence()
+        fence(torch, dist, world)
         gather_ms = (time.perf_counter() - tg) * 1e3
         if rank == 0:
             assert sum(counts) == world * n_rows and allrows.numel() == sum(counts) * 32
 
     if rank == 0:
-        total_desc = world * n_desc * args.steps
+        total_desc = world * n_desc * steps
         value = total_desc / elapsed
         b_alg_pair = 2 * W * H + 28 * n_kp  # frames read once + keypoints in + descriptors out
         launches = max(prof["calls"], 1)  # one tile_kernel launch per extract call (n_pairs <= 32768)
@@ -207,28 +267,39 @@ def main():
         traffic = None
         valu = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.config == "C3":
             tj = json.load(open(tpath))
             traffic = tj.get("tile_kernel_hbm_bytes_per_launch")
             if tj.get("valu_wave_instr_per_descriptor"):
-                # what actually bounds the kernel: vector instruction issue.  Instructions per descriptor from the PMC pass
-                # (profiles/), issue rate of a wave64 VALU instruction measured on this part; duration measured live.
-                n_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
-                clk = 2.4e9
+                # What bounds the kernel is vector instruction issue and LDS cycles, not bytes: instructions per descriptor
+                # from the PMC passes (profiles/), the issue cost of the instruction classes from the micro-benchmark
+                # recorded there, the shader clock from the device, the launch duration measured live.
+                props = torch.cuda.get_device_properties(local_rank)
+                n_cus = props.multi_processor_count
+                clk = float(getattr(props, "clock_rate", 2400000)) * 1e3  # kHz -> Hz
                 issued = tj["valu_wave_instr_per_descriptor"] * n_desc / (tile_ms_avg * 1e-3)
                 peak_issue = n_cus * 4 * clk / tj.get("valu_cycles_per_wave_instr", 2.0)
+                pd = tj.get("per_descriptor", {})
+                cu_cycles = n_cus * clk * tile_ms_avg * 1e-3 / n_desc  # CU cycles per descriptor in this run
                 valu = {"achieved_wave_instr_per_s": issued, "peak_wave_instr_per_s": peak_issue, "frac": issued / peak_issue,
-                        "wave_instr_per_descriptor": tj["valu_wave_instr_per_descriptor"], "clock_hz_assumed": clk}
+                        "wave_instr_per_descriptor": tj["valu_wave_instr_per_descriptor"], "clock_hz": clk,
+                        "cu_cycles_per_descriptor": cu_cycles,
+                        # SQ_ACTIVE_INST_VALU counts quad-cycles over the four SIMDs of a CU: cycles a SIMD's vector pipe is held
+                        "valu_busy_frac": pd.get("SQ_ACTIVE_INST_VALU", 0.0) / cu_cycles if cu_cycles else None,
+                        "lds_busy_frac": pd.get("SQ_LDS_IDX_ACTIVE", 0.0) / cu_cycles if cu_cycles else None,
+                        "lds_bank_conflict_share_of_lds": (pd.get("SQ_LDS_BANK_CONFLICT", 0.0) / pd["SQ_LDS_IDX_ACTIVE"]) if pd.get("SQ_LDS_IDX_ACTIVE") else None}
         out = {
-            "metric": "MoFREAK descriptors/sec on dense 1080p frames; achieved HBM GB/s vs peak",
-            "value": value, "unit": "descriptors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": METRIC,
+            "value": value, "unit": "descriptors/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.config}: {n_pairs} resident {W}x{H} frame pairs per GPU, dense {cfg['step']}-px grid, "
                                    f"{n_kp} keypoints/pair of size {cfg['size']}, 16-byte descriptors",
                        "descriptors_per_step_per_gpu": n_desc, "bit_mode": "SSE", "parallelism": f"one stack per GPU x{world}"},
+            "timed_region_s": elapsed,
             "roofline": {"bound": "hbm", "kernel": "tile_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "copy_ceiling_GBs": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs if copy_gbs else None,
                          "algorithmic_bytes_per_pair": b_alg_pair, "pairs_per_launch": pairs_per_launch,
                          "avg_launch_ms": tile_ms_avg, "launches_timed": prof["calls"],
                          "binning_avg_ms": prof["bin_ms"] / launches, "gather_path_avg_ms": prof["gather_ms"] / launches,
@@ -238,8 +309,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             cp = min(args.cpu_pairs, n_pairs)
-            out["cpu_baseline"] = cpu_baseline(frames, kps, cp, cores=min(ncpu, 16))
-        if world == 1 and not args.no_detector:
+            out.update(cpu_baselines(frames, kps, cp, cores=min(ncpu, 16), shape=f"{W}x{H}"))
+        if world == 1 and not args.no_detector and args.config == "C3":
             # Outside the metric and its timed region: the row in front of the path, for the record.
             try:
                 out["detector"] = detector_figures(ctx, torch, synth, W, H, with_cpu=not args.no_cpu_baseline)
@@ -251,6 +322,146 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ C4: a dataset of clips
+def bench_dataset(args):
+    torch, dist, rank, local_rank, world, on_device = dist_setup(args)
+    from mofreak_amd import harness, synth
+
+    cfg = synth.CONFIGS["C4"]
+    W, H = cfg["W"], cfg["H"]
+    n_clips = args.clips
+    lengths = synth.clip_lengths(n_clips)  # the same seeded lengths on every rank
+    pool = synth.clip_pool(8, int(lengths.max()), W, H)
+    clips = [pool[i % len(pool)][: lengths[i]] for i in range(n_clips)]
+    names = [f"clip{i:05d}.avi" for i in range(n_clips)]
+    mo = harness.MoFREAKUtilities(harness.HMDB51, device=local_rank,
+                                  keypoint_provider=harness.dense_grid_provider(cfg["step"], cfg["size"], cfg["lo"]))
+    harness.run_dataset(clips[: 4 * world], names[: 4 * world], None, mo, rank, world, on_device=on_device)  # warm-up
+    steps = args.steps or 1
+    fence(torch, dist, world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = harness.run_dataset(clips, names, None, mo, rank, world, on_device=on_device)
+    fence(torch, dist, world)
+    elapsed = max_over_ranks(torch, dist, world, on_device, time.perf_counter() - t0)
+    gather_s = max_over_ranks(torch, dist, world, on_device, res["gather_s"])
+    if rank == 0:
+        n_kp = len(synth.config_grid("C4"))
+        n_desc = int(((lengths - 5).clip(min=0) * n_kp).sum())
+        assert res["total_rows"] == n_desc
+        print(json.dumps({
+            "metric": "MoFREAK clips/sec on an HMDB51-shaped batch, one video per GPU, rows gathered to rank 0 (BASELINE config 4)",
+            "value": n_clips * steps / elapsed, "unit": "clips/s", "descriptors_per_s": n_desc * steps / elapsed,
+            "n_gpus": world, "steps": steps, "warmup": 1, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic (8 distinct clips cut to the seeded lengths)",
+            "config": {"workload": f"C4: {n_clips} clips {W}x{H}, seeded log-normal lengths {int(lengths.min())}..{int(lengths.max())} "
+                                   f"frames (median {int(np.median(lengths))}), dense {cfg['step']}-px grid, {n_kp} keypoints/pair",
+                       "descriptors_per_step": n_desc, "parallelism": f"LPT shard of whole clips over {world} rank(s)"},
+            "gather_ms": gather_s * 1e3, "frames_in_MB_per_step": float(lengths.sum() * W * H / 1e6),
+            "note": "host frames in (pageable), rows back: every clip is one synchronous C-ABI call (mofreak_extract_stream)"}), flush=True)
+    mo.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ C5: a long stream
+def bench_stream(args):
+    torch, dist, rank, local_rank, world, on_device = dist_setup(args)
+    import mofreak_amd as M
+    from mofreak_amd import synth
+
+    cfg = synth.CONFIGS["C5"]
+    W, H = cfg["W"], cfg["H"]
+    kps = synth.config_grid("C5")
+    T = args.frames
+    ncpu = len(os.sched_getaffinity(0))
+    distinct = min(T, 256)  # distinct synthetic frames, repeated to the stream's length (host generation is not the subject)
+    base = make_stack(distinct, W, H, t0=5000 * rank, workers=max(1, min(16, ncpu // max(1, world))))
+    ctx = M.Context(local_rank)
+    frames = ctx.host_alloc((T, H, W))  # the decoder's output buffer: page-locked
+    for t0 in range(0, T, distinct):
+        n = min(distinct, T - t0)
+        frames[t0:t0 + n] = base[:n]
+    n_rows_max = (T - 5) * len(kps)
+    rows = ctx.host_alloc((n_rows_max,), M.api.ROW_DTYPE)
+    # resident rate of the same shape for reference (frames already in HBM, no rows back)
+    d_fr = torch.from_numpy(base).cuda()
+    d_kps = torch.from_numpy(kps).cuda()
+    np_res = distinct - 5
+    desc = torch.empty((np_res * len(kps), 16), dtype=torch.uint8, device="cuda")
+    valid = torch.empty(np_res * len(kps), dtype=torch.uint8, device="cuda")
+    for _ in range(2):
+        ctx.extract_pairs(d_fr[5:], d_fr[:np_res], W, H, np_res, d_kps, desc, valid)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ctx.extract_pairs(d_fr[5:], d_fr[:np_res], W, H, np_res, d_kps, desc, valid)
+    ctx.synchronize()
+    resident = 5 * np_res * len(kps) / (time.perf_counter() - t0)
+
+    got = ctx.extract_stream_pipelined_host(frames[: min(T, 600)], kps, chunk_frames=args.chunk, rows_out=rows)  # warm-up
+    assert len(got) == (min(T, 600) - 5) * len(kps)
+    steps = args.steps or 3
+    fence(torch, dist, world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        got = ctx.extract_stream_pipelined_host(frames, kps, chunk_frames=args.chunk, rows_out=rows)
+    fence(torch, dist, world)
+    elapsed = max_over_ranks(torch, dist, world, on_device, time.perf_counter() - t0)
+    assert len(got) == n_rows_max
+    if rank == 0:
+        n_desc = n_rows_max
+        value = world * n_desc * steps / elapsed
+        # the link is full duplex: one new frame in per processed frame on the way down, 32-byte rows on the way up
+        pcie_bound = PCIE_GBS * 1e9 / max(W * H / len(kps), 32.0)
+        print(json.dumps({
+            "metric": "MoFREAK sustained descriptors/sec on a TRECVID-shaped stream, host frames in and rows out included (BASELINE config 5)",
+            "value": value, "unit": "descriptors/s", "n_gpus": world, "steps": steps, "warmup": 1,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": f"synthetic ({distinct} distinct frames repeated)",
+            "config": {"workload": f"C5: one {W}x{H} stream of {T} frames per GPU from page-locked host memory, dense {cfg['step']}-px grid, "
+                                   f"{len(kps)} keypoints/frame, chunks of {args.chunk} frames", "descriptors_per_step_per_gpu": n_desc,
+                       "parallelism": f"one stream per GPU x{world}"},
+            "frames_per_s": world * (T - 5) * steps / elapsed, "resident_descriptors_per_s": resident,
+            "pcie_bound_descriptors_per_s": pcie_bound, "frac_of_min_bound": value / world / min(pcie_bound, resident),
+            "h2d_GBs": (T * W * H * steps / elapsed) / 1e9, "d2h_GBs": (n_desc * 32 * steps / elapsed) / 1e9}), flush=True)
+    ctx.host_free(frames)
+    ctx.host_free(rows)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: as many as make the timed region about 3 s)")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=0, help="resident frame pairs per GPU (default 256; C2: 1000)")
+    ap.add_argument("--config", default="C3", help="C3 = the metric's (1080p, 8-px grid); C2, C4, C5: see the module text")
+    ap.add_argument("--stream", action="store_true", help="with --config C5: the pipelined host-to-device stream (its only mode)")
+    ap.add_argument("--frames", type=int, default=2005, help="C5: frames in the stream")
+    ap.add_argument("--chunk", type=int, default=256, help="C5: frames per pipelined chunk")
+    ap.add_argument("--clips", type=int, default=512, help="C4: clips in the batch (HMDB51 has 6766)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=192, help="pairs of the workload the CPU oracle is timed on (about 25 core-seconds)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL); 'gloo' + "
+                    "--share-device rehearses the N > 1 control flow on a one-GPU box")
+    ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
+    ap.add_argument("--no-detector", action="store_true", help="skip the (untimed-region) keypoint detector figures")
+    args = ap.parse_args()
+    if args.config in ("C2", "C3"):
+        bench_resident(args)
+    elif args.config == "C4":
+        bench_dataset(args)
+    elif args.config == "C5":
+        bench_stream(args)
+    else:
+        raise SystemExit(f"unknown --config {args.config}")
 
 
 if __name__ == "__main__":
