@@ -73,3 +73,15 @@ def test_no_oracle_in_the_product():
                 assert "oracle_lib" not in txt and "mofreak_oracle" not in txt and "libmofreak_oracle" not in txt, f
     out = subprocess.run(["ldd", api.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_host_code_under_address_sanitizer(tmp_path):
+    """SURVEY.md section 5 (sanitizers): the C ABI's host code (tables, .mofreak text, argument checks) and the C++
+    facade's reader / writer built with -fsanitize=address,undefined, kernel launchers stubbed out (no GPU involved;
+    GPU sanitizers are not available on the pool)."""
+    import subprocess
+    host = os.path.join(ROOT, "mofreak_amd", "host")
+    subprocess.check_call(["make", "-C", host, "-s", "asan"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    out = subprocess.run([os.path.join(host, "asan_selftest")], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "asan selftest ok" in out.stdout, out.stdout + out.stderr
