@@ -38,7 +38,7 @@ struct mofreak_ctx {
     // workspace (grown on demand, never shrunk)
     DeviceBuffer integral, band_totals, scratch_desc, scratch_valid, compact_offsets, stage[6], offsets_dev;
     DeviceBuffer kp_key, sorted_idx, slow_list, tile_start, tile_cursor, slow_count, tile_lmin, tile_lmax;  // keypoint binning
-    DeviceBuffer bow_counts;
+    DeviceBuffer bow_counts, bow_expanded;
     // keypoint detector workspace
     DeviceBuffer det_img, det_score, det_touch, det_status, det_rows, det_cand_xy, det_cand_flag, det_cand_emit, det_cand_spec, det_cand_asked, det_cand_win, det_cand_res, det_layer_start,
         det_emit_count, det_tie_waiting, det_wait_list, det_geom, det_emit_offsets, det_running, det_out_kps, det_out_offsets, det_out_resp, det_out_layer, det_planes_out;
@@ -644,6 +644,7 @@ void mofreak_destroy(mofreak_ctx *ctx)
     release(ctx->tile_lmax);
     release(ctx->slow_count);
     release(ctx->bow_counts);
+    release(ctx->bow_expanded);
     for (DeviceBuffer *b : {&ctx->det_img, &ctx->det_score, &ctx->det_touch, &ctx->det_status, &ctx->det_rows, &ctx->det_cand_xy, &ctx->det_cand_flag,
                             &ctx->det_cand_emit, &ctx->det_cand_spec, &ctx->det_cand_asked, &ctx->det_cand_win, &ctx->det_cand_res, &ctx->det_layer_start, &ctx->det_emit_count, &ctx->det_tie_waiting, &ctx->det_wait_list, &ctx->det_geom, &ctx->det_emit_offsets,
                             &ctx->det_running, &ctx->det_out_kps, &ctx->det_out_offsets, &ctx->det_out_resp, &ctx->det_out_layer, &ctx->det_planes_out})
@@ -1112,7 +1113,7 @@ static int bow_common(mofreak_ctx *ctx, const uint8_t *desc16, const uint8_t *va
 {
     if (!ctx) return MOFREAK_ERR_BAD_ARG;
     if (n < 0 || n_codewords <= 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "n >= 0 and n_codewords > 0 required");
-    if (n_codewords > 10240) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "codebook larger than the 160 KiB LDS holds (10240 x 16 B)");
+    if (n_codewords > 10240) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "codebook larger than 10240 codewords (the packed key's index field; the reference's largest is 10100)");
     if (!codebook16 || (n > 0 && !desc16)) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null pointer");
     NEED_DEVICE(ctx);
     const bool host = (flags & MOFREAK_MEM_HOST) != 0;
@@ -1147,7 +1148,8 @@ static int bow_common(mofreak_ctx *ctx, const uint8_t *desc16, const uint8_t *va
         HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, (size_t)n_codewords * 4 + 16, ctx->stream));
     }
     if (n > 0) {
-        const int e = launch_bow_assign(d_desc, d_valid, n, d_cb, n_codewords, d_idx, d_counts, ctx->n_cus, ctx->stream);
+        if ((rc = ensure(ctx, ctx->bow_expanded, bow_expanded_bytes(n_codewords)))) return rc;
+        const int e = launch_bow_assign(d_desc, d_valid, n, d_cb, n_codewords, d_idx, d_counts, ctx->n_cus, ctx->bow_expanded.ptr, ctx->stream);
         if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("bow_assign launch: ") + hipGetErrorString((hipError_t)e));
     }
     if (hist_out) {

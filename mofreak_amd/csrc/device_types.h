@@ -221,8 +221,9 @@ int launch_bin(const BinArgs &a, void *stream);   // zeroes the counters, classi
 int launch_tile(const TileArgs &a, void *stream);
 int launch_bgr2gray(const uint8_t *bgr, int W, int H, int64_t row_stride, int64_t frame_stride, int n_frames, uint8_t *gray,
                     void *stream);
+size_t bow_expanded_bytes(int n_codewords);  // workspace for the codebook expanded to the matrix instruction's operand bytes
 int launch_bow_assign(const uint8_t *desc, const uint8_t *valid, int64_t n, const uint8_t *codebook, int n_codewords,
-                      int32_t *out_index, unsigned int *counts, int n_cus, void *stream);
+                      int32_t *out_index, unsigned int *counts, int n_cus, void *expanded_ws, void *stream);
 int launch_bow_normalize(const unsigned int *counts, int n_codewords, float *hist, int32_t *success, void *stream);
 int launch_unpack_integral(const int32_t *src, int pitch, int W, int H, int n_pairs, int32_t *dst, void *stream);
 int launch_det_pyramid(const DetArgs &a, void *stream);   // difference image + the resampled layers

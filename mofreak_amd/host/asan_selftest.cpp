@@ -21,7 +21,8 @@ int launch_compact(const CompactArgs &, void *) { STUB; }
 int launch_bin(const BinArgs &, void *) { STUB; }
 int launch_tile(const TileArgs &, void *) { STUB; }
 int launch_bgr2gray(const uint8_t *, int, int, int64_t, int64_t, int, uint8_t *, void *) { STUB; }
-int launch_bow_assign(const uint8_t *, const uint8_t *, int64_t, const uint8_t *, int, int32_t *, unsigned int *, int, void *) { STUB; }
+int launch_bow_assign(const uint8_t *, const uint8_t *, int64_t, const uint8_t *, int, int32_t *, unsigned int *, int, void *, void *) { STUB; }
+size_t bow_expanded_bytes(int) { return 0; }
 int launch_bow_normalize(const unsigned int *, int, float *, int32_t *, void *) { STUB; }
 int launch_unpack_integral(const int32_t *, int, int, int, int, int32_t *, void *) { STUB; }
 int launch_det_pyramid(const DetArgs &, void *) { STUB; }

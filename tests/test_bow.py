@@ -90,3 +90,36 @@ def test_bow_on_extracted_descriptors_and_edge_cases(gpu_ctx, oracle):
     with pytest.raises(M.MoFREAKError) as e:
         gpu_ctx.bow_assign_host(h_desc[:4], np.zeros((10241, 16), np.uint8))
     assert e.value.code == -4
+
+
+@pytest.mark.gpu
+def test_bow_histogram_saturates_in_float_like_the_reference(gpu_ctx, oracle):
+    """buildHistogram counts and sums in FLOAT (BagOfWordsRepresentation.cpp:115, :125-136): a bin stops growing at
+    2^24 and the sum rounds per step.  More than 2^24 descriptors on one codeword (an hour-long TRECVID file can get
+    there): the device must give the reference's floats, not the exact integer ratios."""
+    import torch
+    cb = np.zeros((3, 16), np.uint8)
+    cb[1] = 0xFF
+    cb[2, :8] = 0xFF
+    n0, n1, n2 = (1 << 24) + 7, 5, 3
+    d = torch.zeros((n0 + n1 + n2, 16), dtype=torch.uint8, device="cuda")
+    d[n0:n0 + n1] = 0xFF
+    d[n0 + n1:, :8] = 0xFF
+    d_cb = torch.from_numpy(cb).cuda()
+    hist = torch.empty(3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ok = gpu_ctx.bow_histogram(d, d_cb, hist)
+    gpu_ctx.synchronize()
+    # the reference's arithmetic, replayed: bins saturate at 2^24, the sum is accumulated in float in bin order
+    bins = [np.float32(min(n0, 1 << 24)), np.float32(n1), np.float32(n2)]
+    total = np.float32(0)
+    for b in bins:
+        total = np.float32(total + b)
+    want = np.float32([b / total for b in bins])
+    assert ok and hist.cpu().numpy().tobytes() == want.tobytes()
+    assert want[0] != np.float32(n0) / np.float32(n0 + n1 + n2) or True  # (documents the difference; not a requirement)
+    # and the oracle agrees with this reading on a size it can replay quickly
+    small = np.zeros((40, 16), np.uint8)
+    small[30:] = 0xFF
+    h, ok2 = oracle.bow_histogram(small, cb)
+    assert ok2 and h.tolist() == [np.float32(30) / np.float32(40), np.float32(10) / np.float32(40), 0.0]
