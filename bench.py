@@ -314,6 +314,9 @@ def bench_resident(args):
             # Outside the metric and its timed region: the row in front of the path, for the record.
             try:
                 out["detector"] = detector_figures(ctx, torch, synth, W, H, with_cpu=not args.no_cpu_baseline)
+                # the detector's tie rounds are chains of short launches per call: more pairs per call share them
+                big = detector_figures(ctx, torch, synth, W, H, pairs=128, steps=2, with_cpu=False)
+                out["detector"]["at_128_pairs_per_call"] = {k: big[k] for k in ("pairs_per_s", "detect_and_describe_pairs_per_s")}
             except Exception as e:  # never let the side figure take the metric line down
                 out["detector"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

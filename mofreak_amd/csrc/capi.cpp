@@ -133,6 +133,15 @@ int choose_chunk(const mofreak_ctx *ctx, int W, int H, int n_pairs)
     return std::max(1, std::min(chunk, n_pairs));
 }
 
+// Pairs per chunk of the gather path when it runs BEHIND the tile kernel (usually with nothing to do): few big chunks keep
+// the number of (device-gated, empty) launches small.  mofreak_reserve sizes the workspace for the same figure, so that
+// calls after it do not allocate.
+int slow_chunk(int W, int H)
+{
+    const size_t per_pair = (size_t)(H + 1) * integral_pitch(W) * sizeof(int32_t);
+    return (int)std::max<size_t>(1, ((size_t)1 << 30) / per_pair);
+}
+
 struct Geometry {
     int W, H;
     int64_t row_stride, pair_stride;
@@ -202,12 +211,7 @@ int run_gather(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, const 
                const mofreak_keypoint *kps, const int64_t *d_offsets, const int64_t *h_offsets, int64_t n_kp,
                uint8_t *out_desc, uint8_t *out_valid, int32_t *out_info, uint8_t *out_roi19, bool slow_mode)
 {
-    const size_t per_pair = (size_t)(g.H + 1) * integral_pitch(g.W) * sizeof(int32_t);
-    int chunk;
-    if (slow_mode)  // usually nothing to do here: few big chunks keep the number of (gated, empty) launches small
-        chunk = (int)std::max<size_t>(1, ((size_t)1 << 30) / per_pair);
-    else
-        chunk = choose_chunk(ctx, g.W, g.H, n_pairs);
+    int chunk = slow_mode ? slow_chunk(g.W, g.H) : choose_chunk(ctx, g.W, g.H, n_pairs);
     chunk = std::max(1, std::min(chunk, n_pairs));
     const int32_t *gate = slow_mode ? static_cast<const int32_t *>(ctx->slow_count.ptr) : nullptr;
     for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
@@ -534,7 +538,7 @@ int mofreak_create(int device_id, const mofreak_params *params, mofreak_ctx **ou
     CREATE_TRY(hipMemcpy(ctx->d_lut_int, t.lut_int.data(), t.lut_int.size() * sizeof(BoxInt), hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc((void **)&ctx->d_resize, t.resize.size() * sizeof(ResizeTap)));
     CREATE_TRY(hipMalloc((void **)&ctx->d_small, sizeof(SmallTables)));
-    CREATE_TRY(hipMalloc((void **)&ctx->d_status, sizeof(int32_t)));
+    CREATE_TRY(hipMalloc((void **)&ctx->d_status, 2 * sizeof(int32_t)));  // [0] describe kernels (read by mofreak_check_status), [1] detector
     if (const char *ev = std::getenv("MOFREAK_TILE_STAMPS"); ev && ev[0] == '1') {
         CREATE_TRY(hipMalloc((void **)&ctx->d_stamps, kTileStampSlots * sizeof(unsigned long long)));
         CREATE_TRY(hipMemset(ctx->d_stamps, 0, kTileStampSlots * sizeof(unsigned long long)));
@@ -594,7 +598,7 @@ int mofreak_create(int device_id, const mofreak_params *params, mofreak_ctx **ou
     CREATE_TRY(hipMemcpy(ctx->d_lut, t.lut.data(), t.lut.size() * sizeof(PatternPoint), hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(ctx->d_resize, t.resize.data(), t.resize.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(ctx->d_small, &st, sizeof(st), hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemset(ctx->d_status, 0, sizeof(int32_t)));
+    CREATE_TRY(hipMemset(ctx->d_status, 0, 2 * sizeof(int32_t)));
 #undef CREATE_TRY
     *out = ctx;
     return MOFREAK_OK;
@@ -694,7 +698,8 @@ int mofreak_reserve(mofreak_ctx *ctx, int W, int H, int chunk_pairs)
     if (!ctx || W <= 0 || H <= 0) return MOFREAK_ERR_BAD_ARG;
     NEED_DEVICE(ctx);
     ctx->chunk_pairs_hint = chunk_pairs > 0 ? chunk_pairs : 0;
-    const int chunk = choose_chunk(ctx, W, H, 1 << 30);
+    // the larger of the two users: the gather path alone (chunk_pairs at a time) and the gather path behind the tile kernel
+    const int chunk = std::max(choose_chunk(ctx, W, H, 1 << 30), ctx->path_mode == MOFREAK_PATH_GATHER ? 1 : slow_chunk(W, H));
     const int pitch = integral_pitch(W);
     const int n_bands = (H + kBandRows - 1) / kBandRows;
     int rc = ensure(ctx, ctx->integral, (size_t)chunk * (H + 1) * pitch * sizeof(int32_t));
@@ -1477,7 +1482,7 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     a.tie_waiting = static_cast<int32_t *>(ctx->det_tie_waiting.ptr);
     if ((rc = ensure(ctx, ctx->det_wait_list, (size_t)batch * 4096 * sizeof(int32_t)))) return rc;
     a.wait_list = static_cast<int32_t *>(ctx->det_wait_list.ptr);
-    a.status_word = ctx->d_status;
+    a.status_word = ctx->d_status + 1;  // the detector's own word: clearing it leaves the describe kernels' flags alone
     return MOFREAK_OK;
 }
 
@@ -1549,7 +1554,7 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
     const int batch = det_batch(ctx, g, n_pairs);
     DetArgs a{};
     if ((rc = det_workspace(ctx, g, batch, a))) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_status + 1, 0, sizeof(int32_t), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->det_running.ptr, 0, sizeof(int64_t), ctx->stream));
     if (n_pairs == 0) HIP_TRY(ctx, hipMemsetAsync(d_off, 0, sizeof(int64_t), ctx->stream));
     a.threshold = threshold;
@@ -1576,7 +1581,7 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
     int64_t total = 0;
     int32_t st = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->det_running.ptr, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(&st, ctx->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&st, ctx->d_status + 1, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (n_out) *n_out = total;
     if (st & 16) return fail(ctx, MOFREAK_ERR_HIP, "detector: a refinement walk left its staged window (internal error)");
