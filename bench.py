@@ -336,11 +336,16 @@ def bench_dataset(args):
     W, H = cfg["W"], cfg["H"]
     n_clips = args.clips
     lengths = synth.clip_lengths(n_clips)  # the same seeded lengths on every rank
-    pool = synth.clip_pool(8, int(lengths.max()), W, H)
-    clips = [pool[i % len(pool)][: lengths[i]] for i in range(n_clips)]
-    names = [f"clip{i:05d}.avi" for i in range(n_clips)]
     mo = harness.MoFREAKUtilities(harness.HMDB51, device=local_rank,
                                   keypoint_provider=harness.dense_grid_provider(cfg["step"], cfg["size"], cfg["lo"]))
+    pool = synth.clip_pool(8, int(lengths.max()), W, H)
+    if not args.pageable:  # the decoder's output buffers: page-locked, so that a clip's frames go down by DMA at link speed
+        pinned = [mo._ctx.host_alloc(p.shape) for p in pool]
+        for dst, src in zip(pinned, pool):
+            dst[:] = src
+        pool = pinned
+    clips = [pool[i % len(pool)][: lengths[i]] for i in range(n_clips)]
+    names = [f"clip{i:05d}.avi" for i in range(n_clips)]
     harness.run_dataset(clips[: 4 * world], names[: 4 * world], None, mo, rank, world, on_device=on_device)  # warm-up
     steps = args.steps or 1
     fence(torch, dist, world)
@@ -363,7 +368,7 @@ def bench_dataset(args):
                                    f"frames (median {int(np.median(lengths))}), dense {cfg['step']}-px grid, {n_kp} keypoints/pair",
                        "descriptors_per_step": n_desc, "parallelism": f"LPT shard of whole clips over {world} rank(s)"},
             "gather_ms": gather_s * 1e3, "frames_in_MB_per_step": float(lengths.sum() * W * H / 1e6),
-            "note": "host frames in (pageable), rows back: every clip is one synchronous C-ABI call (mofreak_extract_stream)"}), flush=True)
+            "note": f"host frames in ({'pageable' if args.pageable else 'page-locked'} memory), rows back: every clip is one synchronous C-ABI call (mofreak_extract_stream)"}), flush=True)
     mo.close()
     if world > 1:
         dist.barrier()
@@ -450,6 +455,7 @@ def main():
     ap.add_argument("--frames", type=int, default=2005, help="C5: frames in the stream")
     ap.add_argument("--chunk", type=int, default=256, help="C5: frames per pipelined chunk")
     ap.add_argument("--clips", type=int, default=512, help="C4: clips in the batch (HMDB51 has 6766)")
+    ap.add_argument("--pageable", action="store_true", help="C4: clips in ordinary (pageable) host memory instead of page-locked buffers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=192, help="pairs of the workload the CPU oracle is timed on (about 25 core-seconds)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL); 'gloo' + "
