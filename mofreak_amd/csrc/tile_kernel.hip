@@ -850,7 +850,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                 }
             };
             // entry: the task's BoxInt (all_int) or PatternPoint, as loaded; e: its index in the tables
-            auto box = [&](const Task t, const LdsU4 entry, int64_t e) -> int {
+            auto box = [&](const Task t, const LdsU4 entry, uint32_t e) -> int {
                 if (all_int) {
                     const BoxInt B = __builtin_bit_cast(BoxInt, entry);
                     if (B.margin > box_margin) return mean_intensity_int(t.c0, B);
@@ -859,9 +859,9 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                 }
                 return mean_intensity_tile(ibase, __builtin_bit_cast(float, t.c0), __builtin_bit_cast(float, t.c1), __builtin_bit_cast(PatternPoint, entry));
             };
-            auto load_entry = [&](int64_t e) -> LdsU4 {
-                return all_int ? *reinterpret_cast<const LdsU4 *>(a.lut_int + e) : *reinterpret_cast<const LdsU4 *>(a.lut + e);
-            };
+            // both tables have 16-byte entries with the same indexing: one (wave-uniform) base, 32-bit byte offsets
+            const uint8_t *table = all_int ? reinterpret_cast<const uint8_t *>(a.lut_int) : reinterpret_cast<const uint8_t *>(a.lut);
+            auto load_entry = [&](uint32_t e) -> LdsU4 { return *reinterpret_cast<const LdsU4 *>(table + (e << 4)); };
 
             // ---- pass A over the wave's groups: un-rotated box means, orientation sums, theta -> the records
             if (orientation_normalized) {
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                 if (one_scale) {
                     have_idx = kf[0].pk & 63;
 #pragma unroll
-                    for (int u = 0; u < kBoxIters; ++u) E0[u] = load_entry((int64_t)have_idx * kNbOrientation * kNbPoints + task_p[u]);
+                    for (int u = 0; u < kBoxIters; ++u) E0[u] = load_entry((uint32_t)have_idx * (kNbOrientation * kNbPoints) + task_p[u]);
                 }
                 for (int kbase = wave * kGroup; kbase < nb; kbase += kGroup * kTileWaves) {
                     const int last = min(kGroup, nb - kbase) - 1;
@@ -879,13 +879,13 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                     if (!one_scale) {
 #pragma unroll
                         for (int u = 0; u < kBoxIters; ++u)
-                            if ((int)(t[u].pk_theta & 63) != have_idx) E0[u] = load_entry((int64_t)(t[u].pk_theta & 63) * kNbOrientation * kNbPoints + task_p[u]);
+                            if ((int)(t[u].pk_theta & 63) != have_idx) E0[u] = load_entry((t[u].pk_theta & 63) * (kNbOrientation * kNbPoints) + task_p[u]);
                         const int s0 = t[0].pk_theta & 63;
                         have_idx = (int)(t[1].pk_theta & 63) == s0 && (int)(t[kBoxIters - 1].pk_theta & 63) == s0 ? s0 : -1;
                     }
 #pragma unroll
                     for (int u = 0; u < kBoxIters; ++u)
-                        lds_st<uint8_t>(t[u].vdst, (uint8_t)box(t[u], E0[u], (int64_t)(t[u].pk_theta & 63) * kNbOrientation * kNbPoints + task_p[u]));
+                        lds_st<uint8_t>(t[u].vdst, (uint8_t)box(t[u], E0[u], (t[u].pk_theta & 63) * (kNbOrientation * kNbPoints) + task_p[u]));
                     wave_lds_sync();
                     int direction0 = 0, direction1 = 0;
 #pragma unroll
@@ -918,28 +918,24 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             }
             // ---- pass B: box means of the rotated pattern, bits, store.  The pattern points (or boxes) of the next
             //      group are fetched (L2) while the current group's boxes are summed.
-            auto rotated_index = [&](const Task t, int u) -> int64_t {
-                return ((int64_t)(t.pk_theta & 63) * kNbOrientation + (t.pk_theta >> 16)) * kNbPoints + task_p[u];
+            auto rotated_index = [&](const Task t, int u) -> uint32_t {
+                return ((t.pk_theta & 63) * kNbOrientation + (t.pk_theta >> 16)) * kNbPoints + task_p[u];
             };
             LdsU4 ec[kBoxIters];
+            Task tc[kBoxIters];
             if (wave * kGroup < nb) {
-                Task t0[kBoxIters];
-                group_tasks(wave * kGroup, t0);
+                group_tasks(wave * kGroup, tc);
 #pragma unroll
-                for (int u = 0; u < kBoxIters; ++u) ec[u] = load_entry(rotated_index(t0[u], u));
+                for (int u = 0; u < kBoxIters; ++u) ec[u] = load_entry(rotated_index(tc[u], u));
             }
             for (int kbase = wave * kGroup; kbase < nb; kbase += kGroup * kTileWaves) {
                 const int last = min(kGroup, nb - kbase) - 1;
                 const int knext = kbase + kGroup * kTileWaves;
                 LdsU4 en[kBoxIters];
-                {
-                    Task tn[kBoxIters];
-                    group_tasks(knext < nb ? knext : kbase, tn);
+                Task tn[kBoxIters];
+                group_tasks(knext < nb ? knext : kbase, tn);
 #pragma unroll
-                    for (int u = 0; u < kBoxIters; ++u) en[u] = load_entry(rotated_index(tn[u], u));
-                }
-                Task tc[kBoxIters];
-                group_tasks(kbase, tc);
+                for (int u = 0; u < kBoxIters; ++u) en[u] = load_entry(rotated_index(tn[u], u));
 #pragma unroll
                 for (int u = 0; u < kBoxIters; ++u) lds_st<uint8_t>(tc[u].vdst, (uint8_t)box(tc[u], ec[u], rotated_index(tc[u], u)));
                 wave_lds_sync();
@@ -977,7 +973,10 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                 }
                 wave_lds_sync();  // the next group overwrites the box means
 #pragma unroll
-                for (int u = 0; u < kBoxIters; ++u) ec[u] = en[u];
+                for (int u = 0; u < kBoxIters; ++u) {
+                    ec[u] = en[u];
+                    tc[u] = tn[u];
+                }
             }
         }
     }
