@@ -86,6 +86,9 @@ typedef struct mofreak_row {
 
 /* ------------------------------------------------------------------ context */
 int mofreak_abi_version(void);
+/* Bit 0: this is the bounds-checking debug build (every tile-kernel LDS access and descriptor store checked; a violation
+ * comes back from mofreak_check_status as MOFREAK_ERR_HIP).  The product build returns 0. */
+int mofreak_build_flags(void);
 int mofreak_default_params(mofreak_params *p);
 
 /* Replaces MoFREAKUtilities::MoFREAKUtilities (MoFREAKUtilities.cpp:5-8) plus the per-frame

@@ -29,7 +29,7 @@ assert ROW_DTYPE.itemsize == 32
 
 # every symbol include/mofreak_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "mofreak_abi_version", "mofreak_default_params", "mofreak_create", "mofreak_destroy", "mofreak_last_error",
+    "mofreak_abi_version", "mofreak_build_flags", "mofreak_default_params", "mofreak_create", "mofreak_destroy", "mofreak_last_error",
     "mofreak_set_stream", "mofreak_synchronize", "mofreak_reserve", "mofreak_check_status",
     "mofreak_set_profiling", "mofreak_get_profile", "mofreak_set_path", "mofreak_get_tile_stamps", "mofreak_bgr_to_gray", "mofreak_bow_assign", "mofreak_bow_histogram",
     "mofreak_extract_pairs", "mofreak_compact_rows", "mofreak_extract_stream", "mofreak_format_rows",

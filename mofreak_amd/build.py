@@ -8,6 +8,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmofreak_hip.so")
+DEBUG_LIB_PATH = os.path.join(PKG_DIR, "libmofreak_hip_debug.so")  # -DMOFREAK_DEBUG_BOUNDS: checked LDS accesses / stores
 SOURCES = ["kernels.hip", "tile_kernel.hip", "bow_kernel.hip", "detect_kernel.hip", "capi.cpp", "tables.cpp", "format.cpp"]
 HEADERS = ["tables.h", "device_types.h", "device_helpers.h", os.path.join("..", "..", "include", "mofreak_hip.h")]
 # -ffp-contract=off / -fno-fast-math: a handful of float/double expressions restate reference
@@ -30,8 +31,15 @@ def is_stale() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build_native(force: bool = False, verbose: bool = False) -> str:
-    """Compile the shared library if it is missing or older than its sources; returns its path."""
+def build_native(force: bool = False, verbose: bool = False, debug: bool = False) -> str:
+    """Compile the shared library if it is missing or older than its sources; returns its path.
+    debug=True: the bounds-checking build of the same sources (tests only; never what api.load() picks up)."""
+    if debug:
+        cmd = [hipcc(), *FLAGS, "-DMOFREAK_DEBUG_BOUNDS", "-o", DEBUG_LIB_PATH, *[os.path.join(CSRC, s) for s in SOURCES]]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return DEBUG_LIB_PATH
     if not force and not is_stale():
         return LIB_PATH
     cmd = [hipcc(), *FLAGS, "-o", LIB_PATH, *[os.path.join(CSRC, s) for s in SOURCES]]

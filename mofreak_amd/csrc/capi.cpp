@@ -362,6 +362,8 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
             t.tile_start = static_cast<const int32_t *>(ctx->tile_start.ptr) + (d_offsets ? (int64_t)p0 * tiles_x * tiles_y : 0);
             t.sorted_kp = static_cast<const SortedKp *>(ctx->sorted_idx.ptr);
             t.max_ps = static_cast<const int32_t *>(ctx->slow_count.ptr) + 16;
+            t.status = ctx->d_status;
+            t.out_items = d_offsets ? n_kp : (int64_t)np * n_kp;
             t.tile_lmin = static_cast<const uint32_t *>(ctx->tile_lmin.ptr) + (d_offsets ? (int64_t)p0 * tiles_x * tiles_y : 0);
             t.tile_lmax = static_cast<const uint32_t *>(ctx->tile_lmax.ptr) + (d_offsets ? (int64_t)p0 * tiles_x * tiles_y : 0);
             t.out_desc = d_offsets ? out_desc : out_desc + (int64_t)p0 * n_kp * 16;
@@ -450,6 +452,15 @@ int compact_device(mofreak_ctx *ctx, const mofreak_keypoint *kps, const int64_t 
 extern "C" {
 
 int mofreak_abi_version(void) { return MOFREAK_ABI_VERSION; }
+
+int mofreak_build_flags(void)
+{
+#ifdef MOFREAK_DEBUG_BOUNDS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 int mofreak_default_params(mofreak_params *p)
 {
@@ -769,6 +780,7 @@ int mofreak_check_status(mofreak_ctx *ctx)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (s & 1) return fail(ctx, MOFREAK_ERR_ROI, "a keypoint's MIP ROI left the image (the reference throws there); it was marked invalid");
     if (s & 2) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "a keypoint's ROI side exceeds the resize tables; it was marked invalid");
+    if (s & 64) return fail(ctx, MOFREAK_ERR_HIP, "debug build: a tile-kernel access left its bounds (LDS allocation or descriptor output)");
     return MOFREAK_OK;
 }
 

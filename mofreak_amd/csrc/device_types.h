@@ -136,6 +136,8 @@ struct TileArgs {
     const uint32_t *tile_lmin, *tile_lmax;
     const SortedKp *sorted_kp;
     const int32_t *max_ps;      // device word written by the binning pass (see BinArgs)
+    int32_t *status;            // device status word (debug builds: bit 6 = an access left its bounds)
+    int64_t out_items;          // descriptors the output arrays of this launch hold (debug builds check stores against it)
     uint8_t *out_desc;
     uint8_t *out_valid;
     int32_t *out_info;          // optional

@@ -35,6 +35,7 @@ namespace mofreak {
 namespace {
 
 constexpr int kTileThreads = 512;                    // 8 waves; two workgroups per CU = 4 waves per SIMD
+constexpr int kTileLdsLimit = 80 * 1024;             // a workgroup's LDS budget (two per CU); debug builds check accesses against it
 constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kBatch = 96;                           // keypoints described per pass over a tile's list
 constexpr int kGroup = 4;                            // keypoints one wave describes together in stage 3
@@ -65,7 +66,7 @@ constexpr int kOffDirs = kOffKint + kBatch * 4;                              // 
 constexpr int kOffStamps = kOffDirs + kBatch * 8;                            // diagnostic build only: 32 x u64
 constexpr int kTileLdsBytes = kOffStamps + 256;
 static_assert(kP19Wave % 16 == 0 && kOffScratch % 16 == 0 && kOffTheta % 16 == 0, "LDS carve alignment");
-static_assert(2 * kTileLdsBytes <= 160 * 1024, "two workgroups per CU");
+static_assert(2 * kTileLdsBytes <= 160 * 1024 && kTileLdsBytes <= kTileLdsLimit, "two workgroups per CU");
 static_assert(kTileRW % 16 == 0 && kTileRH % kColBlockRows == 0 && kTileRW / 16 <= 16 && kTileThreads == 32 * 16, "region blocking");
 static_assert(kTileH + 2 * kMinHalo >= 32, "a last partial staging step can be shifted up to a full one");
 static_assert(kTileStagePitch % 16 == 0 && 2 * kTileRW <= kTileStagePitch, "a region row's staged bytes fit its integral row");
@@ -87,14 +88,30 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 // LDS accesses by integer byte address (the address of the dynamic LDS block is folded into the scalar bases once):
 // the per-lane address arithmetic stays 32-bit and the instruction's immediate offset takes the constant part.
+//
+// Debug build (-DMOFREAK_DEBUG_BOUNDS, libmofreak_hip_debug.so): every such access is checked against
+// the workgroup's LDS allocation and every descriptor store against the output's extent; an access outside is not made,
+// the fact is recorded and comes back from mofreak_check_status as an error.  The product build has none of it.
+#ifdef MOFREAK_DEBUG_BOUNDS
+__device__ unsigned int g_tile_oob;  // bit 0: LDS access outside the allocation, bit 1: descriptor store outside the output
+#define MOFREAK_LDS_CHECK(addr, T)                                             \
+    if ((uint64_t)(addr) + sizeof(T) > (uint64_t)kTileLdsLimit || ((addr) % alignof(T)) != 0) { \
+        atomicOr(&g_tile_oob, 1u);                                             \
+        (addr) = 0;                                                            \
+    }
+#else
+#define MOFREAK_LDS_CHECK(addr, T)
+#endif
 template <class T>
 __device__ __forceinline__ T lds_ld(uint32_t addr)
 {
+    MOFREAK_LDS_CHECK(addr, T)
     return *(const __attribute__((address_space(3))) T *)(uintptr_t)addr;
 }
 template <class T>
 __device__ __forceinline__ void lds_st(uint32_t addr, T v)
 {
+    MOFREAK_LDS_CHECK(addr, T)
     *(__attribute__((address_space(3))) T *)(uintptr_t)addr = v;
 }
 
@@ -961,7 +978,13 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                         if (lane == qq) app = make_uint2((uint32_t)bits, (uint32_t)(bits >> 32));
                     }
                     if (lane <= last) {  // descriptor and validity flag out, side by side
-                        const int64_t out_idx = out_base + kf[kbase + lane].g;
+                        int64_t out_idx = out_base + kf[kbase + lane].g;
+#ifdef MOFREAK_DEBUG_BOUNDS
+                        if (out_idx < 0 || out_idx >= a.out_items) {
+                            atomicOr(&g_tile_oob, 2u);
+                            out_idx = 0;
+                        }
+#endif
                         if (one_batch) {
                             const uint2 mot = s_mot[kbase + lane];
                             *reinterpret_cast<uint4 *>(a.out_desc + out_idx * 16) = make_uint4(app.x, app.y, mot.x, mot.y);
@@ -981,6 +1004,9 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
         }
     }
     TILE_STAMP(5);
+#ifdef MOFREAK_DEBUG_BOUNDS
+    if (tid == 0 && g_tile_oob) atomicOr(a.status, 64);  // mofreak_check_status reports it
+#endif
     if (STAMPS && tid == 0)
         for (int i = 0; i < kTileStampSlots; ++i)
             if (s_stamps[i]) atomicAdd(&a.stamps[i], s_stamps[i]);

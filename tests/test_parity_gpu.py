@@ -411,6 +411,42 @@ def test_integer_keypoints_on_a_frame_wider_than_2048(gpu_ctx, oracle):
     assert valid.all() and np.array_equal(valid, want_v) and np.array_equal(desc, want_d)
 
 
+def test_bounds_checking_build_of_the_tile_kernel(oracle):
+    """SURVEY.md section 5 (bounds asserts in debug kernels): libmofreak_hip_debug.so is the same source with every
+    LDS access of the tile kernel checked against the workgroup's allocation and every descriptor store against the
+    output's extent.  It must report nothing on inputs that reach every code path -- integer and fractional keypoints,
+    every halo, crowded and border tiles, a width that is not a multiple of 8 -- and still give the oracle's bytes."""
+    import os
+    import subprocess
+    import sys
+    from mofreak_amd import build
+    if not os.path.exists(build.DEBUG_LIB_PATH):
+        build.build_native(debug=True)
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import mofreak_amd as M
+from mofreak_amd import synth
+import oracle_lib
+f = oracle_lib.Freak()
+assert M.api.load().mofreak_build_flags() == 1, "not the bounds-checking build"
+with M.Context(0) as ctx:
+    for W, H, integer in ((417, 301, True), (640, 480, False), (331, 275, False)):
+        fr = synth.synth_stack(7, W, H)
+        rng = np.random.default_rng(W)
+        kps = synth.random_keypoints(rng, 6000, W, H, sizes=(7.0, 9.0, 12.0, 14.5, 18.0), integer_xy=integer)
+        desc, valid = ctx.extract_pairs_host(fr[5:], fr[:2], kps)
+        ctx.check_status()
+        for p in range(2):
+            d, v = f.extract_pair(fr[5 + p], fr[p], kps)
+            assert np.array_equal(desc[p * len(kps):(p + 1) * len(kps)], d) and np.array_equal(valid[p * len(kps):(p + 1) * len(kps)], v)
+print("debug build ok")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MOFREAK_HIP_LIBRARY=build.DEBUG_LIB_PATH)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "debug build ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 # ------------------------------------------------------------------ pipelined long streams (BASELINE config 5)
 @pytest.mark.parametrize("pinned", [False, True])
 def test_pipelined_stream_rows_equal_the_whole_stack_call(gpu_ctx, oracle, pinned):
