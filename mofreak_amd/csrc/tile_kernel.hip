@@ -448,6 +448,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     KpRec *kf = reinterpret_cast<KpRec *>(lds + kOffKf);
     uint32_t *kint = reinterpret_cast<uint32_t *>(lds + kOffKint);
     int2 *s_dirs = reinterpret_cast<int2 *>(lds + kOffDirs);
+    uint32_t *s_roi = reinterpret_cast<uint32_t *>(lds + kOffDirs);  // stage 1 only: where a keypoint's ROI starts in the staged rows
     const bool one_batch = n_tile_kp <= kBatch;
     // The binning pass recorded the smallest and largest ROI side of the tile: equal in the usual case.
     const int tile_L = (int)a.tile_lmin[key];
@@ -467,12 +468,10 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             const int xi = (int)kp.x, yi = (int)kp.y;
             const bool integral = (float)xi == kp.x && (float)yi == kp.y;
             kint[tid] = integral ? lds0 + kOffIntegral + 2 * (kIColOff + (yi - oy) * kIPitch + (xi - ox)) : 0x80000000u;
+            // the ROI's first byte in the staged rows (:293-295, :460 float -> int parameters)
+            const int half = (int)((kp.packed >> 8) & 0xff);
+            s_roi[tid] = (uint32_t)((yi - half - oy + 1) * kTileStagePitch + (xi - half - ox));
         }
-    };
-    // where a keypoint's ROI starts in the staged rows (:293-295, :460 float -> int parameters)
-    auto roi_offset = [&](const KpRec &k) -> uint32_t {
-        const int half = k.pk >> 11;
-        return (uint32_t)(((int)k.ky - half - oy + 1) * kTileStagePitch + ((int)k.kx - half - ox));
     };
 
     // ================= stage 0: the region's gray bytes -> LDS, 16 per lane and step.  Region row r goes to LDS row
@@ -628,12 +627,12 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             const uint32_t cross = __builtin_amdgcn_udot4(c0, p0, __builtin_amdgcn_udot4(c1, p1, 0u, false), false);
             return __ballot((int)(sq - 2u * cross) > mip_theta);
         };
-        auto put_motion = [&](int kk, int g, uint64_t mot) {
+        auto put_motion = [&](int kk, uint64_t mot) {
             const uint2 mv = make_uint2((uint32_t)mot, (uint32_t)(mot >> 32));
             if (one_batch)  // kept for one 16-byte store per descriptor at the end of stage 3
                 s_mot[kk] = mv;
             else  // a crowded tile (several batches) sends its motion bytes out now
-                *reinterpret_cast<uint2 *>(a.out_desc + (out_base + g) * 16 + 8) = mv;
+                *reinterpret_cast<uint2 *>(a.out_desc + (out_base + kf[kk].g) * 16 + 8) = mv;
         };
 
         for (int b0 = 0; b0 < n_tile_kp; b0 += kBatch) {
@@ -652,8 +651,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                 for (int kk = wave; kk < nb; kk += 2 * kTileWaves) {
                     const int kk2 = kk + kTileWaves;
                     const bool two = kk2 < nb;
-                    const KpRec m = kf[kk], m2 = kf[two ? kk2 : kk];
-                    const uint32_t roi = roi_offset(m), roi2 = roi_offset(m2);
+                    const uint32_t roi = s_roi[kk], roi2 = s_roi[two ? kk2 : kk];
                     uint32_t px[2][kMipIters];
 #pragma unroll
                     for (int u = 0; u < kMipIters; ++u) {
@@ -669,8 +667,8 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                     const Strips s2 = read_strips();
                     const uint64_t mot = strip_bits(s1), mot2 = strip_bits(s2);
                     if (lane == 0) {
-                        put_motion(kk, m.g, mot);
-                        if (two) put_motion(kk2, m2.g, mot2);
+                        put_motion(kk, mot);
+                        if (two) put_motion(kk2, mot2);
                     }
                     wave_lds_sync();  // the next pair of keypoints overwrites the 19x19 buffers
                 }
@@ -684,14 +682,14 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                         have_L = L;
                         load_samples(L);
                     }
-                    const uint32_t roi = roi_offset(m);
+                    const uint32_t roi = s_roi[kk];
                     uint32_t px[kMipIters];
 #pragma unroll
                     for (int u = 0; u < kMipIters; ++u) px[u] = sample(ml, u, roi);
                     put_pixels(ml, px);
                     wave_lds_sync();
                     const uint64_t mot = strip_bits(read_strips());
-                    if (lane == 0) put_motion(kk, m.g, mot);
+                    if (lane == 0) put_motion(kk, mot);
                     wave_lds_sync();
                 }
             }
