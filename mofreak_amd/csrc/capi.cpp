@@ -41,8 +41,9 @@ struct mofreak_ctx {
     DeviceBuffer bow_counts, bow_expanded;
     // keypoint detector workspace
     DeviceBuffer det_img, det_score, det_touch, det_status, det_rows, det_cand_xy, det_cand_flag, det_cand_emit, det_cand_spec, det_cand_asked, det_cand_win, det_cand_res, det_layer_start,
-        det_emit_count, det_tie_waiting, det_wait_list, det_geom, det_emit_offsets, det_running, det_out_kps, det_out_offsets, det_out_resp, det_out_layer, det_planes_out;
+        det_emit_count, det_emit_chunks, det_wait_list, det_geom, det_emit_offsets, det_out_kps, det_out_offsets, det_out_resp, det_out_layer, det_planes_out;
     int det_cand_cap = 131072;
+    size_t det_counter_bytes = 0;  // row counts + tie counters behind the running total in det_rows
     int64_t det_kp_capacity = 0;
     ThetaBound *d_theta = nullptr;
     unsigned long long *d_stamps = nullptr;  // MOFREAK_TILE_STAMPS=1: per-phase tick sums of the diagnostic tile kernel
@@ -661,8 +662,8 @@ void mofreak_destroy(mofreak_ctx *ctx)
     release(ctx->bow_counts);
     release(ctx->bow_expanded);
     for (DeviceBuffer *b : {&ctx->det_img, &ctx->det_score, &ctx->det_touch, &ctx->det_status, &ctx->det_rows, &ctx->det_cand_xy, &ctx->det_cand_flag,
-                            &ctx->det_cand_emit, &ctx->det_cand_spec, &ctx->det_cand_asked, &ctx->det_cand_win, &ctx->det_cand_res, &ctx->det_layer_start, &ctx->det_emit_count, &ctx->det_tie_waiting, &ctx->det_wait_list, &ctx->det_geom, &ctx->det_emit_offsets,
-                            &ctx->det_running, &ctx->det_out_kps, &ctx->det_out_offsets, &ctx->det_out_resp, &ctx->det_out_layer, &ctx->det_planes_out})
+                            &ctx->det_cand_emit, &ctx->det_cand_spec, &ctx->det_cand_asked, &ctx->det_cand_win, &ctx->det_cand_res, &ctx->det_layer_start, &ctx->det_emit_count, &ctx->det_emit_chunks, &ctx->det_wait_list, &ctx->det_geom, &ctx->det_emit_offsets,
+                            &ctx->det_out_kps, &ctx->det_out_offsets, &ctx->det_out_resp, &ctx->det_out_layer, &ctx->det_planes_out})
         release(*b);
     release(ctx->integral);
     release(ctx->band_totals);
@@ -1459,7 +1460,9 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     if ((rc = ensure(ctx, ctx->det_score, planes))) return rc;
     if ((rc = ensure(ctx, ctx->det_touch, planes))) return rc;
     if ((rc = ensure(ctx, ctx->det_status, planes))) return rc;
-    if ((rc = ensure(ctx, ctx->det_rows, (size_t)batch * (g.total_rows + 1) * sizeof(int32_t)))) return rc;
+    // one buffer, one fill: the call's running keypoint total (16 bytes), the per-row counts, the tie counters
+    const size_t n_row_counts = (size_t)batch * (g.total_rows + 1), n_tie_counters = (size_t)batch * kDetMaxLayers * 2;
+    if ((rc = ensure(ctx, ctx->det_rows, 16 + (n_row_counts + n_tie_counters) * sizeof(int32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_cand_xy, cands * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_cand_flag, cands))) return rc;
     if ((rc = ensure(ctx, ctx->det_cand_emit, cands))) return rc;
@@ -1470,8 +1473,8 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     if ((rc = ensure(ctx, ctx->det_layer_start, (size_t)batch * (kDetMaxLayers + 1) * sizeof(int32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_emit_count, (size_t)batch * sizeof(int32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_emit_offsets, (size_t)(batch + 1) * sizeof(int64_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->det_tie_waiting, (size_t)batch * kDetMaxLayers * 2 * sizeof(int32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->det_running, sizeof(int64_t)))) return rc;
+    a.emit_chunk_cap = (ctx->det_cand_cap + 1023) / 1024;
+    if ((rc = ensure(ctx, ctx->det_emit_chunks, (size_t)batch * a.emit_chunk_cap * sizeof(int32_t)))) return rc;
     a.g = g;
     if ((rc = upload(ctx, ctx->det_geom, &a.g, sizeof(DetGeom)))) return rc;  // a.g lives in the caller's frame until it synchronises
     a.dg = static_cast<const DetGeom *>(ctx->det_geom.ptr);
@@ -1479,7 +1482,9 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     a.score = static_cast<uint8_t *>(ctx->det_score.ptr);
     a.touch = static_cast<uint8_t *>(ctx->det_touch.ptr);
     a.status = static_cast<uint8_t *>(ctx->det_status.ptr);
-    a.row_count = static_cast<int32_t *>(ctx->det_rows.ptr);
+    a.row_count = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(ctx->det_rows.ptr) + 16);
+    a.tie_waiting = a.row_count + n_row_counts;
+    ctx->det_counter_bytes = (n_row_counts + n_tie_counters) * sizeof(int32_t);
     a.cand_cap = ctx->det_cand_cap;
     a.cand_xy = static_cast<uint32_t *>(ctx->det_cand_xy.ptr);
     a.cand_flag = static_cast<uint8_t *>(ctx->det_cand_flag.ptr);
@@ -1491,7 +1496,7 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     a.layer_start = static_cast<int32_t *>(ctx->det_layer_start.ptr);
     a.emit_count = static_cast<int32_t *>(ctx->det_emit_count.ptr);
     a.emit_offsets = static_cast<int64_t *>(ctx->det_emit_offsets.ptr);
-    a.tie_waiting = static_cast<int32_t *>(ctx->det_tie_waiting.ptr);
+    a.emit_chunks = static_cast<int32_t *>(ctx->det_emit_chunks.ptr);
     if ((rc = ensure(ctx, ctx->det_wait_list, (size_t)batch * 4096 * sizeof(int32_t)))) return rc;
     a.wait_list = static_cast<int32_t *>(ctx->det_wait_list.ptr);
     a.status_word = ctx->d_status + 1;  // the detector's own word: clearing it leaves the describe kernels' flags alone
@@ -1567,7 +1572,8 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
     DetArgs a{};
     if ((rc = det_workspace(ctx, g, batch, a))) return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_status + 1, 0, sizeof(int32_t), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->det_running.ptr, 0, sizeof(int64_t), ctx->stream));
+    int64_t *running = static_cast<int64_t *>(ctx->det_rows.ptr);
+    if (n_pairs == 0) HIP_TRY(ctx, hipMemsetAsync(running, 0, sizeof(int64_t), ctx->stream));
     if (n_pairs == 0) HIP_TRY(ctx, hipMemsetAsync(d_off, 0, sizeof(int64_t), ctx->stream));
     a.threshold = threshold;
     a.safe_threshold = (int)(uint8_t)((float)threshold * 1.0f);  // safeThreshold_ = threshold_ * safetyFactor_ (brisk.cpp:58, 597)
@@ -1581,18 +1587,20 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
         a.n_pairs = np;
         a.first_pair = p0;
         a.f = FrameArgs{d_cur + (int64_t)p0 * pair_stride, d_prev ? d_prev + (int64_t)p0 * pair_stride : nullptr, W, H, row_stride, pair_stride};
-        HIP_TRY(ctx, hipMemsetAsync(a.row_count, 0, (size_t)np * (g.total_rows + 1) * sizeof(int32_t), ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(a.touch, 0, (size_t)np * g.plane_bytes, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(a.status, 0, (size_t)np * g.plane_bytes, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(a.tie_waiting, 0, (size_t)np * kDetMaxLayers * 2 * sizeof(int32_t), ctx->stream));
+        // the counters of the batch (and, in front of them, the call's running total before its first batch); the touch
+        // and status maps are cleared by det_score_kernel
+        if (p0 == 0)
+            HIP_TRY(ctx, hipMemsetAsync(running, 0, 16 + ctx->det_counter_bytes, ctx->stream));
+        else
+            HIP_TRY(ctx, hipMemsetAsync(a.row_count, 0, ctx->det_counter_bytes, ctx->stream));
         int e = launch_det_pyramid(a, ctx->stream);
         if (!e) e = launch_det_scores(a, ctx->stream);
-        if (!e) e = launch_det_keypoints(a, static_cast<int64_t *>(ctx->det_running.ptr), ctx->stream);
+        if (!e) e = launch_det_keypoints(a, running, ctx->stream);
         if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("detector launch: ") + hipGetErrorString((hipError_t)e));
     }
     int64_t total = 0;
     int32_t st = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->det_running.ptr, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&total, running, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(&st, ctx->d_status + 1, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (n_out) *n_out = total;

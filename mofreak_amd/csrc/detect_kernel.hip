@@ -34,7 +34,6 @@ namespace mofreak {
 namespace {
 
 constexpr int kDetThreads = 256;
-constexpr int kDetTieRounds = 1;  // global rounds of tie decisions per layer before the per-pair loop takes the rest
 
 struct PairView {
     const DetGeom *g;
@@ -183,6 +182,7 @@ __global__ __launch_bounds__(kDetThreads) void det_score_kernel(DetArgs a, int l
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint8_t *score = a.score + (int64_t)p * a.dg->plane_bytes + L.off;
+    uint8_t *touch = a.touch + (int64_t)p * a.dg->plane_bytes + L.off, *status = a.status + (int64_t)p * a.dg->plane_bytes + L.off;
     int32_t *row_count = a.row_count + (int64_t)p * (a.dg->total_rows + 1) + L.row_base;
 #pragma unroll
     for (int it = 0; it < kScoreTileH / 4; ++it) {
@@ -214,7 +214,11 @@ __global__ __launch_bounds__(kDetThreads) void det_score_kernel(DetArgs a, int l
             const int vb = arc_lo - c, vd = c - arc_hi;  // brightest all-brighter arc margin, darkest all-darker arc margin
             s = max(max(vb, vd) - 1, 0);
         }
-        if (x < L.w && y < L.h) score[(int64_t)y * L.w + x] = (uint8_t)s;
+        if (x < L.w && y < L.h) {
+            score[(int64_t)y * L.w + x] = (uint8_t)s;
+            touch[(int64_t)y * L.w + x] = 0;  // the two bookkeeping maps of the tie logic start empty: cleared here, under
+            status[(int64_t)y * L.w + x] = 0;  // the arithmetic, instead of by two fills of their own
+        }
         const unsigned long long hit = __ballot(s >= a.safe_threshold);
         if (lane == 0 && hit && y < L.h) atomicAdd(&row_count[y], __popcll(hit));
     }
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(kDetThreads) void det_scan_kernel(DetArgs a)
     __syncthreads();
     if (threadIdx.x == kDetThreads - 1) {
         const int total = part[kDetThreads - 1];
+        a.emit_count[p] = 0;  // summed up by det_emit_count_kernel
         rc[n] = total;
         if (total > a.cand_cap) atomicOr(a.status_word, 4);
     }
@@ -915,8 +920,6 @@ __global__ __launch_bounds__(kDetThreads) void det_refine_kernel(DetArgs a)
 }
 
 // ---- ties
-constexpr uint8_t kDetTieReady = 3;
-
 // The smoothing part of isMax2D (brisk.cpp:874-933) on the reference's score cache as candidate (px, py) would find
 // it (see the header comment): a cell holds its score if it is a detected corner, if the layer below asked for it,
 // or if it lies in the 3x3 patch of a maximum that was processed earlier (raster order) and got as far as its patch;
@@ -925,8 +928,23 @@ struct TieStep {
     bool ready, is_max;
 };
 
-// One bulk load, both answers: is the tie ready (see tie_ready below: no undecided earlier tie whose patch overlaps an
-// unsettled cell of this window) and, if so, does it survive the smoothed comparison.
+// The status map is the one thing ties of a layer tell each other: a byte per pixel that goes from pending to its
+// final value once.  POLL: read it past the CU's vector cache (the workgroup that spins on a chain of ties must see
+// what its other waves publish); otherwise a plain load, where a stale "pending" only makes a tie wait.
+template <bool POLL>
+__device__ __forceinline__ uint8_t status_load(const uint8_t *p)
+{
+    if (POLL) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+__device__ __forceinline__ void status_publish(uint8_t *p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// One bulk load, both answers.  Ready: no undecided tie that precedes this one in raster order could still change a
+// cell it reads -- such a tie matters only through cells of its 3x3 patch that lie in this candidate's 5x5 window AND
+// whose cached value is not settled already (settled: score 0, a detected corner, or asked for from the layer below).
+// And, if ready, whether it survives the smoothed comparison.  Only the 24 cells before (px, py) in raster order can
+// hold a maximum that was processed earlier.
+template <bool POLL>
 __device__ __forceinline__ TieStep tie_step(const PairView &v, const DetLayer &L, int safe_threshold, int px, int py)
 {
     uint8_t st[7][7];
@@ -936,10 +954,14 @@ __device__ __forceinline__ TieStep tie_step(const PairView &v, const DetLayer &L
     for (int dy = -3; dy <= 3; ++dy)
 #pragma unroll
         for (int dx = -3; dx <= 3; ++dx) {
+            if (dy > 0 || (dy == 0 && dx >= 0)) {
+                st[dy + 3][dx + 3] = kStNone;
+                continue;
+            }
             const int mx = px + dx, my = py + dy;
             const bool in = mx >= 0 && my >= 0 && mx < L.w && my < L.h;
-            const uint8_t s = v.status[L.off + (int64_t)(in ? my : py) * L.w + (in ? mx : px)];
-            st[dy + 3][dx + 3] = (in && (dy < 0 || (dy == 0 && dx < 0))) ? s : (uint8_t)kStNone;  // only maxima processed before
+            const uint8_t s = status_load<POLL>(v.status + L.off + (int64_t)(in ? my : py) * L.w + (in ? mx : px));
+            st[dy + 3][dx + 3] = in ? s : (uint8_t)kStNone;
         }
 #pragma unroll
     for (int dy = -2; dy <= 2; ++dy)
@@ -987,168 +1009,108 @@ __device__ __forceinline__ TieStep tie_step(const PairView &v, const DetLayer &L
     return TieStep{!waits, is_max};
 }
 
-__device__ __forceinline__ bool tie_is_max(const PairView &v, const DetLayer &L, int safe_threshold, int px, int py)
-{
-    return tie_step(v, L, safe_threshold, px, py).is_max;
-}
-
-// A tie is ready when no undecided tie that precedes it in raster order could still change a cell it reads: such a
-// tie matters only through cells of its 3x3 patch that lie in this candidate's 5x5 window AND whose cached value
-// is not settled already (settled: score 0, a detected corner, or asked for from the layer below).
-__device__ __forceinline__ bool tie_ready(const PairView &v, const DetLayer &L, int safe_threshold, int px, int py)
-{
-    for (int dy = -3; dy <= 0; ++dy)
-        for (int dx = -3; dx <= 3; ++dx) {
-            if (dy == 0 && dx >= 0) break;
-            const int mx = px + dx, my = py + dy;
-            if (mx < 0 || my < 0 || mx >= L.w) continue;
-            if (v.status[L.off + (int64_t)my * L.w + mx] != kStPending) continue;
-            for (int qy = max(my - 1, py - 2); qy <= min(my + 1, py + 2); ++qy)
-                for (int qx = max(mx - 1, px - 2); qx <= min(mx + 1, px + 2); ++qx) {
-                    if (qx < 3 || qy < 3 || qx >= L.w - 3 || qy >= L.h - 3) continue;
-                    const int64_t o = L.off + (int64_t)qy * L.w + qx;
-                    const int sc = v.score[o];
-                    if (sc != 0 && sc < safe_threshold && !v.touch[o]) return false;
-                }
-        }
-    return true;
-}
-
 __device__ __forceinline__ void tie_apply(const DetArgs &a, const PairView &v, const DetLayer &L, int p, int i, int layer, int px, int py, bool is_max)
 {
     const int64_t ci = (int64_t)p * a.cand_cap + i;
+    uint8_t *st = v.status + L.off + (int64_t)py * L.w + px;
     if (is_max) {  // publish what the refinement kernel parked
         const uint8_t spec = a.cand_spec[ci];
         a.cand_flag[ci] = kDetMax;
         a.cand_emit[ci] = (spec & kEmit) ? 1 : 0;
-        v.status[L.off + (int64_t)py * L.w + px] = (spec & kReached) ? kStReached : kStDone;
         const unsigned long long asked = a.cand_asked[ci];
         if (asked) {
             const uint32_t o = a.cand_win[ci];
             apply_asked(v, layer + 1, (int)(o & 0xffff), (int)(o >> 16), asked);
         }
+        status_publish(st, (spec & kReached) ? kStReached : kStDone);
     } else {
         a.cand_flag[ci] = kDetNotMax;
-        v.status[L.off + (int64_t)py * L.w + px] = kStDone;
+        status_publish(st, kStDone);
     }
 }
 
-__device__ __forceinline__ void tie_decide(const DetArgs &a, const PairView &v, const DetLayer &L, int p, int i, int layer, int px, int py)
-{
-    tie_apply(a, v, L, p, i, layer, px, py, tie_is_max(v, L, a.safe_threshold, px, py));
-}
+// Ties of one layer, all pairs at once.  Every tie looks at its neighbourhood once: the ones that are ready -- the
+// great majority -- decide and publish on the spot (a ready tie depends on no tie that is still pending, so two of them
+// never need each other's outcome, and a status byte changes once, from pending to final: whoever reads the old value
+// merely waits); the others go on the pair's waiting list.  The last workgroup of a pair to finish its share then takes
+// that list: chains of ties that depend on each other, each link spun on by its own thread until the links before it
+// have published.  The earliest pending tie of a layer is always ready, so the spinning ends; all the waves involved
+// belong to one workgroup, so all of them are resident.
+constexpr int kTieThreads = 512, kTieGroups = 8;
+constexpr int kDetWaitCap = 4096;  // waiting ties per pair and layer the last workgroup takes from a list (more: it scans the layer)
 
-// Ties of one layer, all pairs at once, in rounds of mutually independent ones: `ready` marks them (and counts the
-// ones that have to wait), `decide` settles the marked ones.  Two launches, because a tie must not see a neighbour
-// half-way through its decision.
-constexpr int kDetWaitCap = 4096;  // waiting ties per pair and layer the residual loop takes from a list (more: it scans)
-
-__global__ __launch_bounds__(kDetThreads) void det_tie_ready_kernel(DetArgs a, int layer, int32_t *waiting)
+__global__ __launch_bounds__(kTieThreads) void det_tie_layer_kernel(DetArgs a, int layer, int32_t *waiting, int32_t *arrived)
 {
+    __shared__ int s_last;
     const int p = blockIdx.y;
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
-    const int i = ls[layer] + blockIdx.x * kDetThreads + threadIdx.x;
-    if (i >= ls[layer + 1]) return;
-    const int64_t ci = (int64_t)p * a.cand_cap + i;
-    if (a.cand_flag[ci] != kDetTie) return;
-    const uint32_t xy = a.cand_xy[ci];
-    const PairView v = pair_view(a, p);
-    if (tie_ready(v, a.dg->L[layer], a.safe_threshold, (int)(xy & 0xffff), (int)(xy >> 16)))
-        a.cand_flag[ci] = kDetTieReady;
-    else {
-        const int k = atomicAdd(&waiting[p], 1);
-        if (k < kDetWaitCap) a.wait_list[(int64_t)p * kDetWaitCap + k] = i;
-    }
-}
-
-__global__ __launch_bounds__(kDetThreads) void det_tie_decide_kernel(DetArgs a, int layer)
-{
-    const int p = blockIdx.y;
-    const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
-    const int i = ls[layer] + blockIdx.x * kDetThreads + threadIdx.x;
-    if (i >= ls[layer + 1]) return;
-    const int64_t ci = (int64_t)p * a.cand_cap + i;
-    if (a.cand_flag[ci] != kDetTieReady) return;
-    const uint32_t xy = a.cand_xy[ci];
-    const PairView v = pair_view(a, p);
-    tie_decide(a, v, a.dg->L[layer], p, i, layer, (int)(xy & 0xffff), (int)(xy >> 16));
-}
-
-// Whatever the global rounds left waiting (chains of ties that depend on each other): one workgroup per pair loops
-// until the layer is settled.  Pairs with nothing waiting leave at once.
-__global__ __launch_bounds__(kDetThreads) void det_tie_residual_kernel(DetArgs a, int layer, const int32_t *waiting)
-{
-    __shared__ int remaining;
-    const int p = blockIdx.x;
-    if (waiting[p] == 0) return;
-    const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
+    const int lo = ls[layer], hi = ls[layer + 1];
+    if (lo == hi) return;  // same for every workgroup of the pair
     const PairView v = pair_view(a, p);
     const int64_t cb = (int64_t)p * a.cand_cap;
     const DetLayer L = a.dg->L[layer];
-    const int lo = ls[layer], hi = ls[layer + 1];
-    // the waiting ties: from the list the last global round left, or (list overflow) every candidate of the layer
-    const int n_wait = waiting[p];
-    const bool listed = n_wait <= kDetWaitCap;
-    const int32_t *list = a.wait_list + (int64_t)p * kDetWaitCap;
+    int32_t *list = a.wait_list + (int64_t)p * kDetWaitCap;
+    for (int i = lo + blockIdx.x * kTieThreads + threadIdx.x; i < hi; i += gridDim.x * kTieThreads) {
+        if (a.cand_flag[cb + i] != kDetTie) continue;
+        const uint32_t xy = a.cand_xy[cb + i];
+        const int px = (int)(xy & 0xffff), py = (int)(xy >> 16);
+        const TieStep step = tie_step<false>(v, L, a.safe_threshold, px, py);
+        if (step.ready)
+            tie_apply(a, v, L, p, i, layer, px, py, step.is_max);
+        else {
+            const int k = atomicAdd(&waiting[p], 1);
+            if (k < kDetWaitCap) list[k] = i;
+        }
+    }
+    __threadfence();  // this workgroup's decisions and list entries, before its arrival counts
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&arrived[p], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other workgroups' writes, not this CU's cached past
+    const int n_wait = __hip_atomic_load(&waiting[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n_wait == 0) return;
+    const bool listed = n_wait <= kDetWaitCap;  // list overflow: every candidate of the layer
     const int n_items = listed ? n_wait : hi - lo;
     for (;;) {
-        if (threadIdx.x == 0) remaining = 0;
-        __syncthreads();
-        for (int k = threadIdx.x; k < n_items; k += kDetThreads) {
+        bool waits = false;
+        for (int k = threadIdx.x; k < n_items; k += kTieThreads) {
             const int i = listed ? list[k] : lo + k;
-            if (a.cand_flag[cb + i] != kDetTie) continue;
+            if (a.cand_flag[cb + i] != kDetTie) continue;  // written by this thread only from here on
             const uint32_t xy = a.cand_xy[cb + i];
-            if (tie_ready(v, L, a.safe_threshold, (int)(xy & 0xffff), (int)(xy >> 16)))
-                a.cand_flag[cb + i] = kDetTieReady;
+            const int px = (int)(xy & 0xffff), py = (int)(xy >> 16);
+            const TieStep step = tie_step<true>(v, L, a.safe_threshold, px, py);
+            if (step.ready)
+                tie_apply(a, v, L, p, i, layer, px, py, step.is_max);
             else
-                atomicAdd(&remaining, 1);
+                waits = true;
         }
-        __threadfence_block();
-        __syncthreads();
-        for (int k = threadIdx.x; k < n_items; k += kDetThreads) {
-            const int i = listed ? list[k] : lo + k;
-            if (a.cand_flag[cb + i] != kDetTieReady) continue;
-            uint32_t xy = a.cand_xy[cb + i];
-            int px = (int)(xy & 0xffff), py = (int)(xy >> 16);
-            tie_decide(a, v, L, p, i, layer, px, py);
-            // The usual chain is a run of equal scores along a row, each tie waiting for its left neighbour only:
-            // follow it instead of spending a round per link.  The next candidate in raster order is taken if it sits
-            // within reach on the same row, is still waiting (so no other thread owns it this round) and has become
-            // ready; everything it then reads is final (a decided status is written once and never changes).
-            for (int j = i + 1; j < hi; ++j) {
-                __threadfence_block();
-                if (a.cand_flag[cb + j] != kDetTie) break;
-                xy = a.cand_xy[cb + j];
-                const int nx = (int)(xy & 0xffff), ny = (int)(xy >> 16);
-                if (ny != py || nx - px > 3) break;
-                const TieStep step = tie_step(v, L, a.safe_threshold, nx, ny);  // one round of loads per link of the chain
-                if (!step.ready) break;
-                tie_apply(a, v, L, p, j, layer, nx, ny, step.is_max);
-                atomicSub(&remaining, 1);
-                px = nx;
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-        if (remaining == 0) break;
-        __syncthreads();
+        if (!waits) break;
     }
 }
 
 // ------------------------------------------------------------------ ordered emission
+// The candidates of a pair in chunks of kEmitChunk, one workgroup per chunk: how many of each chunk are emitted
+// (and, summed up, of the pair); det_emit_scatter_kernel places a chunk behind the chunks before it.
+constexpr int kEmitChunk = 1024;
+
 __global__ __launch_bounds__(kDetThreads) void det_emit_count_kernel(DetArgs a)
 {
     __shared__ int total;
-    const int p = blockIdx.x;
+    const int p = blockIdx.y, c = blockIdx.x;
+    const int n = a.layer_start[(int64_t)p * (kDetMaxLayers + 1) + a.dg->n_layers];
+    if (c * kEmitChunk >= n) return;
     if (threadIdx.x == 0) total = 0;
     __syncthreads();
-    const int n = a.layer_start[(int64_t)p * (kDetMaxLayers + 1) + a.dg->n_layers];
-    int c = 0;
-    for (int i = threadIdx.x; i < n; i += kDetThreads) c += a.cand_emit[(int64_t)p * a.cand_cap + i];
-    c = wave_sum(c);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&total, c);
+    int cnt = 0;
+    for (int i = c * kEmitChunk + threadIdx.x; i < min(n, (c + 1) * kEmitChunk); i += kDetThreads) cnt += a.cand_emit[(int64_t)p * a.cand_cap + i];
+    cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&total, cnt);
     __syncthreads();
-    if (threadIdx.x == 0) a.emit_count[p] = total;
+    if (threadIdx.x == 0) {
+        a.emit_chunks[(int64_t)p * a.emit_chunk_cap + c] = total;
+        atomicAdd(&a.emit_count[p], total);  // zeroed by det_scan_kernel
+    }
 }
 
 // one workgroup: CSR offsets of the batch's pairs, continuing the running total of the call
@@ -1187,12 +1149,20 @@ __global__ __launch_bounds__(kDetThreads) void det_emit_scan_kernel(DetArgs a, i
 
 __global__ __launch_bounds__(kDetThreads) void det_emit_scatter_kernel(DetArgs a)
 {
-    __shared__ int wave_cnt[4];
-    const int p = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int wave_cnt[4], chunk_base;
+    const int p = blockIdx.y, c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
     const int n = ls[a.dg->n_layers];
-    long long run = a.emit_offsets[p];
-    for (int i0 = 0; i0 < n; i0 += kDetThreads) {
+    if (c * kEmitChunk >= n) return;
+    if (wave == 0) {  // emitted candidates in the chunks before this one
+        int before = 0;
+        for (int k = lane; k < c; k += 64) before += a.emit_chunks[(int64_t)p * a.emit_chunk_cap + k];
+        before = wave_sum(before);
+        if (lane == 0) chunk_base = before;
+    }
+    __syncthreads();
+    long long run = a.emit_offsets[p] + chunk_base;
+    for (int i0 = c * kEmitChunk; i0 < min(n, (c + 1) * kEmitChunk); i0 += kDetThreads) {
         const int i = i0 + threadIdx.x;
         const int64_t ci = (int64_t)p * a.cand_cap + i;
         const bool e = i < n && a.cand_emit[ci];
@@ -1255,18 +1225,13 @@ int launch_det_keypoints(const DetArgs &a, int64_t *running, void *stream)
     hipLaunchKernelGGL(det_candidates_kernel, dim3((a.g.total_rows + 3) / 4, a.n_pairs), dim3(kDetThreads), 0, s, a);
     hipLaunchKernelGGL(det_refine_kernel, dim3((a.cand_cap + kDetThreads - 1) / kDetThreads, a.n_pairs), dim3(kDetThreads), 0, s, a);
     // ties: layer by layer (a layer's ties read what the maxima of the layer below asked for in it)
-    const dim3 cgrid((a.cand_cap + kDetThreads - 1) / kDetThreads, a.n_pairs);
-    for (int l = 0; l < a.g.n_layers; ++l) {
-        for (int round = 0; round < kDetTieRounds; ++round) {
-            hipLaunchKernelGGL(det_tie_ready_kernel, cgrid, dim3(kDetThreads), 0, s, a, l, a.tie_waiting + (int64_t)(l * kDetTieRounds + round) * a.n_pairs);
-            hipLaunchKernelGGL(det_tie_decide_kernel, cgrid, dim3(kDetThreads), 0, s, a, l);
-        }
-        hipLaunchKernelGGL(det_tie_residual_kernel, dim3(a.n_pairs), dim3(kDetThreads), 0, s, a, l,
-                           a.tie_waiting + (int64_t)(l * kDetTieRounds + kDetTieRounds - 1) * a.n_pairs);
-    }
-    hipLaunchKernelGGL(det_emit_count_kernel, dim3(a.n_pairs), dim3(kDetThreads), 0, s, a);
+    for (int l = 0; l < a.g.n_layers; ++l)
+        hipLaunchKernelGGL(det_tie_layer_kernel, dim3(kTieGroups, a.n_pairs), dim3(kTieThreads), 0, s, a, l, a.tie_waiting + (int64_t)(2 * l) * a.n_pairs,
+                           a.tie_waiting + (int64_t)(2 * l + 1) * a.n_pairs);
+    const dim3 egrid((a.cand_cap + kEmitChunk - 1) / kEmitChunk, a.n_pairs);
+    hipLaunchKernelGGL(det_emit_count_kernel, egrid, dim3(kDetThreads), 0, s, a);
     hipLaunchKernelGGL(det_emit_scan_kernel, dim3(1), dim3(kDetThreads), 0, s, a, running);
-    hipLaunchKernelGGL(det_emit_scatter_kernel, dim3(a.n_pairs), dim3(kDetThreads), 0, s, a);
+    hipLaunchKernelGGL(det_emit_scatter_kernel, egrid, dim3(kDetThreads), 0, s, a);
     return (int)hipGetLastError();
 }
 

@@ -201,8 +201,10 @@ struct DetArgs {
     DetResult *cand_res;                    // [n_pairs][cand_cap]
     int32_t *layer_start;                   // [n_pairs][kDetMaxLayers + 1]
     int32_t *emit_count;                    // [n_pairs]
-    int32_t *wait_list;                     // [n_pairs][4096]: the ties the last global round of the current layer left waiting
-    int32_t *tie_waiting;                   // [kDetMaxLayers * 2][n_pairs], zeroed per batch: ties a global round left waiting
+    int32_t *emit_chunks;                   // [n_pairs][emit_chunk_cap]: emitted candidates per chunk of 1024
+    int32_t emit_chunk_cap;
+    int32_t *wait_list;                     // [n_pairs][4096]: the ties of the current layer that were not ready at first sight
+    int32_t *tie_waiting;                   // [kDetMaxLayers][2][n_pairs], zeroed per batch: ties of a layer left waiting; workgroups that arrived
     int64_t *emit_offsets;                  // [n_pairs + 1], relative to out_base
     mofreak_keypoint *out_kps;              // whole-call outputs
     float *out_response;                    // optional
