@@ -928,25 +928,32 @@ struct TieStep {
     bool ready, is_max;
 };
 
-// The status map is the one thing ties of a layer tell each other: a byte per pixel that goes from pending to its
-// final value once.  POLL: read it past the CU's vector cache (the workgroup that spins on a chain of ties must see
-// what its other waves publish); otherwise a plain load, where a stale "pending" only makes a tie wait.
-template <bool POLL>
-__device__ __forceinline__ uint8_t status_load(const uint8_t *p)
+__device__ __forceinline__ unsigned long long load8(const uint8_t *p)
 {
-    if (POLL) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
+    unsigned long long q;
+    __builtin_memcpy(&q, p, 8);  // one unaligned 8-byte load
+    return q;
 }
-__device__ __forceinline__ void status_publish(uint8_t *p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // One bulk load, both answers.  Ready: no undecided tie that precedes this one in raster order could still change a
 // cell it reads -- such a tie matters only through cells of its 3x3 patch that lie in this candidate's 5x5 window AND
 // whose cached value is not settled already (settled: score 0, a detected corner, or asked for from the layer below).
 // And, if ready, whether it survives the smoothed comparison.  Only the 24 cells before (px, py) in raster order can
 // hold a maximum that was processed earlier.
-template <bool POLL>
+// A candidate lies at least 3 pixels inside its layer (the score is zero in the border), so every row segment read
+// here starts inside the layer: fourteen 8-byte loads, issued together (the two bytes some run past the end of a row
+// stay inside the padded plane and are masked out).
 __device__ __forceinline__ TieStep tie_step(const PairView &v, const DetLayer &L, int safe_threshold, int px, int py)
 {
+    const int64_t at = L.off + (int64_t)py * L.w + px;
+    unsigned long long st_row[4], sc_row[5], tc_row[5];
+#pragma unroll
+    for (int dy = -3; dy <= 0; ++dy) st_row[dy + 3] = load8(v.status + at + dy * L.w - 3);
+#pragma unroll
+    for (int dy = -2; dy <= 2; ++dy) {
+        sc_row[dy + 2] = load8(v.score + at + dy * L.w - 2);
+        tc_row[dy + 2] = load8(v.touch + at + dy * L.w - 2);
+    }
     uint8_t st[7][7];
     int sc[5][5];
     uint8_t tc[5][5];
@@ -954,14 +961,8 @@ __device__ __forceinline__ TieStep tie_step(const PairView &v, const DetLayer &L
     for (int dy = -3; dy <= 3; ++dy)
 #pragma unroll
         for (int dx = -3; dx <= 3; ++dx) {
-            if (dy > 0 || (dy == 0 && dx >= 0)) {
-                st[dy + 3][dx + 3] = kStNone;
-                continue;
-            }
-            const int mx = px + dx, my = py + dy;
-            const bool in = mx >= 0 && my >= 0 && mx < L.w && my < L.h;
-            const uint8_t s = status_load<POLL>(v.status + L.off + (int64_t)(in ? my : py) * L.w + (in ? mx : px));
-            st[dy + 3][dx + 3] = in ? s : (uint8_t)kStNone;
+            const bool before = dy < 0 || (dy == 0 && dx < 0);  // the candidate is >= 3 pixels inside: these cells exist
+            st[dy + 3][dx + 3] = before ? (uint8_t)(st_row[before ? dy + 3 : 0] >> (8 * (dx + 3))) : (uint8_t)kStNone;
         }
 #pragma unroll
     for (int dy = -2; dy <= 2; ++dy)
@@ -969,9 +970,8 @@ __device__ __forceinline__ TieStep tie_step(const PairView &v, const DetLayer &L
         for (int dx = -2; dx <= 2; ++dx) {
             const int qx = px + dx, qy = py + dy;
             const bool in = qx >= 3 && qy >= 3 && qx < L.w - 3 && qy < L.h - 3;
-            const int64_t o = L.off + (int64_t)(in ? qy : py) * L.w + (in ? qx : px);
-            sc[dy + 2][dx + 2] = in ? (int)v.score[o] : 0;
-            tc[dy + 2][dx + 2] = in ? v.touch[o] : (uint8_t)0;
+            sc[dy + 2][dx + 2] = in ? (int)((sc_row[dy + 2] >> (8 * (dx + 2))) & 0xff) : 0;
+            tc[dy + 2][dx + 2] = in ? (uint8_t)(tc_row[dy + 2] >> (8 * (dx + 2))) : (uint8_t)0;
         }
     int r[5][5];
     bool waits = false;
@@ -1009,84 +1009,114 @@ __device__ __forceinline__ TieStep tie_step(const PairView &v, const DetLayer &L
     return TieStep{!waits, is_max};
 }
 
-__device__ __forceinline__ void tie_apply(const DetArgs &a, const PairView &v, const DetLayer &L, int p, int i, int layer, int px, int py, bool is_max)
+// What a tie needs besides its neighbourhood, fetched together with it (nothing here depends on the decision)
+struct TieCand {
+    uint32_t xy, win;
+    uint8_t flag, spec;
+    unsigned long long asked;
+};
+__device__ __forceinline__ TieCand tie_cand(const DetArgs &a, int64_t ci)
 {
-    const int64_t ci = (int64_t)p * a.cand_cap + i;
+    return TieCand{a.cand_xy[ci], a.cand_win[ci], a.cand_flag[ci], a.cand_spec[ci], a.cand_asked[ci]};
+}
+
+// The status map is the one thing ties of a layer tell each other: a byte per pixel that goes from pending to its
+// final value once.
+__device__ __forceinline__ void tie_apply(const DetArgs &a, const PairView &v, const DetLayer &L, int64_t ci, const TieCand &c, int layer, int px, int py,
+                                          bool is_max)
+{
     uint8_t *st = v.status + L.off + (int64_t)py * L.w + px;
     if (is_max) {  // publish what the refinement kernel parked
-        const uint8_t spec = a.cand_spec[ci];
         a.cand_flag[ci] = kDetMax;
-        a.cand_emit[ci] = (spec & kEmit) ? 1 : 0;
-        const unsigned long long asked = a.cand_asked[ci];
-        if (asked) {
-            const uint32_t o = a.cand_win[ci];
-            apply_asked(v, layer + 1, (int)(o & 0xffff), (int)(o >> 16), asked);
-        }
-        status_publish(st, (spec & kReached) ? kStReached : kStDone);
+        a.cand_emit[ci] = (c.spec & kEmit) ? 1 : 0;
+        if (c.asked) apply_asked(v, layer + 1, (int)(c.win & 0xffff), (int)(c.win >> 16), c.asked);
+        __hip_atomic_store(st, (c.spec & kReached) ? kStReached : kStDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
         a.cand_flag[ci] = kDetNotMax;
-        status_publish(st, kStDone);
+        __hip_atomic_store(st, (uint8_t)kStDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
-// Ties of one layer, all pairs at once.  Every tie looks at its neighbourhood once: the ones that are ready -- the
-// great majority -- decide and publish on the spot (a ready tie depends on no tie that is still pending, so two of them
-// never need each other's outcome, and a status byte changes once, from pending to final: whoever reads the old value
-// merely waits); the others go on the pair's waiting list.  The last workgroup of a pair to finish its share then takes
-// that list: chains of ties that depend on each other, each link spun on by its own thread until the links before it
-// have published.  The earliest pending tie of a layer is always ready, so the spinning ends; all the waves involved
-// belong to one workgroup, so all of them are resident.
+// Ties of one layer, all pairs at once.  First sight: every tie looks at its neighbourhood once; the ones that are
+// ready -- the great majority -- decide and publish on the spot (a ready tie depends on no tie that is still pending,
+// so two of them never need each other's outcome, and a status byte changes once, from pending to final: whoever reads
+// the old value merely waits); the others go on the pair's waiting list.
 constexpr int kTieThreads = 512, kTieGroups = 8;
-constexpr int kDetWaitCap = 4096;  // waiting ties per pair and layer the last workgroup takes from a list (more: it scans the layer)
+constexpr int kDetWaitCap = 4096;  // waiting ties per pair and layer the chain kernel takes from a list (more: it scans the layer)
 
-__global__ __launch_bounds__(kTieThreads) void det_tie_layer_kernel(DetArgs a, int layer, int32_t *waiting, int32_t *arrived)
+__global__ __launch_bounds__(kTieThreads) void det_tie_first_kernel(DetArgs a, int layer, int32_t *waiting)
 {
-    __shared__ int s_last;
     const int p = blockIdx.y;
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
     const int lo = ls[layer], hi = ls[layer + 1];
-    if (lo == hi) return;  // same for every workgroup of the pair
     const PairView v = pair_view(a, p);
     const int64_t cb = (int64_t)p * a.cand_cap;
     const DetLayer L = a.dg->L[layer];
     int32_t *list = a.wait_list + (int64_t)p * kDetWaitCap;
     for (int i = lo + blockIdx.x * kTieThreads + threadIdx.x; i < hi; i += gridDim.x * kTieThreads) {
-        if (a.cand_flag[cb + i] != kDetTie) continue;
-        const uint32_t xy = a.cand_xy[cb + i];
-        const int px = (int)(xy & 0xffff), py = (int)(xy >> 16);
-        const TieStep step = tie_step<false>(v, L, a.safe_threshold, px, py);
+        const TieCand c = tie_cand(a, cb + i);
+        if (c.flag != kDetTie) continue;
+        const int px = (int)(c.xy & 0xffff), py = (int)(c.xy >> 16);
+        const TieStep step = tie_step(v, L, a.safe_threshold, px, py);
         if (step.ready)
-            tie_apply(a, v, L, p, i, layer, px, py, step.is_max);
+            tie_apply(a, v, L, cb + i, c, layer, px, py, step.is_max);
         else {
             const int k = atomicAdd(&waiting[p], 1);
             if (k < kDetWaitCap) list[k] = i;
         }
     }
-    __threadfence();  // this workgroup's decisions and list entries, before its arrival counts
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&arrived[p], 1) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other workgroups' writes, not this CU's cached past
-    const int n_wait = __hip_atomic_load(&waiting[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// What first sight left waiting: chains of ties that depend on each other.  One workgroup per pair, a thread per link
+// (or several), each spinning until the links before it have published; the earliest pending tie of a layer is
+// always ready, so the spinning ends.  Everything the threads tell each other stays inside the workgroup -- one CU,
+// one vector cache -- so workgroup-scope ordering is all it takes, and all the waves involved are resident.
+__global__ __launch_bounds__(kTieThreads) void det_tie_chain_kernel(DetArgs a, int layer, const int32_t *waiting)
+{
+    const int p = blockIdx.x;
+    const int n_wait = waiting[p];
     if (n_wait == 0) return;
+    const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
+    const int lo = ls[layer], hi = ls[layer + 1];
+    const PairView v = pair_view(a, p);
+    const int64_t cb = (int64_t)p * a.cand_cap;
+    const DetLayer L = a.dg->L[layer];
+    const int32_t *list = a.wait_list + (int64_t)p * kDetWaitCap;
     const bool listed = n_wait <= kDetWaitCap;  // list overflow: every candidate of the layer
     const int n_items = listed ? n_wait : hi - lo;
+#ifdef MOFREAK_TIE_DEBUG
+    int passes = 0;
+    const long long t_begin = wall_clock64();
+#endif
     for (;;) {
+#ifdef MOFREAK_TIE_DEBUG
+        ++passes;
+#endif
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // the pass reads what has been published by now
         bool waits = false;
         for (int k = threadIdx.x; k < n_items; k += kTieThreads) {
             const int i = listed ? list[k] : lo + k;
-            if (a.cand_flag[cb + i] != kDetTie) continue;  // written by this thread only from here on
-            const uint32_t xy = a.cand_xy[cb + i];
-            const int px = (int)(xy & 0xffff), py = (int)(xy >> 16);
-            const TieStep step = tie_step<true>(v, L, a.safe_threshold, px, py);
+            const TieCand c = tie_cand(a, cb + i);
+            if (c.flag != kDetTie) continue;  // written by this thread only
+            const int px = (int)(c.xy & 0xffff), py = (int)(c.xy >> 16);
+            const TieStep step = tie_step(v, L, a.safe_threshold, px, py);
             if (step.ready)
-                tie_apply(a, v, L, p, i, layer, px, py, step.is_max);
+                tie_apply(a, v, L, cb + i, c, layer, px, py, step.is_max);
             else
                 waits = true;
         }
         if (!waits) break;
     }
+#ifdef MOFREAK_TIE_DEBUG
+    {
+        __shared__ int max_passes;
+        if (threadIdx.x == 0) max_passes = 0;
+        __syncthreads();
+        atomicMax(&max_passes, passes);
+        __syncthreads();
+        if (threadIdx.x == 0 && p < 4) printf("pair %d layer %d: %d ties of %d candidates waiting, %d passes, %lld us\n", p, layer, n_wait, hi - lo, max_passes, (wall_clock64() - t_begin) / 100);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ ordered emission
@@ -1225,9 +1255,11 @@ int launch_det_keypoints(const DetArgs &a, int64_t *running, void *stream)
     hipLaunchKernelGGL(det_candidates_kernel, dim3((a.g.total_rows + 3) / 4, a.n_pairs), dim3(kDetThreads), 0, s, a);
     hipLaunchKernelGGL(det_refine_kernel, dim3((a.cand_cap + kDetThreads - 1) / kDetThreads, a.n_pairs), dim3(kDetThreads), 0, s, a);
     // ties: layer by layer (a layer's ties read what the maxima of the layer below asked for in it)
-    for (int l = 0; l < a.g.n_layers; ++l)
-        hipLaunchKernelGGL(det_tie_layer_kernel, dim3(kTieGroups, a.n_pairs), dim3(kTieThreads), 0, s, a, l, a.tie_waiting + (int64_t)(2 * l) * a.n_pairs,
-                           a.tie_waiting + (int64_t)(2 * l + 1) * a.n_pairs);
+    for (int l = 0; l < a.g.n_layers; ++l) {
+        int32_t *waiting = a.tie_waiting + (int64_t)l * a.n_pairs;
+        hipLaunchKernelGGL(det_tie_first_kernel, dim3(kTieGroups, a.n_pairs), dim3(kTieThreads), 0, s, a, l, waiting);
+        hipLaunchKernelGGL(det_tie_chain_kernel, dim3(a.n_pairs), dim3(kTieThreads), 0, s, a, l, waiting);
+    }
     const dim3 egrid((a.cand_cap + kEmitChunk - 1) / kEmitChunk, a.n_pairs);
     hipLaunchKernelGGL(det_emit_count_kernel, egrid, dim3(kDetThreads), 0, s, a);
     hipLaunchKernelGGL(det_emit_scan_kernel, dim3(1), dim3(kDetThreads), 0, s, a, running);
