@@ -138,22 +138,43 @@ __global__ __launch_bounds__(kDetThreads) void det_twothird_kernel(DetArgs a, in
 // score = largest b in [1, 254] for which 9 contiguous ring pixels are all > c + b or all < c - b, 0 if none:
 // what OastDetector9_16::cornerScore's bisection converges to (oast9_16_nms.cc:42-2116), for any start value <= it.
 // over the 16 arcs of 9 contiguous ring pixels: the largest arc minimum and the smallest arc maximum of the raw values
+// three-input minimum / maximum of non-negative values, spelled out: left to itself the compiler re-associates the chains
+// below into more two-input operations than this count
+__device__ __forceinline__ int min3i(int a, int b, int c)
+{
+    int r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int max3i(int a, int b, int c)
+{
+    int r;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ void arc9_extremes(const int (&p)[16], int &max_of_min, int &min_of_max)
 {
-    int lo3[16], hi3[16];
+    // an arc of 9 = three runs of 3: 16 + 16 three-input operations per side, and 8 more to reduce the 16 arcs
+    int lo3[16], hi3[16], lo9[16], hi9[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        lo3[k] = min(p[k], min(p[(k + 1) & 15], p[(k + 2) & 15]));
-        hi3[k] = max(p[k], max(p[(k + 1) & 15], p[(k + 2) & 15]));
+        lo3[k] = min3i(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
+        hi3[k] = max3i(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
     }
-    int best_lo = 0, best_hi = 255;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        best_lo = max(best_lo, min(lo3[k], min(lo3[(k + 3) & 15], lo3[(k + 6) & 15])));
-        best_hi = min(best_hi, max(hi3[k], max(hi3[(k + 3) & 15], hi3[(k + 6) & 15])));
+        lo9[k] = min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+        hi9[k] = max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
     }
-    max_of_min = best_lo;
-    min_of_max = best_hi;
+    int lo5[5], hi5[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        lo5[k] = max3i(lo9[3 * k], lo9[3 * k + 1], lo9[3 * k + 2]);
+        hi5[k] = min3i(hi9[3 * k], hi9[3 * k + 1], hi9[3 * k + 2]);
+    }
+    max_of_min = max(max3i(lo5[0], lo5[1], lo5[2]), max3i(lo5[3], lo5[4], lo9[15]));
+    min_of_max = min(min3i(hi5[0], hi5[1], hi5[2]), min3i(hi5[3], hi5[4], hi9[15]));
 }
 
 constexpr int kScoreTileW = 64, kScoreTileH = 32, kScoreLdsW = 72;  // LDS rows start at image column x0 - 4: aligned dwords
@@ -283,45 +304,57 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
     const bool wide = (L.w & 3) == 0;
     const int per = wide ? 4 : 1;
     const uint8_t *srow = sc + (int64_t)y * L.w;
-    for (int x0 = 0; x0 < L.w; x0 += 64 * per) {
-        const int xl = x0 + per * lane;
-        uint32_t v4 = 0;
-        if (xl < L.w) v4 = wide ? *reinterpret_cast<const uint32_t *>(srow + xl) : (uint32_t)srow[xl];
-        int below = 0, total = 0;
-        bool hit[4];
+    constexpr int kSteps = 8;  // a row in chunks of 8 steps of 64 lanes: the chunk's loads are issued together
+    for (int xc = 0; xc < L.w; xc += kSteps * 64 * per) {
+        uint32_t vv[kSteps];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            hit[j] = j < per && (int)((v4 >> (8 * j)) & 0xff) >= a.safe_threshold;  // the score is zero outside the 3-pixel border
-            const unsigned long long m = __ballot(hit[j]);
-            below += __popcll(m & ((1ull << lane) - 1));
-            total += __popcll(m);
+        for (int u = 0; u < kSteps; ++u) {
+            const int xl = xc + per * (64 * u + lane);
+            const int xs = min(xl, L.w - per);  // stays inside the row; masked below
+            const uint32_t q = wide ? *reinterpret_cast<const uint32_t *>(srow + xs) : (uint32_t)srow[xs];
+            vv[u] = xl < L.w ? q : 0u;
         }
-        int idx = base + below;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (!hit[j]) continue;
-            const int x = xl + j, s = (int)((v4 >> (8 * j)) & 0xff);
-            if (idx < a.cand_cap) {
-                const uint8_t *q = srow + x;
-                int hi = 0, eq = 0;
+        for (int u = 0; u < kSteps; ++u) {
+            const int xl = xc + per * (64 * u + lane);
+            const uint32_t v4 = vv[u];
+            int below = 0, total = 0;
+            bool hit[4];
 #pragma unroll
-                for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        if (dx == 0 && dy == 0) continue;
-                        const int v = q[dy * L.w + dx];
-                        hi |= v > s;
-                        eq |= v == s;
-                    }
-                const uint8_t flag = hi ? kDetNotMax : (eq ? kDetTie : kDetMax);
-                a.cand_xy[cbase + idx] = (uint32_t)x | ((uint32_t)y << 16);
-                a.cand_flag[cbase + idx] = flag;
-                a.cand_emit[cbase + idx] = 0;
-                if (flag == kDetTie) a.status[plane + (int64_t)y * L.w + x] = kStPending;
+            for (int j = 0; j < 4; ++j) {
+                hit[j] = j < per && (int)((v4 >> (8 * j)) & 0xff) >= a.safe_threshold;  // the score is zero outside the 3-pixel border
+                const unsigned long long m = __ballot(hit[j]);
+                below += __popcll(m & ((1ull << lane) - 1));
+                total += __popcll(m);
             }
-            ++idx;
+            if (total == 0) continue;  // wave-uniform
+            int idx = base + below;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!hit[j]) continue;
+                const int x = xl + j, s = (int)((v4 >> (8 * j)) & 0xff);
+                if (idx < a.cand_cap) {
+                    const uint8_t *q = srow + x;
+                    int hi = 0, eq = 0;
+#pragma unroll
+                    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            if (dx == 0 && dy == 0) continue;
+                            const int v = q[dy * L.w + dx];
+                            hi |= v > s;
+                            eq |= v == s;
+                        }
+                    const uint8_t flag = hi ? kDetNotMax : (eq ? kDetTie : kDetMax);
+                    a.cand_xy[cbase + idx] = (uint32_t)x | ((uint32_t)y << 16);
+                    a.cand_flag[cbase + idx] = flag;
+                    a.cand_emit[cbase + idx] = 0;
+                    if (flag == kDetTie) a.status[plane + (int64_t)y * L.w + x] = kStPending;
+                }
+                ++idx;
+            }
+            base += total;
         }
-        base += total;
     }
 }
 
@@ -342,7 +375,14 @@ __device__ __forceinline__ int score_at(const PairView &v, int layer, int x, int
 // ((int)x_1 - 1, (int)y_1 - 1) of getScoreMaxAbove/Below's sampling square, patch and tie rings included -- fetched with six
 // independent 8-byte loads into the thread's own 48 bytes of LDS.  The walk itself is a chain of data-dependent early
 // exits: on global memory every step would pay a full memory latency.
-constexpr int kWinSide = 6, kWinRow = 8, kWinStride = 52;  // 6 rows of 8 bytes per thread; 13 dwords apart: neighbouring threads hit different banks
+constexpr int kWinSide = 6, kWinRow = 8, kWinBytes = 48, kWinStride = 108;  // two windows (above, below) of 6 rows of 8 bytes per thread; 27 dwords apart: neighbouring threads hit different banks
+__device__ __forceinline__ unsigned long long load8(const uint8_t *p)
+{
+    unsigned long long q;
+    __builtin_memcpy(&q, p, 8);  // one unaligned 8-byte load
+    return q;
+}
+
 struct Window {
     uint8_t *cells;
     int ox, oy, layer;
@@ -350,7 +390,10 @@ struct Window {
     bool escaped;              // the walk left the window (cannot happen by construction; reported if it does)
 };
 
-__device__ __forceinline__ void window_load(const PairView &v, Window &w)
+struct WindowRows {
+    unsigned long long r[kWinSide];
+};
+__device__ __forceinline__ WindowRows window_fetch(const PairView &v, const Window &w)
 {
     const DetLayer &L = v.g->L[w.layer];
     // which of the six columns lie inside the scored region (3-pixel border): a byte mask over one 8-byte row
@@ -362,19 +405,23 @@ __device__ __forceinline__ void window_load(const PairView &v, Window &w)
     }
     const int oxc = min(max(w.ox, 0), max(L.w - 1, 0));  // ox >= 0 by construction; the clamp only keeps the address sane
     if (oxc != w.ox) colmask = 0;
-    unsigned long long rows[kWinSide];
+    WindowRows rows;
 #pragma unroll
     for (int r = 0; r < kWinSide; ++r) {  // one unaligned 8-byte load per row, all six in flight together; the plane is
         const int y = w.oy + r;           // padded, so the two bytes past the window never leave the allocation
         const int yc = min(max(y, 0), max(L.h - 1, 0));
         unsigned long long q;
         __builtin_memcpy(&q, v.score + L.off + (int64_t)yc * L.w + oxc, 8);
-        rows[r] = (y >= 3 && y < L.h - 3) ? (q & colmask) : 0ull;
+        rows.r[r] = (y >= 3 && y < L.h - 3) ? (q & colmask) : 0ull;
     }
+    return rows;
+}
+__device__ __forceinline__ void window_store(const Window &w, const WindowRows &rows)
+{
 #pragma unroll
     for (int r = 0; r < kWinSide; ++r) {
-        *reinterpret_cast<uint32_t *>(w.cells + r * kWinRow) = (uint32_t)rows[r];
-        *reinterpret_cast<uint32_t *>(w.cells + r * kWinRow + 4) = (uint32_t)(rows[r] >> 32);
+        *reinterpret_cast<uint32_t *>(w.cells + r * kWinRow) = (uint32_t)rows.r[r];
+        *reinterpret_cast<uint32_t *>(w.cells + r * kWinRow + 4) = (uint32_t)(rows.r[r] >> 32);
     }
 }
 
@@ -404,22 +451,23 @@ __device__ __forceinline__ void apply_asked(const PairView &v, int layer_above, 
     }
 }
 
-// AgastDetector5_8::cornerScore from b = 0 (agast5_8_nms.cc:42; brisk.cpp:1696-1703): 5 contiguous of the 8 neighbours
-__device__ __forceinline__ int score_5_8(const PairView &v, int x, int y)
+// AgastDetector5_8::cornerScore from b = 0 (agast5_8_nms.cc:42; brisk.cpp:1696-1703): 5 contiguous of the 8 neighbours,
+// on a 5x5 image block held in registers (rows py-2 .. py+2, bytes = columns px-2 ..): the score at (px + ax, py + ay),
+// neighbours in init_pattern order (agast5_8.h:66-76).  For a candidate, which lies at least 3 pixels inside the layer,
+// none of the nine positions asked for touches the 2-pixel border where BriskLayer::getAgastScore_5_8 returns 0.
+__device__ __forceinline__ int score_5_8_block(const unsigned long long (&im)[5], int ax, int ay)
 {
-    const DetLayer &L = v.g->L[0];
-    if (x < 2 || y < 2 || x >= L.w - 2 || y >= L.h - 2) return 0;
-    const uint8_t *t = v.img + L.off + (int64_t)y * L.w + x;
-    const int c = t[0], w = L.w;
+    auto at = [&](int dx, int dy) { return (int)((im[ay + dy + 2] >> (8 * (ax + dx + 2))) & 0xff); };
+    const int c = at(0, 0);
     int d[8];
-    d[0] = t[-1] - c;  // init_pattern order (agast5_8.h:66-76)
-    d[1] = t[-w - 1] - c;
-    d[2] = t[-w] - c;
-    d[3] = t[-w + 1] - c;
-    d[4] = t[1] - c;
-    d[5] = t[w + 1] - c;
-    d[6] = t[w] - c;
-    d[7] = t[w - 1] - c;
+    d[0] = at(-1, 0) - c;
+    d[1] = at(-1, -1) - c;
+    d[2] = at(0, -1) - c;
+    d[3] = at(1, -1) - c;
+    d[4] = at(1, 0) - c;
+    d[5] = at(1, 1) - c;
+    d[6] = at(0, 1) - c;
+    d[7] = at(-1, 1) - c;
     int vb = -256, vd = -256;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -581,31 +629,11 @@ __device__ __forceinline__ float refine1d(int variant, float s_05, float s0, flo
     return ret_val;
 }
 
-template <bool MARK>
-__device__ __forceinline__ float patch_subpixel(const PairView &v, int layer, int x, int y, float &dx, float &dy)
-{
-    int s[9];
-    s[0] = score_at<MARK>(v, layer, x - 1, y - 1);
-    s[1] = score_at<MARK>(v, layer, x - 1, y);
-    s[2] = score_at<MARK>(v, layer, x - 1, y + 1);
-    s[3] = score_at<MARK>(v, layer, x, y - 1);
-    s[4] = score_at<MARK>(v, layer, x, y);
-    s[5] = score_at<MARK>(v, layer, x, y + 1);
-    s[6] = score_at<MARK>(v, layer, x + 1, y - 1);
-    s[7] = score_at<MARK>(v, layer, x + 1, y);
-    s[8] = score_at<MARK>(v, layer, x + 1, y + 1);
-    return subpixel2d(s, dx, dy);
-}
-
-// getScoreMaxAbove (ABOVE, brisk.cpp:1106-1249) / getScoreMaxBelow (:1251-1416)
+// the sampling square of getScoreMaxAbove (ABOVE, brisk.cpp:1123-1133) / getScoreMaxBelow (:1269-1281) in the neighbouring layer
 template <bool ABOVE>
-__device__ __forceinline__ float neighbour_layer_max(const PairView &v, Window &win, int layer, int x_layer, int y_layer, int threshold, bool &ismax, float &dx,
-                                                     float &dy)
+__device__ __forceinline__ void walk_square(int layer, int x_layer, int y_layer, float &x_1, float &x1, float &y_1, float &y1)
 {
-    ismax = false;
-    const int nl = ABOVE ? layer + 1 : layer - 1;
     const bool octave = (layer & 1) == 0;
-    float x_1, x1, y_1, y1;
     if (ABOVE) {
         if (octave) {  // double division (:1123-1126)
             x_1 = (float)((double)(float)(4 * x_layer - 1 - 2) / 6.0);
@@ -631,13 +659,33 @@ __device__ __forceinline__ float neighbour_layer_max(const PairView &v, Window &
             y1 = (float)((double)(float)(6 * y_layer + 1 + 3) / 4.0);
         }
     }
+}
+
+// where the walk's window sits: it reaches from (int)x_1 - 1 (patch around max_x = (int)x1 when that equals (int)x_1)
+// to (int)x1 + 1 <= (int)x_1 + 3: five cells; the window holds six
+template <bool ABOVE>
+__device__ __forceinline__ void window_place(Window &win, int layer, int x_layer, int y_layer)
+{
+    float x_1, x1, y_1, y1;
+    walk_square<ABOVE>(layer, x_layer, y_layer, x_1, x1, y_1, y1);
+    win.ox = (int)x_1 - 1;
+    win.oy = (int)y_1 - 1;
+    win.layer = ABOVE ? layer + 1 : layer - 1;
+    win.asked = 0;
+    win.escaped = false;
+}
+
+// getScoreMaxAbove (ABOVE, brisk.cpp:1106-1249) / getScoreMaxBelow (:1251-1416); the window is in place and filled
+template <bool ABOVE>
+__device__ __forceinline__ float neighbour_layer_max(const PairView &v, Window &win, int layer, int x_layer, int y_layer, int threshold, bool &ismax, float &dx,
+                                                     float &dy)
+{
+    ismax = false;
+    const bool octave = (layer & 1) == 0;
+    float x_1, x1, y_1, y1;
+    walk_square<ABOVE>(layer, x_layer, y_layer, x_1, x1, y_1, y1);
     const float thr = (float)threshold;
     const int xa = (int)(x_1 + 1), xb = (int)x1, ya = (int)(y_1 + 1), yb = (int)y1;
-    win.ox = (int)x_1 - 1;  // the walk reaches from (int)x_1 - 1 (patch around max_x = (int)x1 when that equals (int)x_1)
-    win.oy = (int)y_1 - 1;  // to (int)x1 + 1 <= (int)x_1 + 3: five cells; the window holds six
-    win.layer = nl;
-    win.asked = 0;
-    window_load(v, win);
     auto S = [&](int x, int y) { return window_at<ABOVE>(v, win, x, y); };  // getAgastScore(int, int, 1)
     auto Q = [&](int x, int y) { return window_at<false>(v, win, x, y); };  // same, for the layer below (no bookkeeping)
     auto F = [&](float xf, float yf) {                                      // getAgastScore(float, float, 1): bilinear through uint8_t
@@ -790,38 +838,65 @@ __device__ __forceinline__ Refined refine_maximum(const PairView &v, uint8_t *ld
     out.asked = 0;
     out.ox = out.oy = 0;
     out.escaped = false;
-    Window win;
-    win.cells = lds_cells;
-    win.escaped = false;
     const bool single = g.n_layers == 1, last = layer == g.n_layers - 1, octave = (layer & 1) == 0;
-    const int center = score_at<false>(v, layer, px, py);
+    // Everything the refinement reads, requested at once (the walks are chains of data-dependent early exits: fetched
+    // step by step, each would pay a memory latency): the windows of the two neighbouring layers, the candidate's own
+    // 3x3 patch -- its centre is the candidate's score -- and, on layer 0, the 5x5 image block behind the 5/8 scores.
+    // A candidate lies at least 3 pixels inside its layer, so these row segments start inside it (the bytes that run
+    // past a row's end stay inside the padded plane and are not used).
+    Window wa, wb;
+    wa.cells = lds_cells;
+    wb.cells = lds_cells + kWinBytes;
+    WindowRows ra, rb;
+    if (!last) {
+        window_place<true>(wa, layer, px, py);
+        ra = window_fetch(v, wa);
+    }
+    if (layer > 0) {
+        window_place<false>(wb, layer, px, py);
+        rb = window_fetch(v, wb);
+    }
+    unsigned long long own[3], im[5];
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) own[dy + 1] = load8(v.score + L.off + (int64_t)(py + dy) * L.w + px - 1);
+    const bool guess_below = layer == 0 && !single;
+    if (guess_below) {
+#pragma unroll
+        for (int dy = -2; dy <= 2; ++dy) im[dy + 2] = load8(v.img + L.off + (int64_t)(py + dy) * L.w + px - 2);
+    }
+    if (!last) window_store(wa, ra);
+    if (layer > 0) window_store(wb, rb);
+    const int center = (int)((own[1] >> 8) & 0xff);
     bool ismax = true;
     float max_above = 0.f, max_below = 0.f;
     float delta_x_above = 0.f, delta_y_above = 0.f, delta_x_below = 0.f, delta_y_below = 0.f, delta_x_layer, delta_y_layer;
     if (!last) {  // refine3D: getScoreMaxAbove first (:945-950)
-        max_above = neighbour_layer_max<true>(v, win, layer, px, py, center, ismax, delta_x_above, delta_y_above);
-        out.asked = win.asked;
-        out.ox = win.ox;
-        out.oy = win.oy;
-        out.escaped = win.escaped;
+        max_above = neighbour_layer_max<true>(v, wa, layer, px, py, center, ismax, delta_x_above, delta_y_above);
+        out.asked = wa.asked;
+        out.ox = wa.ox;
+        out.oy = wa.oy;
+        out.escaped = wa.escaped;
         if (!ismax) return out;
     }
     if (layer > 0) {  // getScoreMaxBelow: the last layer (:651-657), octaves above 0 (:991-996), intra layers (:1049-1053)
-        max_below = neighbour_layer_max<false>(v, win, layer, px, py, center, ismax, delta_x_below, delta_y_below);
-        out.escaped |= win.escaped;
+        max_below = neighbour_layer_max<false>(v, wb, layer, px, py, center, ismax, delta_x_below, delta_y_below);
+        out.escaped |= wb.escaped;
         if (!ismax) return out;
     } else if (!single) {  // layer 0: guess the missing layer below with the 5/8 mask (:959-989)
         int s[9];
         int mb = 0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            s[k] = score_5_8(v, px + k / 3 - 1, py + k % 3 - 1);
+            s[k] = score_5_8_block(im, k / 3 - 1, k % 3 - 1);
             mb = max(mb, s[k]);
         }
         (void)subpixel2d(s, delta_x_below, delta_y_below);
         max_below = (float)mb;
     }
-    const float max_layer = patch_subpixel<false>(v, layer, px, py, delta_x_layer, delta_y_layer);
+    int own_patch[9];  // s_0_0, s_0_1, s_0_2, s_1_0, ... (first index x): getAgastScore(int, int, 1) on the own layer (:1685-1694)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) own_patch[k] = (int)((own[k % 3] >> (8 * (k / 3))) & 0xff);
+    const float max_layer = subpixel2d(own_patch, delta_x_layer, delta_y_layer);
     out.reached = true;
     if (single) {  // :609-638
         out.emit = true;
@@ -901,22 +976,44 @@ __device__ __forceinline__ void finish_candidate(const DetArgs &a, const PairVie
 }
 
 // maxima without ties: independent of everything else; ties: refined ahead of their decision
+constexpr int kRefineChunk = 1024;  // candidates per workgroup
+
 __global__ __launch_bounds__(kDetThreads) void det_refine_kernel(DetArgs a)
 {
     __shared__ __attribute__((aligned(4))) uint8_t windows[kDetThreads * kWinStride];
-    const int p = blockIdx.y, i = blockIdx.x * kDetThreads + threadIdx.x;
+    __shared__ int todo[kRefineChunk], wave_cnt[4], n_todo;
+    const int p = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
-    if (i >= ls[a.dg->n_layers]) return;
-    const int64_t ci = (int64_t)p * a.cand_cap + i;
-    const uint8_t flag = a.cand_flag[ci];
-    if (flag == kDetNotMax) return;
-    const uint32_t xy = a.cand_xy[ci];
+    const int n = ls[a.dg->n_layers], c0 = blockIdx.x * kRefineChunk;
+    if (c0 >= n) return;
+    // Only a quarter or so of the candidates are maxima or ties: the chunk's ones are gathered first (order does not
+    // matter here), so that the walks below run with full waves.
+    if (threadIdx.x == 0) n_todo = 0;
+    __syncthreads();
+    for (int i0 = c0; i0 < min(n, c0 + kRefineChunk); i0 += kDetThreads) {
+        const int i = i0 + threadIdx.x;
+        const bool take = i < n && a.cand_flag[(int64_t)p * a.cand_cap + i] != kDetNotMax;
+        const unsigned long long m = __ballot(take);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int before = n_todo;
+        for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+        if (take) todo[before + __popcll(m & ((1ull << lane) - 1))] = i;
+        __syncthreads();
+        if (threadIdx.x == 0) n_todo += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
     const PairView v = pair_view(a, p);
-    const int layer = layer_of(ls, a.dg->n_layers, i), x = (int)(xy & 0xffff), y = (int)(xy >> 16);
-    if (flag == kDetMax)
-        finish_candidate<false>(a, v, windows + threadIdx.x * kWinStride, p, i, layer, x, y);
-    else
-        finish_candidate<true>(a, v, windows + threadIdx.x * kWinStride, p, i, layer, x, y);
+    for (int k = threadIdx.x; k < n_todo; k += kDetThreads) {
+        const int i = todo[k];
+        const int64_t ci = (int64_t)p * a.cand_cap + i;
+        const uint32_t xy = a.cand_xy[ci];
+        const int layer = layer_of(ls, a.dg->n_layers, i), x = (int)(xy & 0xffff), y = (int)(xy >> 16);
+        if (a.cand_flag[ci] == kDetMax)
+            finish_candidate<false>(a, v, windows + threadIdx.x * kWinStride, p, i, layer, x, y);
+        else
+            finish_candidate<true>(a, v, windows + threadIdx.x * kWinStride, p, i, layer, x, y);
+    }
 }
 
 // ---- ties
@@ -927,13 +1024,6 @@ __global__ __launch_bounds__(kDetThreads) void det_refine_kernel(DetArgs a)
 struct TieStep {
     bool ready, is_max;
 };
-
-__device__ __forceinline__ unsigned long long load8(const uint8_t *p)
-{
-    unsigned long long q;
-    __builtin_memcpy(&q, p, 8);  // one unaligned 8-byte load
-    return q;
-}
 
 // One bulk load, both answers.  Ready: no undecided tie that precedes this one in raster order could still change a
 // cell it reads -- such a tie matters only through cells of its 3x3 patch that lie in this candidate's 5x5 window AND
@@ -1253,7 +1343,7 @@ int launch_det_keypoints(const DetArgs &a, int64_t *running, void *stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(det_scan_kernel, dim3(a.n_pairs), dim3(kDetThreads), 0, s, a);
     hipLaunchKernelGGL(det_candidates_kernel, dim3((a.g.total_rows + 3) / 4, a.n_pairs), dim3(kDetThreads), 0, s, a);
-    hipLaunchKernelGGL(det_refine_kernel, dim3((a.cand_cap + kDetThreads - 1) / kDetThreads, a.n_pairs), dim3(kDetThreads), 0, s, a);
+    hipLaunchKernelGGL(det_refine_kernel, dim3((a.cand_cap + kRefineChunk - 1) / kRefineChunk, a.n_pairs), dim3(kDetThreads), 0, s, a);
     // ties: layer by layer (a layer's ties read what the maxima of the layer below asked for in it)
     for (int l = 0; l < a.g.n_layers; ++l) {
         int32_t *waiting = a.tie_waiting + (int64_t)l * a.n_pairs;
