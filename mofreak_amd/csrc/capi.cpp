@@ -257,7 +257,7 @@ int run_gather(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, const 
         a.slow_count = gate;
         a.n_pairs_total = n_pairs;
         const int64_t want = (n_items + 3) / 4;
-        const int n_blocks = (int)std::min<int64_t>(want, (int64_t)ctx->n_cus * 8);
+        const int n_blocks = (int)std::min<int64_t>(want, (int64_t)ctx->n_cus * 8);  // 8 workgroups of 4 waves: all a CU can hold at describe_kernel's register count
         const int e = launch_describe(a, n_blocks, ctx->stream);
         if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("describe launch: ") + hipGetErrorString((hipError_t)e));
     }

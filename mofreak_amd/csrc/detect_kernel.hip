@@ -976,7 +976,7 @@ __device__ __forceinline__ void finish_candidate(const DetArgs &a, const PairVie
 }
 
 // maxima without ties: independent of everything else; ties: refined ahead of their decision
-constexpr int kRefineChunk = 1024;  // candidates per workgroup
+constexpr int kRefineChunk = 512;  // candidates per workgroup
 
 __global__ __launch_bounds__(kDetThreads) void det_refine_kernel(DetArgs a)
 {

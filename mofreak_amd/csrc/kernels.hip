@@ -175,6 +175,20 @@ struct WaveScratch {
     uint8_t p19[2][kP19Pad];
 };
 
+// The pair a keypoint belongs to: the last p in [0, n_pairs) with offsets[p] <= g (offsets ascend, offsets[0] <= g).  The
+// wave looks at 64 offsets per step, all steps' loads independent -- a binary search would be a chain of dependent
+// memory round trips in front of everything else the keypoint needs.
+__device__ __forceinline__ int pair_of(const int64_t *offsets, int n_pairs, int64_t g, int lane)
+{
+    int below = 0;
+    for (int b = 0; b < n_pairs; b += 64) {
+        const int i = b + lane;
+        const bool le = i < n_pairs && offsets[min(i, n_pairs - 1)] <= g;
+        below += __popcll(__ballot(le));
+    }
+    return max(below - 1, 0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // describe_kernel: one wavefront per keypoint instance (grid-stride over the chunk's instances).
 // ------------------------------------------------------------------------------------------------
@@ -209,14 +223,7 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a)
             } else {
                 g = a.slow_list[item];
                 out_idx = g;
-                int lo = 0, hi = (int)a.n_pairs_total;  // pair within the whole call; skip keypoints of other chunks
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (a.kp_offsets[mid] <= g)
-                        lo = mid;
-                    else
-                        hi = mid;
-                }
+                const int lo = pair_of(a.kp_offsets, (int)a.n_pairs_total, g, lane);  // pair within the whole call; skip keypoints of other chunks
                 if (lo < a.first_pair || lo >= a.first_pair + a.n_pairs) continue;
                 pair_local = lo - (int)a.first_pair;
             }
@@ -227,15 +234,7 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a)
         } else {
             g = a.item_base + item;
             out_idx = g;
-            int lo = 0, hi = a.n_pairs;  // kp_offsets[first_pair+lo] <= g < kp_offsets[first_pair+hi]
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (a.kp_offsets[a.first_pair + mid] <= g)
-                    lo = mid;
-                else
-                    hi = mid;
-            }
-            pair_local = lo;
+            pair_local = pair_of(a.kp_offsets + a.first_pair, a.n_pairs, g, lane);  // kp_offsets[first_pair+lo] <= g < kp_offsets[first_pair+lo+1]
         }
         const mofreak_keypoint kp = a.kps[g];
         const float kx = kp.x, ky = kp.y, size = kp.size;
