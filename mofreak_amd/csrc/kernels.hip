@@ -204,14 +204,20 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a)
     const int lane = lane_id();
     const int wave_in_block = threadIdx.x >> 6;
     WaveScratch &ws = scratch[wave_in_block];
-    const int64_t n_waves = (int64_t)gridDim.x * 4;
     const int W = a.f.W, H = a.f.H;
 
     // gather path behind the tile kernel: the instances are the binning pass's slow list (device-resident count)
     const int64_t n_slow = a.slow_list ? (int64_t)*a.slow_count : 0;
     const int64_t n_items = a.slow_list ? (a.kp_offsets ? n_slow : n_slow * a.n_pairs) : a.n_items;
 
-    for (int64_t item = (int64_t)blockIdx.x * 4 + wave_in_block; item < n_items; item += n_waves) {
+    // Workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own: every XCD takes one contiguous eighth
+    // of the items, so that the wavefronts in flight behind one L2 work on neighbouring keypoints -- neighbouring rows of
+    // one pair's integral, a band that fits that L2 -- instead of on all pairs at once (launch_describe rounds the grid
+    // up to a multiple of 8).
+    const int xcd = blockIdx.x & 7;
+    const int64_t per_xcd = (n_items + 7) / 8, xcd_end = min(n_items, (xcd + 1) * per_xcd);
+    const int64_t xcd_waves = (int64_t)(gridDim.x >> 3) * 4;
+    for (int64_t item = xcd * per_xcd + (int64_t)(blockIdx.x >> 3) * 4 + wave_in_block; item < xcd_end; item += xcd_waves) {
         // ---- which keypoint of which pair
         int64_t g, out_idx;
         int pair_local;
@@ -512,7 +518,7 @@ int launch_integral(const IntegralArgs &a, void *stream)
 
 int launch_describe(const DescribeArgs &a, int n_blocks, void *stream)
 {
-    hipLaunchKernelGGL(describe_kernel, dim3(n_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(describe_kernel, dim3((n_blocks + 7) & ~7), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 

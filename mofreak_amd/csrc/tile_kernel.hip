@@ -344,8 +344,19 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs a)
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= a.n_kp) return;
     const int key = a.kp_key[g];
-    if (key >= 0 && a.tile_cursor[key] < 0) {
-        a.slow_list[atomicAdd(a.slow_count, 1)] = (int)g;
+    const bool to_slow = key == -2 || (key >= 0 && a.tile_cursor[key] < 0);
+    // the gather path's list: one counter bump per wave, the wave's keypoints in order behind it -- the list stays close
+    // to keypoint order (the order the detector emits: layer, then raster), which is what gives describe_kernel's
+    // neighbouring wavefronts neighbouring rows of the integral
+    const unsigned long long slow_lanes = __ballot(to_slow);
+    if (slow_lanes) {
+        const int first = __ffsll((long long)slow_lanes) - 1;
+        int base = 0;
+        if (lane_id() == first) base = atomicAdd(a.slow_count, __popcll(slow_lanes));
+        base = __shfl(base, first);
+        if (to_slow) a.slow_list[base + __popcll(slow_lanes & ((1ull << lane_id()) - 1))] = (int)g;
+    }
+    if (to_slow) {
     } else if (key >= 0) {
         const int pos = a.tile_start[key] + atomicAdd(&a.tile_cursor[key], 1);
         const mofreak_keypoint kp = a.kps[g];
@@ -356,8 +367,6 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs a)
                    ((uint32_t)scale_index_scalar(a.small, kp.size) << 16);  // :293-295 ROI side / half, FREAK scale index
         s.g = (int)g;
         a.sorted_kp[pos] = s;
-    } else if (key == -2) {
-        a.slow_list[atomicAdd(a.slow_count, 1)] = (int)g;
     } else {
         // erased: zero descriptor, valid = 0, in every pair that lists this keypoint
         const int reps = a.kp_offsets ? 1 : a.n_pairs;

@@ -1,0 +1,37 @@
+"""Times the keypoint detector (and, with `describe`, the descriptors behind it) on 1920x1080 moving-object frame pairs.
+
+usage: python mofreak_amd/tools/detector_probe.py [pairs_per_call=32] [calls=6] [describe]
+The command the detector profiles under profiles/ are taken on (mofreak_amd/tools/profile_detector.sh).
+"""
+import sys, os, time, numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import torch
+from mofreak_amd import api, synth
+pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+describe = len(sys.argv) > 3 and sys.argv[3] == "describe"
+W, H = 1920, 1080
+ctx = api.Context()
+distinct = 4
+fr = synth.moving_objects_stack(5 + distinct, W, H)
+cur = torch.from_numpy(np.stack([fr[5 + (p % distinct)] for p in range(pairs)])).cuda()
+prev = torch.from_numpy(np.stack([fr[p % distinct] for p in range(pairs)])).cuda()
+cap = 32768 * pairs
+kps = torch.empty((cap, 3), dtype=torch.float32, device="cuda")
+offs = torch.empty(pairs + 1, dtype=torch.int64, device="cuda")
+desc = torch.empty((cap, 16), dtype=torch.uint8, device="cuda")
+valid = torch.empty(cap, dtype=torch.uint8, device="cuda")
+n = ctx.detect_pairs(cur, prev, W, H, pairs, kps, offs, capacity=cap)
+if describe:
+    ctx.extract_pairs(cur, prev, W, H, pairs, kps, desc, valid, kp_offsets=offs, n_kp=n)
+ctx.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    n = ctx.detect_pairs(cur, prev, W, H, pairs, kps, offs, capacity=cap)
+    if describe:
+        ctx.extract_pairs(cur, prev, W, H, pairs, kps, desc, valid, kp_offsets=offs, n_kp=n)
+ctx.synchronize()
+t1 = time.perf_counter()
+print(f"pairs={pairs} kp/pair={n/pairs:.0f} {'detect+describe' if describe else 'detect'} {pairs*steps/(t1-t0):.0f} pairs/s  {1e3*(t1-t0)/steps:.3f} ms/call")
+sz = kps[:n, 2].cpu().numpy()
+print("size quantiles", np.quantile(sz, [0, .1, .25, .5, .75, .9, 1]).round(1), "frac>14.9", (sz > 14.9).mean())
