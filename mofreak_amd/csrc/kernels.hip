@@ -41,28 +41,43 @@ __global__ __launch_bounds__(256) void band_kernel(IntegralArgs a)
         if (lane < 4) out[lane] = 0;  // physical columns 0..3; column 3 is logical column 0
         const bool aligned = (((uintptr_t)c | (uintptr_t)p) & 3) == 0;
         int carry = 0;
-        for (int x0 = 0; x0 < W; x0 += 256) {
-            const int x = x0 + lane * 4;
-            uint32_t cv = 0, pv = 0;
-            if (aligned && x + 3 < W) {
-                cv = *reinterpret_cast<const uint32_t *>(c + x);
-                pv = *reinterpret_cast<const uint32_t *>(p + x);
-            } else {
+        constexpr int kPre = 8;  // a row in chunks of 8 steps of 256 pixels: the chunk's loads are requested together
+        for (int xc = 0; xc < W; xc += 256 * kPre) {
+            uint32_t cvv[kPre], pvv[kPre];
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (x + k < W) {
-                        cv |= (uint32_t)c[x + k] << (8 * k);
-                        pv |= (uint32_t)p[x + k] << (8 * k);
-                    }
+            for (int u = 0; u < kPre; ++u) {
+                const int x = xc + 256 * u + lane * 4;
+                const bool fast = aligned && x + 3 < W;
+                const int xs = fast ? x : 0;  // an address that is always there; the slow lanes fill in below
+                uint32_t cv = aligned ? *reinterpret_cast<const uint32_t *>(c + xs) : 0u;
+                uint32_t pv = aligned ? *reinterpret_cast<const uint32_t *>(p + xs) : 0u;
+                if (!fast) {
+                    cv = 0;
+                    pv = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (x + k < W) {
+                            cv |= (uint32_t)c[x + k] << (8 * k);
+                            pv |= (uint32_t)p[x + k] << (8 * k);
+                        }
+                }
+                cvv[u] = cv;
+                pvv[u] = pv;
             }
-            const int p0 = absdiff_u8(cv, pv, 0);
-            const int p1 = p0 + absdiff_u8(cv, pv, 1);
-            const int p2 = p1 + absdiff_u8(cv, pv, 2);
-            const int p3 = p2 + absdiff_u8(cv, pv, 3);
-            const int incl = wave_inclusive_scan(p3);
-            const int base = carry + incl - p3;
-            if (x < W) *reinterpret_cast<int4 *>(out + x + 4) = make_int4(base + p0, base + p1, base + p2, base + p3);
-            carry += __shfl(incl, 63);
+#pragma unroll
+            for (int u = 0; u < kPre; ++u) {
+                const int x = xc + 256 * u + lane * 4;
+                if (xc + 256 * u >= W) break;  // wave-uniform
+                const uint32_t cv = cvv[u], pv = pvv[u];
+                const int p0 = absdiff_u8(cv, pv, 0);
+                const int p1 = p0 + absdiff_u8(cv, pv, 1);
+                const int p2 = p1 + absdiff_u8(cv, pv, 2);
+                const int p3 = p2 + absdiff_u8(cv, pv, 3);
+                const int incl = wave_inclusive_scan(p3);
+                const int base = carry + incl - p3;
+                if (x < W) *reinterpret_cast<int4 *>(out + x + 4) = make_int4(base + p0, base + p1, base + p2, base + p3);
+                carry += __shfl(incl, 63);
+            }
         }
     }
     __syncthreads();
@@ -94,10 +109,16 @@ __global__ __launch_bounds__(256) void band_scan_kernel(int32_t *band_totals, in
     if (c >= pitch) return;
     int32_t *t = band_totals + (int64_t)blockIdx.y * n_bands * pitch + c;
     int acc = 0;
-    for (int b = 0; b < n_bands; ++b) {
-        const int v = t[(int64_t)b * pitch];
-        t[(int64_t)b * pitch] = acc;
-        acc += v;
+    constexpr int kPre = 16;  // bands whose totals are requested together
+    for (int b0 = 0; b0 < n_bands; b0 += kPre) {
+        int v[kPre];
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) v[u] = b0 + u < n_bands ? t[(int64_t)(b0 + u) * pitch] : 0;
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            if (b0 + u < n_bands) t[(int64_t)(b0 + u) * pitch] = acc;
+            acc += v[u];
+        }
     }
 }
 
