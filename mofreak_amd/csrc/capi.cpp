@@ -37,7 +37,7 @@ struct mofreak_ctx {
     int32_t *d_status = nullptr;
     // workspace (grown on demand, never shrunk)
     DeviceBuffer integral, band_totals, scratch_desc, scratch_valid, compact_offsets, stage[6], offsets_dev;
-    DeviceBuffer kp_key, sorted_idx, slow_list, tile_start, tile_cursor, slow_count, tile_lmin, tile_lmax;  // keypoint binning
+    DeviceBuffer kp_key, sorted_idx, slow_list, slow_count;  // keypoint binning (slow_count: all its counters, BinArgs)
     DeviceBuffer bow_counts, bow_expanded;
     // keypoint detector workspace
     DeviceBuffer det_img, det_score, det_touch, det_status, det_rows, det_cand_xy, det_cand_flag, det_cand_emit, det_cand_spec, det_cand_asked, det_cand_win, det_cand_res, det_layer_start,
@@ -295,11 +295,12 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
         if ((rc = ensure(ctx, ctx->kp_key, (size_t)n_kp * 4))) return rc;
         if ((rc = ensure(ctx, ctx->sorted_idx, (size_t)n_kp * sizeof(SortedKp)))) return rc;
         if ((rc = ensure(ctx, ctx->slow_list, (size_t)n_kp * 4))) return rc;
-        if ((rc = ensure(ctx, ctx->tile_start, (size_t)(n_keys + 1) * 4))) return rc;
-        if ((rc = ensure(ctx, ctx->tile_cursor, (size_t)n_keys * 4))) return rc;
-        if ((rc = ensure(ctx, ctx->tile_lmin, (size_t)n_keys * 4))) return rc;
-        if ((rc = ensure(ctx, ctx->tile_lmax, (size_t)n_keys * 4))) return rc;
-        if ((rc = ensure(ctx, ctx->slow_count, 256))) return rc;
+        // every counter of the binning pass in one buffer (one fill clears them): the gather path's count and the largest
+        // pattern size on a 64-byte line each, then per key the population / start, the scatter cursor and the smallest
+        // (stored complemented, so that it too starts from zero) and largest ROI side
+        const size_t key_pad = ((size_t)n_keys + 1 + 15) & ~(size_t)15;
+        if ((rc = ensure(ctx, ctx->slow_count, (kBinHeaderInts + 4 * key_pad) * sizeof(int32_t)))) return rc;
+        int32_t *bin_base = static_cast<int32_t *>(ctx->slow_count.ptr);
         BinArgs b;
         b.kps = kps;
         b.kp_offsets = d_offsets;
@@ -312,14 +313,15 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
         b.force_slow = 0;
         b.small = ctx->d_small;
         b.kp_key = static_cast<int32_t *>(ctx->kp_key.ptr);
-        b.tile_start = static_cast<int32_t *>(ctx->tile_start.ptr);
-        b.tile_cursor = static_cast<int32_t *>(ctx->tile_cursor.ptr);
-        b.tile_lmin = static_cast<uint32_t *>(ctx->tile_lmin.ptr);
-        b.tile_lmax = static_cast<uint32_t *>(ctx->tile_lmax.ptr);
+        b.tile_start = bin_base + kBinHeaderInts;
+        b.tile_cursor = b.tile_start + key_pad;
+        b.tile_lmin_c = reinterpret_cast<uint32_t *>(b.tile_cursor + key_pad);
+        b.tile_lmax = b.tile_lmin_c + key_pad;
+        b.counter_bytes = (kBinHeaderInts + 4 * key_pad) * sizeof(int32_t);
         b.sorted_kp = static_cast<SortedKp *>(ctx->sorted_idx.ptr);
         b.slow_list = static_cast<int32_t *>(ctx->slow_list.ptr);
-        b.slow_count = static_cast<int32_t *>(ctx->slow_count.ptr);
-        b.max_ps = static_cast<int32_t *>(ctx->slow_count.ptr) + 16;  // same 256-byte buffer, its own 64-byte line
+        b.slow_count = bin_base;
+        b.max_ps = bin_base + 16;  // its own 64-byte line
         b.out_desc = out_desc;
         b.out_valid = out_valid;
         b.out_info = out_info;
@@ -360,13 +362,13 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
             t.kp_offsets = d_offsets;
             t.n_kp = n_kp;
             // CSR: bins are per (pair, tile); shared list: per tile, outputs offset by the pair
-            t.tile_start = static_cast<const int32_t *>(ctx->tile_start.ptr) + (d_offsets ? (int64_t)p0 * tiles_x * tiles_y : 0);
+            t.tile_start = b.tile_start + (d_offsets ? (int64_t)p0 * tiles_x * tiles_y : 0);
             t.sorted_kp = static_cast<const SortedKp *>(ctx->sorted_idx.ptr);
-            t.max_ps = static_cast<const int32_t *>(ctx->slow_count.ptr) + 16;
+            t.max_ps = b.max_ps;
             t.status = ctx->d_status;
             t.out_items = d_offsets ? n_kp : (int64_t)np * n_kp;
-            t.tile_lmin = static_cast<const uint32_t *>(ctx->tile_lmin.ptr) + (d_offsets ? (int64_t)p0 * tiles_x * tiles_y : 0);
-            t.tile_lmax = static_cast<const uint32_t *>(ctx->tile_lmax.ptr) + (d_offsets ? (int64_t)p0 * tiles_x * tiles_y : 0);
+            t.tile_lmin_c = b.tile_lmin_c + (d_offsets ? (int64_t)p0 * tiles_x * tiles_y : 0);
+            t.tile_lmax = b.tile_lmax + (d_offsets ? (int64_t)p0 * tiles_x * tiles_y : 0);
             t.out_desc = d_offsets ? out_desc : out_desc + (int64_t)p0 * n_kp * 16;
             t.out_valid = d_offsets ? out_valid : out_valid + (int64_t)p0 * n_kp;
             t.stamps = ctx->d_stamps;
@@ -654,10 +656,6 @@ void mofreak_destroy(mofreak_ctx *ctx)
     release(ctx->kp_key);
     release(ctx->sorted_idx);
     release(ctx->slow_list);
-    release(ctx->tile_start);
-    release(ctx->tile_cursor);
-    release(ctx->tile_lmin);
-    release(ctx->tile_lmax);
     release(ctx->slow_count);
     release(ctx->bow_counts);
     release(ctx->bow_expanded);

@@ -47,6 +47,8 @@ struct IntegralArgs {
     int32_t n_pairs;
 };
 
+constexpr int kBinHeaderInts = 64;  // slow_count at int 0, max_ps at int 16 of the binning pass's counter buffer
+
 struct DescribeArgs {
     FrameArgs f;               // cur/prev point at the first pair of the chunk
     const int32_t *integral;   // chunk-local
@@ -95,8 +97,9 @@ struct BinArgs {
     int32_t *kp_key;            // [n_kp] key >= 0, -1 erased, -2 slow
     int32_t *tile_start;        // [n_keys + 1] counts, then exclusive starts
     int32_t *tile_cursor;       // [n_keys]
-    uint32_t *tile_lmin;        // [n_keys] smallest / largest ROI side among the tile's keypoints: equal in the usual
-    uint32_t *tile_lmax;        // case, and then the tile kernel can fetch its sample table before it has seen a keypoint
+    uint32_t *tile_lmin_c;      // [n_keys] smallest (as its complement ~L) / largest ROI side among the tile's keypoints: equal in
+    uint32_t *tile_lmax;        // the usual case, and then the tile kernel can fetch its sample table before it has seen a keypoint
+    size_t counter_bytes;       // slow_count .. the end of tile_lmax are one buffer (kBinHeaderInts in front of tile_start): one fill
     SortedKp *sorted_kp;        // [n_kp] keypoints grouped by key
     int32_t *slow_list;         // [n_kp]
     int32_t *slow_count;        // [1]
@@ -133,7 +136,7 @@ struct TileArgs {
     const int64_t *kp_offsets;  // nullptr: shared list (tile lists are the same for every pair)
     int64_t n_kp;
     const int32_t *tile_start;
-    const uint32_t *tile_lmin, *tile_lmax;
+    const uint32_t *tile_lmin_c, *tile_lmax;  // smallest ROI side stored complemented (BinArgs)
     const SortedKp *sorted_kp;
     const int32_t *max_ps;      // device word written by the binning pass (see BinArgs)
     int32_t *status;            // device status word (debug builds: bit 6 = an access left its bounds)

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(BinArgs a)
             key = (int)k64;
             tile_ps = ps;
             atomicAdd(&a.tile_start[key], 1);
-            atomicMin(&a.tile_lmin[key], (uint32_t)L);
+            atomicMax(&a.tile_lmin_c[key], ~(uint32_t)L);
             atomicMax(&a.tile_lmax[key], (uint32_t)L);
         } else {
             key = -2;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     uint32_t *s_roi = reinterpret_cast<uint32_t *>(lds + kOffDirs);  // stage 1 only: where a keypoint's ROI starts in the staged rows
     const bool one_batch = n_tile_kp <= kBatch;
     // The binning pass recorded the smallest and largest ROI side of the tile: equal in the usual case.
-    const int tile_L = (int)a.tile_lmin[key];
+    const int tile_L = (int)~a.tile_lmin_c[key];
     const bool uniform = tile_L == (int)a.tile_lmax[key];
 
     auto make_records = [&](int b0, int nb) {
@@ -1024,17 +1024,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
 int launch_bin(const BinArgs &a, void *stream)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(a.tile_start, 0, (size_t)(a.n_keys + 1) * sizeof(int32_t), s);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(a.tile_cursor, 0, (size_t)a.n_keys * sizeof(int32_t), s);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(a.tile_lmin, 0xff, (size_t)a.n_keys * sizeof(uint32_t), s);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(a.tile_lmax, 0, (size_t)a.n_keys * sizeof(uint32_t), s);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(a.slow_count, 0, sizeof(int32_t), s);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(a.max_ps, 0, sizeof(int32_t), s);
+    hipError_t e = hipMemsetAsync(a.slow_count, 0, a.counter_bytes, s);  // all counters of the pass (BinArgs)
     if (e != hipSuccess) return (int)e;
     const int blocks = (int)((a.n_kp + 255) / 256);
     if (blocks > 0) hipLaunchKernelGGL(bin_count_kernel, dim3(blocks), dim3(256), 0, s, a);
