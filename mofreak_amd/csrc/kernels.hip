@@ -9,6 +9,8 @@
 //                                                 difference image (:427-428, :453-456) and the Motion
 //                                                 Interchange Pattern bytes (:460 -> :288-325 -> :46-99)
 //   compact_*                                     the stable "erase + push_back" of :436-483
+#include <algorithm>
+
 #include "device_helpers.h"
 
 namespace mofreak {
@@ -26,7 +28,10 @@ __global__ __launch_bounds__(256) void band_kernel(IntegralArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t rp[];  // [kBandRows][pitch] row-prefix sums
     if (a.gate != nullptr && *a.gate == 0) return;  // nothing was left to the gather path
-    const int band = blockIdx.x, pair = blockIdx.y;
+    // a bounded grid walks the (pair, band) items: when the gate is shut -- dense grids of small keypoints -- only a few
+    // thousand workgroups come and go instead of one per band
+    for (int item = blockIdx.x; item < a.n_bands * a.n_pairs; item += gridDim.x) {
+    const int band = item % a.n_bands, pair = item / a.n_bands;
     const int W = a.f.W, pitch = a.pitch;
     const int y0 = band * kBandRows;
     const int rows = min(kBandRows, a.f.H - y0);
@@ -99,6 +104,8 @@ __global__ __launch_bounds__(256) void band_kernel(IntegralArgs a)
             if (FINAL) *reinterpret_cast<int4 *>(integ + (int64_t)(y0 + r + 1) * pitch + c4) = acc;
         }
         if (!FINAL) *reinterpret_cast<int4 *>(a.band_totals + bt + c4) = acc;
+    }
+    __syncthreads();  // the next item reuses the row-prefix buffer
     }
 }
 
@@ -524,7 +531,7 @@ __global__ __launch_bounds__(256) void compact_scatter_kernel(CompactArgs a)
 int launch_integral(const IntegralArgs &a, void *stream)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid(a.n_bands, a.n_pairs);
+    const dim3 grid((unsigned)std::min<int64_t>((int64_t)a.n_bands * a.n_pairs, 4096));
     const size_t lds = (size_t)kBandRows * a.pitch * sizeof(int32_t);
     if (lds > 64 * 1024) {  // more than the default dynamic-LDS limit: opt in (a CU has 160 KiB)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&band_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
