@@ -1132,7 +1132,11 @@ __device__ __forceinline__ void tie_apply(const DetArgs &a, const PairView &v, c
 // so two of them never need each other's outcome, and a status byte changes once, from pending to final: whoever reads
 // the old value merely waits); the others go on the pair's waiting list.
 constexpr int kTieThreads = 512, kTieGroups = 8;
+#ifdef MOFREAK_DEBUG_BOUNDS
+constexpr int kDetWaitCap = 8;  // the debug build overflows the list on every tie-heavy image: the scanning fallback gets tested
+#else
 constexpr int kDetWaitCap = 4096;  // waiting ties per pair and layer the chain kernel takes from a list (more: it scans the layer)
+#endif
 
 __global__ __launch_bounds__(kTieThreads) void det_tie_first_kernel(DetArgs a, int layer, int32_t *waiting)
 {

@@ -1,6 +1,9 @@
 """Parity of the HIP keypoint detector (mofreak_amd/csrc/detect_kernel.hip) with the CPU oracle
 (oracle/brisk_oracle.c): pyramid bytes, dense corner scores, and the keypoint list -- coordinates, size, response,
 layer AND order, all bit-exact -- through the C ABI."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -276,3 +279,31 @@ def test_other_frame_gaps(native_lib, oracle):
         assert got.tobytes() == want.tobytes()
         assert want["frame_number"].min() == gap - 1
         c.close()
+
+
+def test_tie_chains_when_the_waiting_list_overflows():
+    """det_tie_chain_kernel takes the ties that were not ready at first sight from a list of 4096 per pair and layer and
+    scans the whole layer when the list overflows.  The debug library (libmofreak_hip_debug.so) is the same source with
+    a list of 8, so tie-heavy images take the scanning path on every layer: same keypoints as the oracle."""
+    import subprocess
+    from mofreak_amd import build
+    if not os.path.exists(build.DEBUG_LIB_PATH):
+        build.build_native(debug=True)
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import mofreak_amd as M
+import test_detector_gpu as T
+assert M.api.load().mofreak_build_flags() == 1, "not the debug build"
+with M.Context(0) as ctx:
+    for seed, levels, block, thr in ((1, 4, 3, 30), (5, 4, 1, 30), (7, 3, 2, 25)):
+        img = T._quantised_noise(seed, 300, 400, levels, block)
+        kps, offs, resp, layer = ctx.detect_pairs_host(img, None, thr, 3)
+        T._assert_same_keypoints((kps, resp, layer), T._oracle_keypoints(img, thr, 3), "seed %%d" %% seed)
+        assert len(kps) > 100
+print("overflow path ok")
+""" % (os.path.dirname(here), here)
+    env = dict(os.environ, MOFREAK_HIP_LIBRARY=build.DEBUG_LIB_PATH)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "overflow path ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
