@@ -923,6 +923,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                     if (osub == 0 && oq <= last) s_dirs[kbase + oq] = make_int2(direction0, direction1);
                     wave_lds_sync();  // the next group overwrites the box means
                 }
+                TILE_STAMP(5);
                 // thetas of all the wave's keypoints in one go: lane = keypoint (group lane / 4, slot lane % 4)
                 {
                     const int kp = (wave + kTileWaves * (lane >> 2)) * kGroup + (lane & 3);
@@ -935,6 +936,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                     }
                     wave_lds_sync();  // pass B reads the thetas
                 }
+                TILE_STAMP(6);
             } else if (a.out_info) {
                 for (int kbase = wave * kGroup; kbase < nb; kbase += kGroup * kTileWaves)
                     if (lane < min(kGroup, nb - kbase))
@@ -1010,7 +1012,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             }
         }
     }
-    TILE_STAMP(5);
+    TILE_STAMP(7);
 #ifdef MOFREAK_DEBUG_BOUNDS
     if (tid == 0 && g_tile_oob) atomicOr(a.status, 64);  // mofreak_check_status reports it
 #endif

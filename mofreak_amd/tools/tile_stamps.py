@@ -16,7 +16,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 
 import numpy as np  # noqa: E402
 
-PHASES = ["stage0 gray tiles", "stage1 MIP", "stage2 row pass", "stage2 column sums", "stage2 column carries", "stage3 FREAK"]
+PHASES = ["stage0 gray tiles", "stage1 MIP", "stage2 row pass", "stage2 column sums", "stage2 column carries", "stage3 FREAK setup + pass A (wave 0)",
+          "stage3 thetas", "stage3 pass B + waiting for the other waves"]
 
 
 def main():
