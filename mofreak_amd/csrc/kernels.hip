@@ -195,10 +195,7 @@ __global__ __launch_bounds__(256) void bgr2gray_kernel(const uint8_t *bgr, int W
     }
 }
 
-constexpr int kRoiLdsSide = 32;  // ROIs up to 32x32 are staged in LDS; larger ones are sampled from global memory
-
 struct WaveScratch {
-    uint8_t roi[2][kRoiLdsSide * kRoiLdsSide];
     ResizeTap taps[2][20];
     uint8_t p19[2][kP19Pad];
 };
@@ -220,7 +217,7 @@ __device__ __forceinline__ int pair_of(const int64_t *offsets, int n_pairs, int6
 // ------------------------------------------------------------------------------------------------
 // describe_kernel: one wavefront per keypoint instance (grid-stride over the chunk's instances).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a)
+__global__ __launch_bounds__(256, 4) void describe_kernel(DescribeArgs a)
 {
     __shared__ __attribute__((aligned(16))) SmallTables st;
     __shared__ __attribute__((aligned(16))) WaveScratch scratch[4];
@@ -245,32 +242,69 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a)
     const int xcd = blockIdx.x & 7;
     const int64_t per_xcd = (n_items + 7) / 8, xcd_end = min(n_items, (xcd + 1) * per_xcd);
     const int64_t xcd_waves = (int64_t)(gridDim.x >> 3) * 4;
-    for (int64_t item = xcd * per_xcd + (int64_t)(blockIdx.x >> 3) * 4 + wave_in_block; item < xcd_end; item += xcd_waves) {
-        // ---- which keypoint of which pair
+    // Which keypoint of which pair an item is takes two dependent memory round trips (list entry -> keypoint record and
+    // pair offsets) before the keypoint's own work can start: they are taken ahead of time -- the list entry two items
+    // ahead, the record one item ahead -- so that a wavefront's chain per keypoint is only the keypoint's own.
+    struct ItemId {
         int64_t g, out_idx;
+        int pair_local;  // -1: the pair is found from kp_offsets (CSR)
+        bool live;
+    };
+    struct ItemKp {
+        mofreak_keypoint kp;
         int pair_local;
+        bool live;
+    };
+    auto item_id = [&](int64_t item) -> ItemId {
+        ItemId r{0, 0, -1, item < xcd_end};
+        if (!r.live) return r;
         if (a.slow_list != nullptr) {
             if (a.kp_offsets == nullptr) {
-                pair_local = (int)(item / n_slow);
-                g = a.slow_list[item - (int64_t)pair_local * n_slow];
-                out_idx = (a.first_pair + pair_local) * a.n_kp + g;
+                r.pair_local = (int)(item / n_slow);
+                r.g = a.slow_list[item - (int64_t)r.pair_local * n_slow];
+                r.out_idx = (a.first_pair + r.pair_local) * a.n_kp + r.g;
             } else {
-                g = a.slow_list[item];
-                out_idx = g;
-                const int lo = pair_of(a.kp_offsets, (int)a.n_pairs_total, g, lane);  // pair within the whole call; skip keypoints of other chunks
-                if (lo < a.first_pair || lo >= a.first_pair + a.n_pairs) continue;
-                pair_local = lo - (int)a.first_pair;
+                r.g = a.slow_list[item];
+                r.out_idx = r.g;
             }
         } else if (a.kp_offsets == nullptr) {
-            pair_local = (int)((uint64_t)item / (uint64_t)a.n_kp);
-            g = item - (int64_t)pair_local * a.n_kp;
-            out_idx = a.item_base + item;
+            r.pair_local = (int)((uint64_t)item / (uint64_t)a.n_kp);
+            r.g = item - (int64_t)r.pair_local * a.n_kp;
+            r.out_idx = a.item_base + item;
         } else {
-            g = a.item_base + item;
-            out_idx = g;
-            pair_local = pair_of(a.kp_offsets + a.first_pair, a.n_pairs, g, lane);  // kp_offsets[first_pair+lo] <= g < kp_offsets[first_pair+lo+1]
+            r.g = a.item_base + item;
+            r.out_idx = r.g;
         }
-        const mofreak_keypoint kp = a.kps[g];
+        return r;
+    };
+    auto item_kp = [&](const ItemId &id) -> ItemKp {
+        ItemKp r{mofreak_keypoint{0.f, 0.f, 0.f}, id.pair_local, id.live};
+        if (!id.live) return r;
+        r.kp = a.kps[id.g];
+        if (id.pair_local < 0) {
+            if (a.slow_list != nullptr) {
+                const int lo = pair_of(a.kp_offsets, (int)a.n_pairs_total, id.g, lane);  // pair within the whole call
+                r.live = lo >= a.first_pair && lo < a.first_pair + a.n_pairs;              // keypoints of other chunks: skipped
+                r.pair_local = lo - (int)a.first_pair;
+            } else {
+                r.pair_local = pair_of(a.kp_offsets + a.first_pair, a.n_pairs, id.g, lane);  // kp_offsets[first_pair+lo] <= g < kp_offsets[first_pair+lo+1]
+            }
+        }
+        return r;
+    };
+    const int64_t item0 = xcd * per_xcd + (int64_t)(blockIdx.x >> 3) * 4 + wave_in_block;
+    ItemId id_next = item_id(item0), id_next2 = item_id(item0 + xcd_waves);
+    ItemKp kp_next = item_kp(id_next);
+    for (int64_t item = item0; item < xcd_end; item += xcd_waves) {
+        const ItemId id = id_next;
+        const ItemKp ik = kp_next;
+        id_next = id_next2;
+        id_next2 = item_id(item + 2 * xcd_waves);
+        kp_next = item_kp(id_next);
+        if (!ik.live) continue;
+        const int64_t out_idx = id.out_idx;
+        const int pair_local = ik.pair_local;
+        const mofreak_keypoint kp = ik.kp;
         const float kx = kp.x, ky = kp.y, size = kp.size;
 
         // ---- DescriptorExtractor::compute + FREAK::computeImpl keypoint filter
@@ -303,6 +337,9 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a)
         }
 
         if (ok) {
+            // the 19 + 19 resize taps of this ROI side: asked for now, parked in LDS when the MIP part gets to them
+            ResizeTap my_tap{0, 0, 0, 0};
+            if (lane < 2 * kPatch) my_tap = a.resize[(int64_t)L * 2 * kPatch + lane];
             // ================= FREAK on the difference image (through its integral)
             const int32_t *integ = a.integral + (int64_t)pair_local * (H + 1) * a.pitch;
             const PatternPoint *lut_scale = a.lut + (int64_t)idx * kNbOrientation * kNbPoints;
@@ -339,41 +376,44 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a)
             }
 
             // ================= MIP on (current, previous) gray frames
-            {
-                const ResizeTap *tab = a.resize + (int64_t)L * 2 * kPatch;
-                if (lane < 2 * kPatch) ws.taps[lane / kPatch][lane % kPatch] = tab[lane];
-            }
-            const uint8_t *src_c = cur + (int64_t)tl_y * a.f.row_stride + tl_x;
-            const uint8_t *src_p = prev + (int64_t)tl_y * a.f.row_stride + tl_x;
-            const bool staged = L <= kRoiLdsSide;
-            if (staged) {
-                // lanes = (row, column) of a strip of the ROI; 16-wide strips for small ROIs, 32-wide otherwise
-                const int wshift = L <= 16 ? 4 : 5;
-                const int c = lane & ((1 << wshift) - 1), r0 = lane >> wshift, rstep = 64 >> wshift;
-                if (c < L)
-                    for (int r = r0; r < L; r += rstep) {
-                        ws.roi[0][r * L + c] = src_c[(int64_t)r * a.f.row_stride + c];
-                        ws.roi[1][r * L + c] = src_p[(int64_t)r * a.f.row_stride + c];
-                    }
-            }
+            // cv::resize(ROI -> 19x19, INTER_LINEAR) of both frames straight from memory: an output pixel's two taps of a
+            // row are neighbouring bytes (or the same byte at the right edge), so one unaligned 4-byte load per row and
+            // frame brings them; a lane's (up to) six output pixels ask for their loads three pixels (12 loads) at a time.  A
+            // load that would run past the end of its frame row starts up to 3 bytes early instead and is shifted.
+            if (lane < 2 * kPatch) ws.taps[lane / kPatch][lane % kPatch] = my_tap;
             wave_lds_sync();
-            for (int o = lane; o < kPatch * kPatch; o += 64) {
+            constexpr int kMipPasses = (kPatch * kPatch + 63) / 64, kMipHalf = 3;  // output pixels per lane whose loads are in flight together
+#pragma unroll
+            for (int h = 0; h < kMipPasses; h += kMipHalf) {
+            uint32_t qc0[kMipHalf], qc1[kMipHalf], qp0[kMipHalf], qp1[kMipHalf];
+#pragma unroll
+            for (int u = 0; u < kMipHalf; ++u) {
+                const int o = min(lane + 64 * (h + u), kPatch * kPatch - 1);
                 const int dy = o / kPatch, dx = o - dy * kPatch;
                 const ResizeTap tx = ws.taps[0][dx], ty = ws.taps[1][dy];
-                uint8_t oc, op;
-                if (staged) {
-                    const uint8_t *rc0 = ws.roi[0] + ty.ofs * L, *rc1 = ws.roi[0] + ty.ofs1 * L;
-                    const uint8_t *rp0 = ws.roi[1] + ty.ofs * L, *rp1 = ws.roi[1] + ty.ofs1 * L;
-                    oc = resize_px(rc0[tx.ofs], rc0[tx.ofs1], rc1[tx.ofs], rc1[tx.ofs1], tx, ty);
-                    op = resize_px(rp0[tx.ofs], rp0[tx.ofs1], rp1[tx.ofs], rp1[tx.ofs1], tx, ty);
-                } else {
-                    const uint8_t *rc0 = src_c + (int64_t)ty.ofs * a.f.row_stride, *rc1 = src_c + (int64_t)ty.ofs1 * a.f.row_stride;
-                    const uint8_t *rp0 = src_p + (int64_t)ty.ofs * a.f.row_stride, *rp1 = src_p + (int64_t)ty.ofs1 * a.f.row_stride;
-                    oc = resize_px(rc0[tx.ofs], rc0[tx.ofs1], rc1[tx.ofs], rc1[tx.ofs1], tx, ty);
-                    op = resize_px(rp0[tx.ofs], rp0[tx.ofs1], rp1[tx.ofs], rp1[tx.ofs1], tx, ty);
+                const int col = tl_x + tx.ofs, xs = min(col, W - 4);
+                const int64_t r0 = (int64_t)(tl_y + ty.ofs) * a.f.row_stride + xs, r1 = (int64_t)(tl_y + ty.ofs1) * a.f.row_stride + xs;
+                __builtin_memcpy(&qc0[u], cur + r0, 4);
+                __builtin_memcpy(&qc1[u], cur + r1, 4);
+                __builtin_memcpy(&qp0[u], prev + r0, 4);
+                __builtin_memcpy(&qp1[u], prev + r1, 4);
+            }
+#pragma unroll
+            for (int u = 0; u < kMipHalf; ++u) {
+                const int o = lane + 64 * (h + u);
+                const int oc_ = min(o, kPatch * kPatch - 1);
+                const int dy = oc_ / kPatch, dx = oc_ - dy * kPatch;
+                const ResizeTap tx = ws.taps[0][dx], ty = ws.taps[1][dy];
+                const int col = tl_x + tx.ofs;
+                const int sh0 = 8 * (col - min(col, W - 4)), sh1 = sh0 + 8 * (tx.ofs1 - tx.ofs);
+                auto px = [&](uint32_t q0, uint32_t q1) {
+                    return resize_px((int)((q0 >> sh0) & 0xff), (int)((q0 >> sh1) & 0xff), (int)((q1 >> sh0) & 0xff), (int)((q1 >> sh1) & 0xff), tx, ty);
+                };
+                if (o < kPatch * kPatch) {
+                    ws.p19[0][o] = px(qc0[u], qc1[u]);
+                    ws.p19[1][o] = px(qp0[u], qp1[u]);
                 }
-                ws.p19[0][o] = oc;
-                ws.p19[1][o] = op;
+            }
             }
             wave_lds_sync();
             mot = mip_bits(ws.p19[0], ws.p19[1], st.mip_theta);
