@@ -57,6 +57,13 @@ __device__ __forceinline__ PairView pair_view(const DetArgs &a, int p)
 
 __device__ __forceinline__ int avg_u8(int a, int b) { return (a + b + 1) >> 1; }  // _mm_avg_epu8
 
+__device__ __forceinline__ unsigned long long load8(const uint8_t *p)
+{
+    unsigned long long q;
+    __builtin_memcpy(&q, p, 8);  // one unaligned 8-byte load
+    return q;
+}
+
 // ------------------------------------------------------------------ pyramid
 __global__ __launch_bounds__(kDetThreads) void det_diff_kernel(DetArgs a)
 {
@@ -84,38 +91,49 @@ __global__ __launch_bounds__(kDetThreads) void det_diff_kernel(DetArgs a)
     }
 }
 
-// BriskLayer::halfsample (brisk.cpp:1840-1972), one output pixel per thread.
+// BriskLayer::halfsample (brisk.cpp:1840-1972).  One output pixel:
+__device__ __forceinline__ int half_pixel(const uint8_t *u, const uint8_t *l, int c, int hsize, int end)
+{
+    if (c < 16 * end)  // pairs of 16-byte blocks: rounding average of the two vertical rounding averages
+        return avg_u8(avg_u8(u[2 * c], l[2 * c]), avg_u8(u[2 * c + 1], l[2 * c + 1]));
+    if (c < 8 * hsize)  // the odd block: truncating mean of the vertical averages (:1929-1933)
+        return (avg_u8(u[2 * c], l[2 * c]) + avg_u8(u[2 * c + 1], l[2 * c + 1])) / 2;
+    // scalar tail (:1949-1956): columns k and k+1 behind the last whole block, not 2k and 2k+1
+    const int k = c - 8 * hsize, b = 16 * hsize;
+    return (u[b + k] + u[b + k + 1] + l[b + k] + l[b + k + 1]) / 4;
+}
+
+// Four output pixels per thread: inside the main blocks and the odd block (whose extents are multiples of 8 outputs)
+// they come from 8 bytes of each of the two source rows -- two 8-byte loads, one 4-byte store; the tail and the last
+// pixels of a row go one by one.
 __global__ __launch_bounds__(kDetThreads) void det_half_kernel(DetArgs a, int src_l, int dst_l)
 {
     const DetLayer S = a.dg->L[src_l], D = a.dg->L[dst_l];
-    const int c = blockIdx.x * kDetThreads + threadIdx.x, r = blockIdx.y, p = blockIdx.z;
+    const int c = 4 * (blockIdx.x * kDetThreads + threadIdx.x), r = blockIdx.y, p = blockIdx.z;
     if (c >= D.w) return;
     const uint8_t *u = a.img + (int64_t)p * a.dg->plane_bytes + S.off + (int64_t)(2 * r) * S.w, *l = u + S.w;
+    uint8_t *out = a.img + (int64_t)p * a.dg->plane_bytes + D.off + (int64_t)r * D.w + c;
     const int hsize = S.w / 16, end = hsize / 2;
-    int out;
-    if (c < 16 * end) {  // pairs of 16-byte blocks: rounding average of the two vertical rounding averages
-        out = avg_u8(avg_u8(u[2 * c], l[2 * c]), avg_u8(u[2 * c + 1], l[2 * c + 1]));
-    } else if (c < 8 * hsize) {  // the odd block: truncating mean of the vertical averages (:1929-1933)
-        out = (avg_u8(u[2 * c], l[2 * c]) + avg_u8(u[2 * c + 1], l[2 * c + 1])) / 2;
-    } else {  // scalar tail (:1949-1956): columns k and k+1 behind the last whole block, not 2k and 2k+1
-        const int k = c - 8 * hsize, b = 16 * hsize;
-        out = (u[b + k] + u[b + k + 1] + l[b + k] + l[b + k + 1]) / 4;
+    if (c + 4 <= 8 * hsize && c + 4 <= D.w) {
+        const bool main_blocks = c < 16 * end;
+        const unsigned long long qu = load8(u + 2 * c), ql = load8(l + 2 * c);
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v0 = avg_u8((int)((qu >> (16 * k)) & 0xff), (int)((ql >> (16 * k)) & 0xff));
+            const int v1 = avg_u8((int)((qu >> (16 * k + 8)) & 0xff), (int)((ql >> (16 * k + 8)) & 0xff));
+            packed |= (uint32_t)(main_blocks ? avg_u8(v0, v1) : (v0 + v1) / 2) << (8 * k);
+        }
+        __builtin_memcpy(out, &packed, 4);
+        return;
     }
-    a.img[(int64_t)p * a.dg->plane_bytes + D.off + (int64_t)r * D.w + c] = (uint8_t)out;
+    for (int k = 0; k < 4 && c + k < D.w; ++k) out[k] = (uint8_t)half_pixel(u, l, c + k, hsize, end);
 }
 
-// BriskLayer::twothirdsample (brisk.cpp:1974-2065), one output pixel per thread.
-__global__ __launch_bounds__(kDetThreads) void det_twothird_kernel(DetArgs a, int src_l, int dst_l)
+// BriskLayer::twothirdsample (brisk.cpp:1974-2065).  One output pixel of output row r2 (mid = source row 3 * (r2 / 2) + 1,
+// outer = the row above it for the upper output row of the pair, below it for the lower one):
+__device__ __forceinline__ int twothird_pixel(const uint8_t *outer, const uint8_t *mid, int c, int hsize)
 {
-    const DetLayer S = a.dg->L[src_l], D = a.dg->L[dst_l];
-    const int c = blockIdx.x * kDetThreads + threadIdx.x, r2 = blockIdx.y, p = blockIdx.z;
-    if (c >= D.w) return;
-    const int r = r2 >> 1;
-    const uint8_t *base = a.img + (int64_t)p * a.dg->plane_bytes + S.off;
-    const uint8_t *mid = base + (int64_t)(3 * r + 1) * S.w;
-    const uint8_t *outer = (r2 & 1) ? mid + S.w : mid - S.w;  // third row for the lower output row, first for the upper
-    const int hsize = S.w / 15;
-    int out;
     if (c < 10 * hsize) {
         // shuffle masks of :1982-1984: outer column / "middle" column per output byte; the last pair reads 12, not 13
         const int i = c / 10, m = c - 10 * i;
@@ -124,14 +142,60 @@ __global__ __launch_bounds__(kDetThreads) void det_twothird_kernel(DetArgs a, in
         const int x2 = 15 * i + t2, x1 = 15 * i + t1;
         const int v2 = avg_u8(avg_u8(outer[x2], mid[x2]), outer[x2]);
         const int v1 = avg_u8(avg_u8(outer[x1], mid[x1]), outer[x1]);
-        out = avg_u8(avg_u8(v2, v1), v2);
-    } else {  // scalar remainder (:2036-2052)
-        const int k = c - 10 * hsize, j = 15 * hsize + 3 * (k >> 1);
-        const int X2 = outer[j + 1], B2 = mid[j + 1];
-        const int X = (k & 1) ? outer[j + 2] : outer[j], B = (k & 1) ? mid[j + 2] : mid[j];
-        out = ((4 * X + 2 * (X2 + B) + B2) / 9) & 0xff;
+        return avg_u8(avg_u8(v2, v1), v2);
     }
-    a.img[(int64_t)p * a.dg->plane_bytes + D.off + (int64_t)r2 * D.w + c] = (uint8_t)out;
+    // scalar remainder (:2036-2052)
+    const int k = c - 10 * hsize, j = 15 * hsize + 3 * (k >> 1);
+    const int X2 = outer[j + 1], B2 = mid[j + 1];
+    const int X = (k & 1) ? outer[j + 2] : outer[j], B = (k & 1) ? mid[j + 2] : mid[j];
+    return ((4 * X + 2 * (X2 + B) + B2) / 9) & 0xff;
+}
+
+// A thread takes one block of the SSSE3 loop -- 15 source columns of two rows in, 10 bytes out: two 16-byte loads (the
+// 16th byte belongs to the next block or the padded plane and is not used), the vertical step on all 15 columns, the
+// horizontal step per output byte -- or, behind the blocks, one pixel of the scalar remainder.
+__global__ __launch_bounds__(kDetThreads) void det_twothird_kernel(DetArgs a, int src_l, int dst_l)
+{
+    const DetLayer S = a.dg->L[src_l], D = a.dg->L[dst_l];
+    const int t = blockIdx.x * kDetThreads + threadIdx.x, r2 = blockIdx.y, p = blockIdx.z;
+    const int hsize = S.w / 15, rest = D.w - 10 * hsize;  // blocks, then `rest` remainder pixels
+    if (t >= hsize + rest) return;
+    const int r = r2 >> 1;
+    const uint8_t *base = a.img + (int64_t)p * a.dg->plane_bytes + S.off;
+    const uint8_t *mid = base + (int64_t)(3 * r + 1) * S.w;
+    const uint8_t *outer = (r2 & 1) ? mid + S.w : mid - S.w;  // third row for the lower output row, first for the upper
+    uint8_t *out = a.img + (int64_t)p * a.dg->plane_bytes + D.off + (int64_t)r2 * D.w;
+    if (t >= hsize) {
+        const int c = 10 * hsize + (t - hsize);
+        out[c] = (uint8_t)twothird_pixel(outer, mid, c, hsize);
+        return;
+    }
+    unsigned long long o[2], m[2];
+    o[0] = load8(outer + 15 * t);
+    o[1] = load8(outer + 15 * t + 8);
+    m[0] = load8(mid + 15 * t);
+    m[1] = load8(mid + 15 * t + 8);
+    int v[15];  // _mm_avg_epu8(_mm_avg_epu8(outer, mid), outer) per column
+#pragma unroll
+    for (int x = 0; x < 15; ++x) {
+        const int ov = (int)((o[x >> 3] >> (8 * (x & 7))) & 0xff), mv = (int)((m[x >> 3] >> (8 * (x & 7))) & 0xff);
+        v[x] = avg_u8(avg_u8(ov, mv), ov);
+    }
+    constexpr int t2[10] = {0, 2, 3, 5, 6, 8, 9, 11, 12, 14}, t1[10] = {1, 1, 4, 4, 7, 7, 10, 10, 12, 12};  // the shuffle masks of :1982-1984
+    unsigned long long lo = 0;
+    uint32_t hi = 0;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const unsigned long long b = (unsigned long long)avg_u8(avg_u8(v[t2[k]], v[t1[k]]), v[t2[k]]);
+        if (k < 8)
+            lo |= b << (8 * k);
+        else
+            hi |= (uint32_t)b << (8 * (k - 8));
+    }
+    uint8_t *dst = out + 10 * t;
+    __builtin_memcpy(dst, &lo, 8);
+    const uint16_t hi16 = (uint16_t)hi;
+    __builtin_memcpy(dst + 8, &hi16, 2);
 }
 
 // ------------------------------------------------------------------ dense corner scores
@@ -376,13 +440,6 @@ __device__ __forceinline__ int score_at(const PairView &v, int layer, int x, int
 // independent 8-byte loads into the thread's own 48 bytes of LDS.  The walk itself is a chain of data-dependent early
 // exits: on global memory every step would pay a full memory latency.
 constexpr int kWinSide = 6, kWinRow = 8, kWinBytes = 48, kWinStride = 108;  // two windows (above, below) of 6 rows of 8 bytes per thread; 27 dwords apart: neighbouring threads hit different banks
-__device__ __forceinline__ unsigned long long load8(const uint8_t *p)
-{
-    unsigned long long q;
-    __builtin_memcpy(&q, p, 8);  // one unaligned 8-byte load
-    return q;
-}
-
 struct Window {
     uint8_t *cells;
     int ox, oy, layer;
@@ -1321,12 +1378,13 @@ int launch_det_pyramid(const DetArgs &a, void *stream)
     hipLaunchKernelGGL(det_diff_kernel, dim3((g.L[0].w + 4 * kDetThreads - 1) / (4 * kDetThreads), g.L[0].h, a.n_pairs), dim3(kDetThreads), 0, s, a);
     // BriskScaleSpace::constructPyramid (brisk.cpp:572-588): layer 1 = 2/3 of layer 0, layer i >= 2 = half of layer i-2
     for (int l = 1; l < g.n_layers; ++l) {
-        const dim3 grid((g.L[l].w + kDetThreads - 1) / kDetThreads, g.L[l].h, a.n_pairs);
-        if (grid.x == 0 || grid.y == 0) continue;
-        if (l == 1)
-            hipLaunchKernelGGL(det_twothird_kernel, grid, dim3(kDetThreads), 0, s, a, 0, 1);
-        else
-            hipLaunchKernelGGL(det_half_kernel, grid, dim3(kDetThreads), 0, s, a, l - 2, l);
+        if (g.L[l].w == 0 || g.L[l].h == 0) continue;
+        if (l == 1) {  // a thread per 15-column block of the source row pair + one per remainder pixel
+            const int hsize = g.L[0].w / 15, items = hsize + (g.L[1].w - 10 * hsize);
+            hipLaunchKernelGGL(det_twothird_kernel, dim3((items + kDetThreads - 1) / kDetThreads, g.L[l].h, a.n_pairs), dim3(kDetThreads), 0, s, a, 0, 1);
+        } else {  // a thread per four output pixels
+            hipLaunchKernelGGL(det_half_kernel, dim3((g.L[l].w + 4 * kDetThreads - 1) / (4 * kDetThreads), g.L[l].h, a.n_pairs), dim3(kDetThreads), 0, s, a, l - 2, l);
+        }
     }
     return (int)hipGetLastError();
 }
