@@ -67,24 +67,28 @@ __device__ __forceinline__ unsigned long long load8(const uint8_t *p)
 // ------------------------------------------------------------------ pyramid
 __global__ __launch_bounds__(kDetThreads) void det_diff_kernel(DetArgs a)
 {
-    const int p = blockIdx.z, y = blockIdx.y;
-    const int x0 = (blockIdx.x * kDetThreads + threadIdx.x) * 4;
-    const int W = a.dg->L[0].w;
-    if (x0 >= W) return;
+    const int p = blockIdx.y;
+    const int W = a.dg->L[0].w, H = a.dg->L[0].h;
+    const int per_row = (W + 15) / 16, t = blockIdx.x * kDetThreads + threadIdx.x;  // 16-pixel pieces, row after row
+    const int y = t / per_row, x0 = (t - y * per_row) * 16;
+    if (y >= H) return;
     const uint8_t *c = a.f.cur + (int64_t)p * a.f.pair_stride + (int64_t)y * a.f.row_stride + x0;
     const uint8_t *q = a.f.prev ? a.f.prev + (int64_t)p * a.f.pair_stride + (int64_t)y * a.f.row_stride + x0 : nullptr;
     uint8_t *d = a.img + (int64_t)p * a.dg->plane_bytes + a.dg->L[0].off + (int64_t)y * W + x0;
-    // cv::absdiff (MoFREAKUtilities.cpp:413-414), four pixels per thread; one dword each way where everything is aligned
-    const bool wide = x0 + 4 <= W && (((uintptr_t)c | (uintptr_t)d | (q ? (uintptr_t)q : 0)) & 3) == 0;
+    // cv::absdiff (MoFREAKUtilities.cpp:413-414), sixteen pixels per thread; 16 bytes each way where everything is aligned
+    const bool wide = x0 + 16 <= W && (((uintptr_t)c | (uintptr_t)d | (q ? (uintptr_t)q : 0)) & 15) == 0;
     if (wide) {
-        const uint32_t u = *reinterpret_cast<const uint32_t *>(c), v = q ? *reinterpret_cast<const uint32_t *>(q) : 0u;
-        uint32_t r = 0;
+        const uint4 u = *reinterpret_cast<const uint4 *>(c), v = q ? *reinterpret_cast<const uint4 *>(q) : make_uint4(0, 0, 0, 0);
+        auto word = [](uint32_t s, uint32_t t) {
+            uint32_t r = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r |= (uint32_t)absdiff_u8(u, v, k) << (8 * k);
-        *reinterpret_cast<uint32_t *>(d) = r;
+            for (int k = 0; k < 4; ++k) r |= (uint32_t)absdiff_u8(s, t, k) << (8 * k);
+            return r;
+        };
+        *reinterpret_cast<uint4 *>(d) = make_uint4(word(u.x, v.x), word(u.y, v.y), word(u.z, v.z), word(u.w, v.w));
         return;
     }
-    const int n = min(4, W - x0);
+    const int n = min(16, W - x0);
     for (int k = 0; k < n; ++k) {
         const int u = c[k], v = q ? q[k] : 0;
         d[k] = (uint8_t)(u > v ? u - v : v - u);
@@ -1375,7 +1379,8 @@ int launch_det_pyramid(const DetArgs &a, void *stream)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const DetGeom &g = a.g;
-    hipLaunchKernelGGL(det_diff_kernel, dim3((g.L[0].w + 4 * kDetThreads - 1) / (4 * kDetThreads), g.L[0].h, a.n_pairs), dim3(kDetThreads), 0, s, a);
+    if (g.L[0].w > 0 && g.L[0].h > 0)
+        hipLaunchKernelGGL(det_diff_kernel, dim3((unsigned)(((int64_t)((g.L[0].w + 15) / 16) * g.L[0].h + kDetThreads - 1) / kDetThreads), a.n_pairs), dim3(kDetThreads), 0, s, a);
     // BriskScaleSpace::constructPyramid (brisk.cpp:572-588): layer 1 = 2/3 of layer 0, layer i >= 2 = half of layer i-2
     for (int l = 1; l < g.n_layers; ++l) {
         if (g.L[l].w == 0 || g.L[l].h == 0) continue;
