@@ -109,6 +109,23 @@ def test_ties_are_broken_like_the_sequential_reference(ctx, seed, levels, block,
     assert len(want_all) == len(kps)
 
 
+def test_rows_wider_than_one_chunk(ctx):
+    """Layer rows longer than the 2048 pixels the candidate kernel takes per chunk (and than one pyramid block row):
+    keypoints next to the chunk boundary see their neighbours across it."""
+    rng = np.random.default_rng(11)
+    img = _quantised_noise(3, 96, 4400, levels=5, block=2)
+    img[:, 2040:2060] = rng.integers(0, 255, (96, 20), dtype=np.uint8)   # busy columns around x = 2048
+    img[:, 4090:4104] = rng.integers(0, 255, (96, 14), dtype=np.uint8)   # and around the half-resolution layer's (x = 4096)
+    ctx.set_detect_capacity(1 << 20)  # this much noise has more corner candidates than the default reserve
+    try:
+        kps, offs, resp, layer = ctx.detect_pairs_host(img, None, 30, 2)
+    finally:
+        ctx.set_detect_capacity(131072)
+    _assert_same_keypoints((kps, resp, layer), _oracle_keypoints(img, 30, 2), "4400-wide")
+    near = np.abs(kps[:, 0] - 2048) < 6
+    assert near.any(), "no keypoint next to the chunk boundary: the input does not test it"
+
+
 def test_full_hd_pair_and_capacity_errors(ctx):
     fr = synth.moving_objects_stack(6, 1920, 1080)
     d = O.absdiff(fr[5], fr[0])
