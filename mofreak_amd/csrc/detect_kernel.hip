@@ -1243,13 +1243,41 @@ __global__ __launch_bounds__(kTieThreads) void det_tie_chain_kernel(DetArgs a, i
     int passes = 0;
     const long long t_begin = wall_clock64();
 #endif
+    // a thread's first two ties stay in registers between passes (there are rarely more than a few hundred per pair and
+    // layer): a pass is then one round of neighbourhood loads, not list entry -> record -> neighbourhood
+    constexpr int kOwn = 2;
+    TieCand own[kOwn];
+    int own_i[kOwn];
+    bool own_waits[kOwn];
+#pragma unroll
+    for (int j = 0; j < kOwn; ++j) {
+        const int k = threadIdx.x + j * kTieThreads;
+        own_i[j] = k < n_items ? (listed ? list[k] : lo + k) : lo;
+    }
+#pragma unroll
+    for (int j = 0; j < kOwn; ++j) {
+        own[j] = tie_cand(a, cb + own_i[j]);
+        own_waits[j] = threadIdx.x + j * kTieThreads < n_items && own[j].flag == kDetTie;
+    }
     for (;;) {
 #ifdef MOFREAK_TIE_DEBUG
         ++passes;
 #endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // the pass reads what has been published by now
         bool waits = false;
-        for (int k = threadIdx.x; k < n_items; k += kTieThreads) {
+#pragma unroll
+        for (int j = 0; j < kOwn; ++j) {
+            if (!own_waits[j]) continue;
+            const int px = (int)(own[j].xy & 0xffff), py = (int)(own[j].xy >> 16);
+            const TieStep step = tie_step(v, L, a.safe_threshold, px, py);
+            if (step.ready) {
+                tie_apply(a, v, L, cb + own_i[j], own[j], layer, px, py, step.is_max);
+                own_waits[j] = false;
+            } else {
+                waits = true;
+            }
+        }
+        for (int k = threadIdx.x + kOwn * kTieThreads; k < n_items; k += kTieThreads) {
             const int i = listed ? list[k] : lo + k;
             const TieCand c = tie_cand(a, cb + i);
             if (c.flag != kDetTie) continue;  // written by this thread only
