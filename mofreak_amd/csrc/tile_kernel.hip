@@ -305,37 +305,51 @@ __global__ __launch_bounds__(256) void bin_count_kernel(BinArgs a)
 constexpr int kSparseTile = 4;   // keypoints below which a tile is handed to the gather path
 constexpr int kSparseMarker = -(1 << 30);
 
-// Pass 2: exclusive scan of the tile populations (single workgroup; n_keys is a few hundred to ~1e5).
+// Pass 2: exclusive scan of the tile populations (single workgroup; n_keys is a few hundred to ~1e5): every thread
+// sums a run of consecutive keys, the run totals are scanned across the workgroup, every thread writes its run's starts
+// -- two sweeps of independent loads instead of a barrier-separated step per 256 keys.
 __global__ __launch_bounds__(256) void bin_scan_kernel(int32_t *tile_start, int32_t *tile_cursor, int32_t *slow_count, int64_t n_kp,
                                                        int64_t n_keys)
 {
-    __shared__ int carry_s;
     __shared__ int wave_tot[4];
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
     const int lane = lane_id(), w = threadIdx.x >> 6;
     const int n_slow = *slow_count;  // counted by pass 1; pass 3 counts again while it fills the list
     const bool drop_sparse = n_slow > 0 && (int64_t)n_slow * 8 >= n_kp;
     __syncthreads();
     if (threadIdx.x == 0) *slow_count = 0;
-    for (int64_t b0 = 0; b0 < n_keys; b0 += 256) {
-        const int64_t b = b0 + threadIdx.x;
-        int v = b < n_keys ? tile_start[b] : 0;
-        if (drop_sparse && v > 0 && v < kSparseTile) {
-            v = 0;
-            tile_cursor[b] = kSparseMarker;  // pass 3 sends this tile's keypoints to the slow list
+    const int64_t run = (n_keys + 255) / 256, b0 = min((int64_t)threadIdx.x * run, n_keys), b1 = min(b0 + run, n_keys);
+    constexpr int kPre = 8;  // keys whose populations are requested together
+    int sum = 0;
+    for (int64_t bb = b0; bb < b1; bb += kPre) {
+        int v[kPre];
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) v[u] = bb + u < b1 ? tile_start[bb + u] : 0;
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            if (drop_sparse && v[u] > 0 && v[u] < kSparseTile) {
+                v[u] = 0;
+                tile_start[bb + u] = 0;
+                tile_cursor[bb + u] = kSparseMarker;  // pass 3 sends this tile's keypoints to the slow list
+            }
+            sum += v[u];
         }
-        const int incl = wave_inclusive_scan(v);
-        if (lane == 63) wave_tot[w] = incl;
-        __syncthreads();
-        int base = carry_s;
-        for (int i = 0; i < w; ++i) base += wave_tot[i];
-        if (b < n_keys) tile_start[b] = base + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 255) carry_s = base + incl;
-        __syncthreads();
     }
-    if (threadIdx.x == 0) tile_start[n_keys] = carry_s;
+    const int incl = wave_inclusive_scan(sum);
+    if (lane == 63) wave_tot[w] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int i = 0; i < w; ++i) base += wave_tot[i];
+    for (int64_t bb = b0; bb < b1; bb += kPre) {
+        int v[kPre];
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) v[u] = bb + u < b1 ? tile_start[bb + u] : 0;
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            if (bb + u < b1) tile_start[bb + u] = base;
+            base += v[u];
+        }
+    }
+    if (threadIdx.x == 255) tile_start[n_keys] = base;  // the last run ends at n_keys (empty runs pass the total along)
 }
 
 // Pass 3: scatter keypoints into their tile's segment / the slow list; finalise erased keypoints.
