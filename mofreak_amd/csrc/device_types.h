@@ -95,6 +95,7 @@ struct BinArgs {
     int32_t force_slow;         // every valid keypoint goes to the gather path (tests, roi19 dumps)
     const SmallTables *small;
     int32_t *kp_key;            // [n_kp] key >= 0, -1 erased, -2 slow
+    uint8_t *kp_scale;          // [n_kp] FREAK scale index (0 for keypoints that fail the size / finiteness tests)
     int32_t *tile_start;        // [n_keys + 1] counts, then exclusive starts
     int32_t *tile_cursor;       // [n_keys]
     uint32_t *tile_lmin_c;      // [n_keys] smallest (as its complement ~L) / largest ROI side among the tile's keypoints: equal in

@@ -255,40 +255,88 @@ __device__ __forceinline__ int pair_of(const int64_t *offs, int n_pairs, int64_t
     return lo;
 }
 
-// Pass 1: classify every keypoint (erased / tile path / gather path) and count tile populations.
+// Pass 1: classify every keypoint (erased / tile path / gather path) and count tile populations.  The two searches a
+// keypoint needs -- its FREAK scale among the 63 size thresholds, its pair among the CSR offsets -- run on copies in
+// LDS: in global memory each is a chain of five or six dependent loads.
+constexpr int kBinOffsetsLds = 2048;  // CSR offsets (pairs + 1) a workgroup keeps in LDS; more: searched in global memory
+
 __global__ __launch_bounds__(256) void bin_count_kernel(BinArgs a)
 {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= a.n_kp) return;
+    __shared__ float s_thr[kNbScales];
+    __shared__ int32_t s_ps[kNbScales];
+    __shared__ int64_t s_off[kBinOffsetsLds];
     const SmallTables *st = a.small;
-    const mofreak_keypoint kp = a.kps[g];
-    const float kx = kp.x, ky = kp.y, size = kp.size;
-    // DescriptorExtractor::compute + FREAK::computeImpl keypoint filter (same tests as describe_kernel)
-    bool ok = (size >= FLT_EPSILON) && (size <= FLT_MAX) && (fabsf(kx) <= FLT_MAX) && (fabsf(ky) <= FLT_MAX);
-    const int idx = ok ? scale_index_scalar(st, size) : 0;
-    const int ps = st->pattern_sizes[idx];
-    if (kx <= ps || ky <= ps || kx >= a.W - ps || ky >= a.H - ps) ok = false;
-    int key = -1;
-    int tile_ps = 0;
-    if (ok) {
-        const int x_i = (int)kx, y_i = (int)ky;
-        const int half = ((int)size) / 2, L = (int)ceilf(size);
-        const bool roi_in = (x_i - half >= 0) && (y_i - half >= 0) && (x_i - half + L <= a.W) && (y_i - half + L <= a.H);
-        const bool fast = !a.force_slow && ps <= kTileHalo && L <= kTileMaxRoi && half <= kTileMipHalo &&
-                          (L - half) <= kTileMipHalo + 1 && roi_in;
-        if (fast) {
-            const int tile = (y_i / kTileH) * a.tiles_x + (x_i / kTileW);
-            const int64_t k64 = a.kp_offsets ? (int64_t)pair_of(a.kp_offsets, a.n_pairs, g) * (a.tiles_x * a.tiles_y) + tile : tile;
-            key = (int)k64;
-            tile_ps = ps;
-            atomicAdd(&a.tile_start[key], 1);
-            atomicMax(&a.tile_lmin_c[key], ~(uint32_t)L);
-            atomicMax(&a.tile_lmax[key], (uint32_t)L);
-        } else {
-            key = -2;
-        }
+    if (threadIdx.x < kNbScales) {
+        s_thr[threadIdx.x] = st->scale_thresholds[threadIdx.x];
+        s_ps[threadIdx.x] = st->pattern_sizes[threadIdx.x];
     }
-    a.kp_key[g] = key;
+    const bool offsets_in_lds = a.kp_offsets != nullptr && a.n_pairs + 1 <= kBinOffsetsLds;
+    if (offsets_in_lds)
+        for (int i = threadIdx.x; i <= a.n_pairs; i += 256) s_off[i] = a.kp_offsets[i];
+    __syncthreads();
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = g < a.n_kp;
+    int key = -1;
+    int tile_ps = 0, tile_L = 0;
+    if (live) {
+        const mofreak_keypoint kp = a.kps[g];
+        const float kx = kp.x, ky = kp.y, size = kp.size;
+        // DescriptorExtractor::compute + FREAK::computeImpl keypoint filter (same tests as describe_kernel)
+        bool ok = (size >= FLT_EPSILON) && (size <= FLT_MAX) && (fabsf(kx) <= FLT_MAX) && (fabsf(ky) <= FLT_MAX);
+        int idx = 0;
+        if (ok) {
+            if (!st->scale_normalized) {
+                idx = st->fixed_scale_index;
+            } else {
+                int lo = 0, hi = kNbScales - 1;  // number of thresholds <= size (thresholds ascend)
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (size >= s_thr[mid])
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                idx = lo;
+            }
+        }
+        a.kp_scale[g] = (uint8_t)idx;  // pass 3 packs it into the sorted record
+        const int ps = s_ps[idx];
+        if (kx <= ps || ky <= ps || kx >= a.W - ps || ky >= a.H - ps) ok = false;
+        if (ok) {
+            const int x_i = (int)kx, y_i = (int)ky;
+            const int half = ((int)size) / 2, L = (int)ceilf(size);
+            const bool roi_in = (x_i - half >= 0) && (y_i - half >= 0) && (x_i - half + L <= a.W) && (y_i - half + L <= a.H);
+            const bool fast = !a.force_slow && ps <= kTileHalo && L <= kTileMaxRoi && half <= kTileMipHalo &&
+                              (L - half) <= kTileMipHalo + 1 && roi_in;
+            if (fast) {
+                const int tile = (y_i / kTileH) * a.tiles_x + (x_i / kTileW);
+                int64_t k64 = tile;
+                if (a.kp_offsets) k64 += (int64_t)pair_of(offsets_in_lds ? s_off : a.kp_offsets, a.n_pairs, g) * (a.tiles_x * a.tiles_y);
+                key = (int)k64;
+                tile_ps = ps;
+                tile_L = L;
+            } else {
+                key = -2;
+            }
+        }
+        a.kp_key[g] = key;
+    }
+    // Tile populations and ROI-side ranges: one set of atomics per distinct tile in the wave, not per keypoint (neighbouring
+    // keypoints share tiles, and atomics on one address from all over the chip are served one after the other)
+    for (unsigned long long todo = __ballot(key >= 0); todo;) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(key, leader), lead_L = __shfl(tile_L, leader);
+        const unsigned long long same = __ballot(key == k);
+        if (lane_id() == leader) {
+            atomicAdd(&a.tile_start[k], __popcll(same));
+            atomicMax(&a.tile_lmin_c[k], ~(uint32_t)lead_L);
+            atomicMax(&a.tile_lmax[k], (uint32_t)lead_L);
+        } else if (key == k && tile_L != lead_L) {  // mixed sizes in one tile: rare
+            atomicMax(&a.tile_lmin_c[k], ~(uint32_t)tile_L);
+            atomicMax(&a.tile_lmax[k], (uint32_t)tile_L);
+        }
+        todo &= ~same;
+    }
     // how many keypoints already need the gather path: pass 2 decides from it whether thin tiles follow them there
     const unsigned long long slow = __ballot(key == -2);
     if (slow && lane_id() == __ffsll((long long)slow) - 1) atomicAdd(a.slow_count, __popcll(slow));
@@ -370,15 +418,27 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs a)
         base = __shfl(base, first);
         if (to_slow) a.slow_list[base + __popcll(slow_lanes & ((1ull << lane_id()) - 1))] = (int)g;
     }
+    // a tile's keypoints: one cursor bump per distinct tile in the wave, the wave's keypoints of that tile in order behind it
+    const bool to_tile = !to_slow && key >= 0;
+    int pos = 0;
+    for (unsigned long long todo = __ballot(to_tile); todo;) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(key, leader);
+        const unsigned long long same = __ballot(to_tile && key == k);
+        int base = 0;
+        if (lane_id() == leader) base = a.tile_start[k] + atomicAdd(&a.tile_cursor[k], __popcll(same));
+        base = __shfl(base, leader);
+        if (to_tile && key == k) pos = base + __popcll(same & ((1ull << lane_id()) - 1));
+        todo &= ~same;
+    }
     if (to_slow) {
     } else if (key >= 0) {
-        const int pos = a.tile_start[key] + atomicAdd(&a.tile_cursor[key], 1);
         const mofreak_keypoint kp = a.kps[g];
         SortedKp s;
         s.x = kp.x;
         s.y = kp.y;
         s.packed = (uint32_t)(int)ceilf(kp.size) | ((uint32_t)(((int)kp.size) / 2) << 8) |
-                   ((uint32_t)scale_index_scalar(a.small, kp.size) << 16);  // :293-295 ROI side / half, FREAK scale index
+                   ((uint32_t)a.kp_scale[g] << 16);  // :293-295 ROI side / half, FREAK scale index (pass 1)
         s.g = (int)g;
         a.sorted_kp[pos] = s;
     } else {
