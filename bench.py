@@ -346,12 +346,13 @@ def bench_dataset(args):
         pool = pinned
     clips = [pool[i % len(pool)][: lengths[i]] for i in range(n_clips)]
     names = [f"clip{i:05d}.avi" for i in range(n_clips)]
-    harness.run_dataset(clips[: 4 * world], names[: 4 * world], None, mo, rank, world, on_device=on_device)  # warm-up
+    harness.run_dataset(clips[: 4 * world * args.workers], names[: 4 * world * args.workers], None, mo, rank, world, on_device=on_device,
+                        workers=args.workers)  # warm-up
     steps = args.steps or 1
     fence(torch, dist, world)
     t0 = time.perf_counter()
     for _ in range(steps):
-        res = harness.run_dataset(clips, names, None, mo, rank, world, on_device=on_device)
+        res = harness.run_dataset(clips, names, None, mo, rank, world, on_device=on_device, workers=args.workers)
     fence(torch, dist, world)
     elapsed = max_over_ranks(torch, dist, world, on_device, time.perf_counter() - t0)
     gather_s = max_over_ranks(torch, dist, world, on_device, res["gather_s"])
@@ -366,7 +367,8 @@ def bench_dataset(args):
             "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic (8 distinct clips cut to the seeded lengths)",
             "config": {"workload": f"C4: {n_clips} clips {W}x{H}, seeded log-normal lengths {int(lengths.min())}..{int(lengths.max())} "
                                    f"frames (median {int(np.median(lengths))}), dense {cfg['step']}-px grid, {n_kp} keypoints/pair",
-                       "descriptors_per_step": n_desc, "parallelism": f"LPT shard of whole clips over {world} rank(s)"},
+                       "descriptors_per_step": n_desc,
+                       "parallelism": f"LPT shard of whole clips over {world} rank(s), {args.workers} host thread(s) with a context each per rank"},
             "gather_ms": gather_s * 1e3, "frames_in_MB_per_step": float(lengths.sum() * W * H / 1e6),
             "note": f"host frames in ({'pageable' if args.pageable else 'page-locked'} memory), rows back: every clip is one synchronous C-ABI call (mofreak_extract_stream)"}), flush=True)
     mo.close()
@@ -455,6 +457,7 @@ def main():
     ap.add_argument("--frames", type=int, default=2005, help="C5: frames in the stream")
     ap.add_argument("--chunk", type=int, default=256, help="C5: frames per pipelined chunk")
     ap.add_argument("--clips", type=int, default=512, help="C4: clips in the batch (HMDB51 has 6766)")
+    ap.add_argument("--workers", type=int, default=4, help="C4: host threads per rank, each with a context of its own, taking the rank's clips in turn")
     ap.add_argument("--pageable", action="store_true", help="C4: clips in ordinary (pageable) host memory instead of page-locked buffers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=192, help="pairs of the workload the CPU oracle is timed on (about 25 core-seconds)")

@@ -62,8 +62,21 @@ class MoFREAKUtilities:
         self.actions: dict[str, int] = {}
         self.features: deque = deque()  # of structured rows (api.ROW_DTYPE arrays)
         self._labels: deque = deque()
+        self._device, self._params = device, dict(params)
         self._ctx = api.Context(device, **params)
         self.keypoint_provider = keypoint_provider or dense_grid_provider()
+
+    def clone(self) -> "MoFREAKUtilities":
+        """Another instance with the same parameters and keypoint source and a context (stream, workspace) of its own:
+        what a second host thread extracting other videos on the same device uses (one context per thread)."""
+        return MoFREAKUtilities(self.dataset, self._device, self.keypoint_provider, **self._params)
+
+    def workers(self, n: int) -> list:
+        """This instance and n - 1 clones of it (kept for later calls, closed with it)."""
+        self._clones = getattr(self, "_clones", [])
+        while len(self._clones) < n - 1:
+            self._clones.append(self.clone())
+        return [self] + self._clones[: n - 1]
 
     # ---- the hot path
     def computeMoFREAKFromFile(self, video_filename: str, mofreak_filename: str,
@@ -156,6 +169,9 @@ class MoFREAKUtilities:
         self.current_action = self.actions[folder_name]
 
     def close(self):
+        for c in getattr(self, "_clones", []):
+            c.close()
+        self._clones = []
         self._ctx.close()
 
 
@@ -229,12 +245,15 @@ def compute_mofreak_files(video_paths: Sequence[str], out_dir: str, mofreak: MoF
 
 
 def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mofreak: MoFREAKUtilities, rank: int = 0,
-                world_size: int = 1, costs: Sequence[float] | None = None, group=None, on_device: bool = False) -> dict:
+                world_size: int = 1, costs: Sequence[float] | None = None, group=None, on_device: bool = False,
+                workers: int = 1) -> dict:
     """BASELINE config 4 end to end (main.cpp:854-924 over a whole dataset).
 
     videos[i]: a (T, H, W) uint8 gray stack or the path of a .npy file holding one; names[i]: its output stem.
     1. shard: longest-processing-time-first over `costs` (default: frame counts), one video per GPU at a time;
-    2. every rank extracts its videos' rows (no collective on the data path);
+    2. every rank extracts its videos' rows (no collective on the data path); workers > 1: that many host threads, each
+       with a context of its own (mofreak.clone()), take the rank's videos in turn, so that one clip's copies run under
+       another's kernels -- a clip is one synchronous C-ABI call, and short clips are all latency;
     3. the one exchange: counts per video (all_gather) + gather_rows of the 32-byte rows to rank 0;
     4. rank 0 writes <out_dir>/<name>.mofreak for every video, rows in (video, frame, keypoint) order -- the bytes a
        1-rank run writes (out_dir None: nothing is written, the gathered rows are still returned on rank 0).
@@ -253,11 +272,28 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
         costs = [stack_of(v).shape[0] for v in videos]
     mine = shard_videos(costs, world_size)[rank]
     t0 = time.perf_counter()
-    parts, counts = [], np.zeros(n, np.int64)
-    for i in mine:
-        rows = mofreak.extract_rows(np.ascontiguousarray(stack_of(videos[i])))
+    counts = np.zeros(n, np.int64)
+    if workers > 1 and len(mine) > 1:
+        import queue
+        from concurrent.futures import ThreadPoolExecutor
+
+        pool = queue.SimpleQueue()
+        for m in mofreak.workers(min(workers, len(mine))):
+            pool.put(m)
+
+        def one(i):
+            m = pool.get()  # an instance nobody else is using
+            try:
+                return m.extract_rows(np.ascontiguousarray(stack_of(videos[i])))
+            finally:
+                pool.put(m)
+
+        with ThreadPoolExecutor(max_workers=min(workers, len(mine))) as ex:
+            parts = list(ex.map(one, mine))  # in the order of `mine`, whichever thread did what
+    else:
+        parts = [mofreak.extract_rows(np.ascontiguousarray(stack_of(videos[i]))) for i in mine]
+    for i, rows in zip(mine, parts):
         counts[i] = len(rows)
-        parts.append(rows)
     local = np.concatenate(parts) if parts else np.zeros(0, api.ROW_DTYPE)
     t_compute = time.perf_counter() - t0
 

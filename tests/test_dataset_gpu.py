@@ -30,12 +30,14 @@ def _mofreak(device=0):
     return harness.MoFREAKUtilities(harness.HMDB51, device=device, keypoint_provider=harness.dense_grid_provider(c["step"], c["size"], c["lo"]))
 
 
-def test_c4_dataset_rows_match_the_oracle_and_files_are_ordered(oracle, tmp_path):
+@pytest.mark.parametrize("workers", [1, 3])
+def test_c4_dataset_rows_match_the_oracle_and_files_are_ordered(oracle, tmp_path, workers):
+    """workers = 3: three host threads, each with a context of its own, take the clips in turn."""
     clips, names, lengths = _clips()
     assert len(synth.config_grid("C4")) == 150 and lengths.min() >= 20 and len(set(lengths.tolist())) > 20
     mo = _mofreak()
     try:
-        res = harness.run_dataset(clips, names, str(tmp_path), mo)
+        res = harness.run_dataset(clips, names, str(tmp_path), mo, workers=workers)
     finally:
         mo.close()
     f = oracle.Freak()
