@@ -304,9 +304,10 @@ __global__ __launch_bounds__(kDetThreads) void det_score_kernel(DetArgs a, int l
             s = max(max(vb, vd) - 1, 0);
         }
         if (x < L.w && y < L.h) {
-            score[(int64_t)y * L.w + x] = (uint8_t)s;
-            touch[(int64_t)y * L.w + x] = 0;  // the two bookkeeping maps of the tie logic start empty: cleared here, under
-            status[(int64_t)y * L.w + x] = 0;  // the arithmetic, instead of by two fills of their own
+            const uint32_t o = (uint32_t)y * (uint32_t)L.w + (uint32_t)x;  // a layer has fewer than 2^32 pixels: uniform base + 32-bit offset
+            score[o] = (uint8_t)s;
+            touch[o] = 0;   // the two bookkeeping maps of the tie logic start empty: cleared here, under the arithmetic,
+            status[o] = 0;  // instead of by two fills of their own
         }
         const unsigned long long hit = __ballot(s >= a.safe_threshold);
         if (lane == 0 && hit && y < L.h) atomicAdd(&row_count[y], __popcll(hit));
