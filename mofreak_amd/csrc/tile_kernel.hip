@@ -418,19 +418,25 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs a)
         base = __shfl(base, first);
         if (to_slow) a.slow_list[base + __popcll(slow_lanes & ((1ull << lane_id()) - 1))] = (int)g;
     }
-    // a tile's keypoints: one cursor bump per distinct tile in the wave, the wave's keypoints of that tile in order behind it
+    // a tile's keypoints: one cursor bump per distinct tile in the wave, the wave's keypoints of that tile in order behind
+    // it.  Who leads which tile is worked out first, without touching memory, so that all the bumps (which return a value:
+    // a memory round trip each) are in flight together.
     const bool to_tile = !to_slow && key >= 0;
-    int pos = 0;
+    int leader = 0, rank = 0, count = 0;
     for (unsigned long long todo = __ballot(to_tile); todo;) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int k = __shfl(key, leader);
+        const int first = __ffsll((long long)todo) - 1;
+        const int k = __shfl(key, first);
         const unsigned long long same = __ballot(to_tile && key == k);
-        int base = 0;
-        if (lane_id() == leader) base = a.tile_start[k] + atomicAdd(&a.tile_cursor[k], __popcll(same));
-        base = __shfl(base, leader);
-        if (to_tile && key == k) pos = base + __popcll(same & ((1ull << lane_id()) - 1));
+        if (to_tile && key == k) {
+            leader = first;
+            rank = __popcll(same & ((1ull << lane_id()) - 1));
+            count = __popcll(same);
+        }
         todo &= ~same;
     }
+    int pos = 0;
+    if (to_tile && lane_id() == leader) pos = a.tile_start[key] + atomicAdd(&a.tile_cursor[key], count);
+    pos = __shfl(pos, leader) + rank;
     if (to_slow) {
     } else if (key >= 0) {
         const mofreak_keypoint kp = a.kps[g];
