@@ -292,7 +292,10 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
         const int tiles_x = (g.W + kTileW - 1) / kTileW, tiles_y = (g.H + kTileH - 1) / kTileH;
         const int64_t n_keys = (int64_t)tiles_x * tiles_y * (d_offsets ? n_pairs : 1);
         if (n_keys >= ((int64_t)1 << 31)) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "too many (pair, tile) bins in one call");
-        if ((rc = ensure(ctx, ctx->kp_key, (size_t)n_kp * 5))) return rc;  // keys, then a byte of scale index per keypoint
+        const size_t bin_blocks = ((size_t)n_kp + 255) / 256;
+        // keys, then a byte of scale index per keypoint, then (4-byte aligned) pass 1's two figures per workgroup
+        const size_t wg_at = ((size_t)n_kp * 5 + 3) & ~(size_t)3;
+        if ((rc = ensure(ctx, ctx->kp_key, wg_at + 2 * bin_blocks * sizeof(int32_t) + 16))) return rc;
         if ((rc = ensure(ctx, ctx->sorted_idx, (size_t)n_kp * sizeof(SortedKp)))) return rc;
         if ((rc = ensure(ctx, ctx->slow_list, (size_t)n_kp * 4))) return rc;
         // every counter of the binning pass in one buffer (one fill clears them): the gather path's count and the largest
@@ -314,6 +317,8 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
         b.small = ctx->d_small;
         b.kp_key = static_cast<int32_t *>(ctx->kp_key.ptr);
         b.kp_scale = static_cast<uint8_t *>(ctx->kp_key.ptr) + (size_t)n_kp * 4;
+        b.wg_slow = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(ctx->kp_key.ptr) + wg_at);
+        b.wg_maxps = b.wg_slow + bin_blocks;
         b.tile_start = bin_base + kBinHeaderInts;
         b.tile_cursor = b.tile_start + key_pad;
         b.tile_lmin_c = reinterpret_cast<uint32_t *>(b.tile_cursor + key_pad);

@@ -105,6 +105,7 @@ struct BinArgs {
     int32_t *slow_list;         // [n_kp]
     int32_t *slow_count;        // [1]
     int32_t *max_ps;            // [1] largest patternSizes[] among the tile-path keypoints: sizes the tile kernel's halo
+    int32_t *wg_slow, *wg_maxps;  // [ceil(n_kp / 256)] pass 1's per-workgroup gather-path count / largest tile-path pattern
     uint8_t *out_desc;          // erased keypoints are finalised by the binning pass (zeros, valid = 0)
     uint8_t *out_valid;
     int32_t *out_info;

@@ -337,14 +337,24 @@ __global__ __launch_bounds__(256) void bin_count_kernel(BinArgs a)
         }
         todo &= ~same;
     }
-    // how many keypoints already need the gather path: pass 2 decides from it whether thin tiles follow them there
+    // How many keypoints already need the gather path (pass 2 decides from it whether thin tiles follow them there) and
+    // the largest pattern on the tile path (it sizes the tile kernel's integral halo): one pair of numbers per
+    // workgroup, reduced by pass 2 -- thousands of atomics on one address are served one after the other, and a wave
+    // does not retire before its own has been.
+    __shared__ int s_wave_slow[4], s_wave_ps[4];
     const unsigned long long slow = __ballot(key == -2);
-    if (slow && lane_id() == __ffsll((long long)slow) - 1) atomicAdd(a.slow_count, __popcll(slow));
-    // the largest pattern on the tile path sizes the tile kernel's integral halo
     int m = tile_ps;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-    if (m > 0 && lane_id() == 0) atomicMax(a.max_ps, m);
+    if (lane_id() == 0) {
+        s_wave_slow[threadIdx.x >> 6] = __popcll(slow);
+        s_wave_ps[threadIdx.x >> 6] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.wg_slow[blockIdx.x] = s_wave_slow[0] + s_wave_slow[1] + s_wave_slow[2] + s_wave_slow[3];
+        a.wg_maxps[blockIdx.x] = max(max(s_wave_ps[0], s_wave_ps[1]), max(s_wave_ps[2], s_wave_ps[3]));
+    }
 }
 
 // A tile costs the same whether it holds 5 keypoints or 90 (gray tiles, the integral), the gather path costs per
@@ -356,15 +366,31 @@ constexpr int kSparseMarker = -(1 << 30);
 // Pass 2: exclusive scan of the tile populations (single workgroup; n_keys is a few hundred to ~1e5): every thread
 // sums a run of consecutive keys, the run totals are scanned across the workgroup, every thread writes its run's starts
 // -- two sweeps of independent loads instead of a barrier-separated step per 256 keys.
-__global__ __launch_bounds__(256) void bin_scan_kernel(int32_t *tile_start, int32_t *tile_cursor, int32_t *slow_count, int64_t n_kp,
-                                                       int64_t n_keys)
+__global__ __launch_bounds__(256) void bin_scan_kernel(int32_t *tile_start, int32_t *tile_cursor, int32_t *slow_count, int32_t *max_ps,
+                                                       const int32_t *wg_slow, const int32_t *wg_maxps, int n_blocks, int64_t n_kp, int64_t n_keys)
 {
-    __shared__ int wave_tot[4];
+    __shared__ int wave_tot[4], wave_slow[4], wave_ps[4];
     const int lane = lane_id(), w = threadIdx.x >> 6;
-    const int n_slow = *slow_count;  // counted by pass 1; pass 3 counts again while it fills the list
-    const bool drop_sparse = n_slow > 0 && (int64_t)n_slow * 8 >= n_kp;
+    // pass 1's per-workgroup figures: keypoints that need the gather path anyway, the largest pattern on the tile path
+    int ns = 0, mp = 0;
+    for (int i = threadIdx.x; i < n_blocks; i += 256) {
+        ns += wg_slow[i];
+        mp = max(mp, wg_maxps[i]);
+    }
+    ns = wave_sum(ns);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mp = max(mp, __shfl_xor(mp, o));
+    if (lane == 0) {
+        wave_slow[w] = ns;
+        wave_ps[w] = mp;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) *slow_count = 0;
+    const int n_slow = wave_slow[0] + wave_slow[1] + wave_slow[2] + wave_slow[3];
+    const bool drop_sparse = n_slow > 0 && (int64_t)n_slow * 8 >= n_kp;
+    if (threadIdx.x == 0) {
+        *max_ps = max(max(wave_ps[0], wave_ps[1]), max(wave_ps[2], wave_ps[3]));
+        *slow_count = 0;  // pass 3 counts while it fills the list
+    }
     const int64_t run = (n_keys + 255) / 256, b0 = min((int64_t)threadIdx.x * run, n_keys), b1 = min(b0 + run, n_keys);
     constexpr int kPre = 8;  // keys whose populations are requested together
     int sum = 0;
@@ -403,21 +429,28 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(int32_t *tile_start, int3
 // Pass 3: scatter keypoints into their tile's segment / the slow list; finalise erased keypoints.
 __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs a)
 {
+    __shared__ int s_wave_slow[4], s_base;
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= a.n_kp) return;
-    const int key = a.kp_key[g];
+    const bool live = g < a.n_kp;
+    const int key = live ? a.kp_key[g] : -1;
     const bool to_slow = key == -2 || (key >= 0 && a.tile_cursor[key] < 0);
-    // the gather path's list: one counter bump per wave, the wave's keypoints in order behind it -- the list stays close
-    // to keypoint order (the order the detector emits: layer, then raster), which is what gives describe_kernel's
-    // neighbouring wavefronts neighbouring rows of the integral
+    // the gather path's list: one counter bump per workgroup (bumps of one address are served one after the other), the
+    // workgroup's keypoints in order behind it -- the list stays close to keypoint order (the order the detector emits:
+    // layer, then raster), which is what gives describe_kernel's neighbouring wavefronts neighbouring rows of the integral
     const unsigned long long slow_lanes = __ballot(to_slow);
-    if (slow_lanes) {
-        const int first = __ffsll((long long)slow_lanes) - 1;
-        int base = 0;
-        if (lane_id() == first) base = atomicAdd(a.slow_count, __popcll(slow_lanes));
-        base = __shfl(base, first);
-        if (to_slow) a.slow_list[base + __popcll(slow_lanes & ((1ull << lane_id()) - 1))] = (int)g;
+    if (lane_id() == 0) s_wave_slow[threadIdx.x >> 6] = __popcll(slow_lanes);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = s_wave_slow[0] + s_wave_slow[1] + s_wave_slow[2] + s_wave_slow[3];
+        s_base = total ? atomicAdd(a.slow_count, total) : 0;
     }
+    __syncthreads();
+    if (to_slow) {
+        int base = s_base;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += s_wave_slow[w];
+        a.slow_list[base + __popcll(slow_lanes & ((1ull << lane_id()) - 1))] = (int)g;
+    }
+    if (!live) return;
     // a tile's keypoints: one cursor bump per distinct tile in the wave, the wave's keypoints of that tile in order behind
     // it.  Who leads which tile is worked out first, without touching memory, so that all the bumps (which return a value:
     // a memory round trip each) are in flight together.
@@ -1110,7 +1143,8 @@ int launch_bin(const BinArgs &a, void *stream)
     if (e != hipSuccess) return (int)e;
     const int blocks = (int)((a.n_kp + 255) / 256);
     if (blocks > 0) hipLaunchKernelGGL(bin_count_kernel, dim3(blocks), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, s, a.tile_start, a.tile_cursor, a.slow_count, a.n_kp, a.n_keys);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, s, a.tile_start, a.tile_cursor, a.slow_count, a.max_ps, a.wg_slow, a.wg_maxps, blocks,
+                       a.n_kp, a.n_keys);
     if (blocks > 0) hipLaunchKernelGGL(bin_scatter_kernel, dim3(blocks), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
