@@ -366,14 +366,16 @@ constexpr int kSparseMarker = -(1 << 30);
 // Pass 2: exclusive scan of the tile populations (single workgroup; n_keys is a few hundred to ~1e5): every thread
 // sums a run of consecutive keys, the run totals are scanned across the workgroup, every thread writes its run's starts
 // -- two sweeps of independent loads instead of a barrier-separated step per 256 keys.
-__global__ __launch_bounds__(256) void bin_scan_kernel(int32_t *tile_start, int32_t *tile_cursor, int32_t *slow_count, int32_t *max_ps,
+constexpr int kScanThreads = 1024, kScanWaves = kScanThreads / 64;
+
+__global__ __launch_bounds__(kScanThreads) void bin_scan_kernel(int32_t *tile_start, int32_t *tile_cursor, int32_t *slow_count, int32_t *max_ps,
                                                        const int32_t *wg_slow, const int32_t *wg_maxps, int n_blocks, int64_t n_kp, int64_t n_keys)
 {
-    __shared__ int wave_tot[4], wave_slow[4], wave_ps[4];
+    __shared__ int wave_tot[kScanWaves], wave_slow[kScanWaves], wave_ps[kScanWaves];
     const int lane = lane_id(), w = threadIdx.x >> 6;
     // pass 1's per-workgroup figures: keypoints that need the gather path anyway, the largest pattern on the tile path
     int ns = 0, mp = 0;
-    for (int i = threadIdx.x; i < n_blocks; i += 256) {
+    for (int i = threadIdx.x; i < n_blocks; i += kScanThreads) {
         ns += wg_slow[i];
         mp = max(mp, wg_maxps[i]);
     }
@@ -385,13 +387,17 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(int32_t *tile_start, int3
         wave_ps[w] = mp;
     }
     __syncthreads();
-    const int n_slow = wave_slow[0] + wave_slow[1] + wave_slow[2] + wave_slow[3];
+    int n_slow = 0, max_pattern = 0;
+    for (int i = 0; i < kScanWaves; ++i) {
+        n_slow += wave_slow[i];
+        max_pattern = max(max_pattern, wave_ps[i]);
+    }
     const bool drop_sparse = n_slow > 0 && (int64_t)n_slow * 8 >= n_kp;
     if (threadIdx.x == 0) {
-        *max_ps = max(max(wave_ps[0], wave_ps[1]), max(wave_ps[2], wave_ps[3]));
+        *max_ps = max_pattern;
         *slow_count = 0;  // pass 3 counts while it fills the list
     }
-    const int64_t run = (n_keys + 255) / 256, b0 = min((int64_t)threadIdx.x * run, n_keys), b1 = min(b0 + run, n_keys);
+    const int64_t run = (n_keys + kScanThreads - 1) / kScanThreads, b0 = min((int64_t)threadIdx.x * run, n_keys), b1 = min(b0 + run, n_keys);
     constexpr int kPre = 8;  // keys whose populations are requested together
     int sum = 0;
     for (int64_t bb = b0; bb < b1; bb += kPre) {
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(int32_t *tile_start, int3
             base += v[u];
         }
     }
-    if (threadIdx.x == 255) tile_start[n_keys] = base;  // the last run ends at n_keys (empty runs pass the total along)
+    if (threadIdx.x == kScanThreads - 1) tile_start[n_keys] = base;  // the last run ends at n_keys (empty runs pass the total along)
 }
 
 // Pass 3: scatter keypoints into their tile's segment / the slow list; finalise erased keypoints.
@@ -1143,7 +1149,7 @@ int launch_bin(const BinArgs &a, void *stream)
     if (e != hipSuccess) return (int)e;
     const int blocks = (int)((a.n_kp + 255) / 256);
     if (blocks > 0) hipLaunchKernelGGL(bin_count_kernel, dim3(blocks), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, s, a.tile_start, a.tile_cursor, a.slow_count, a.max_ps, a.wg_slow, a.wg_maxps, blocks,
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, a.tile_start, a.tile_cursor, a.slow_count, a.max_ps, a.wg_slow, a.wg_maxps, blocks,
                        a.n_kp, a.n_keys);
     if (blocks > 0) hipLaunchKernelGGL(bin_scatter_kernel, dim3(blocks), dim3(256), 0, s, a);
     return (int)hipGetLastError();
