@@ -157,7 +157,7 @@ int validate_frames(const mofreak_ctx *ctx, const void *cur, const void *prev, i
     if (row_stride < W) return fail(ctx, MOFREAK_ERR_BAD_ARG, "row_stride < W");
     if (n_pairs > 1 && pair_stride == 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "pair_stride is 0");
     if ((size_t)kBandRows * integral_pitch(W) * sizeof(int32_t) > 160 * 1024)
-        return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "frame wider than the banded integral kernel supports (W <= 5112)");
+        return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "frame wider than the banded integral kernel supports (W <= 10232)");
     if ((int64_t)(H + 1) * integral_pitch(W) >= ((int64_t)1 << 31))
         return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "frame too large for 32-bit integral indexing");
     return MOFREAK_OK;
@@ -168,7 +168,7 @@ int run_integral(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, cons
                  const int32_t *gate = nullptr)
 {
     const int pitch = integral_pitch(g.W);
-    const int n_bands = (g.H + kBandRows - 1) / kBandRows;
+    const int n_bands = (g.H + kBandRows * kBandGroup - 1) / (kBandRows * kBandGroup);
     int rc = ensure(ctx, ctx->integral, (size_t)np * (g.H + 1) * pitch * sizeof(int32_t));
     if (rc) return rc;
     rc = ensure(ctx, ctx->band_totals, (size_t)np * n_bands * pitch * sizeof(int32_t));
@@ -717,7 +717,7 @@ int mofreak_reserve(mofreak_ctx *ctx, int W, int H, int chunk_pairs)
     // the larger of the two users: the gather path alone (chunk_pairs at a time) and the gather path behind the tile kernel
     const int chunk = std::max(choose_chunk(ctx, W, H, 1 << 30), ctx->path_mode == MOFREAK_PATH_GATHER ? 1 : slow_chunk(W, H));
     const int pitch = integral_pitch(W);
-    const int n_bands = (H + kBandRows - 1) / kBandRows;
+    const int n_bands = (H + kBandRows * kBandGroup - 1) / (kBandRows * kBandGroup);
     int rc = ensure(ctx, ctx->integral, (size_t)chunk * (H + 1) * pitch * sizeof(int32_t));
     if (rc) return rc;
     return ensure(ctx, ctx->band_totals, (size_t)chunk * n_bands * pitch * sizeof(int32_t));

@@ -27,7 +27,9 @@ struct SmallTables {
 // (H+1) rows of `pitch` int32 per pair; logical column c (0..W) lives at physical column c+3, so the
 // 4-pixel group starting at pixel x = 4g (logical columns x+1..x+4) is one aligned 16-byte store.
 constexpr int kIntegralColOffset = 3;
-constexpr int kBandRows = 4;  // rows per band of the banded integral kernels: a wave per row; 31 KB of LDS per workgroup at 1080p, five per CU
+constexpr int kBandRows = 4;   // rows of the banded integral kernels' LDS buffer: a wave per row; 31 KB per workgroup at 1080p, five per CU
+constexpr int kBandGroup = 4;  // such slabs per band: a workgroup takes them one after the other; band totals are per band
+constexpr int kBandColIters = 10;  // 1024 columns per iteration of the column pass: pitch <= 10240 (what 160 KB of LDS allow)
 
 struct FrameArgs {
     const uint8_t *cur;

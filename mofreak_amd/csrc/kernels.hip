@@ -17,7 +17,7 @@ namespace mofreak {
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// Integral image of |cur - prev|, banded: a workgroup owns kBandRows rows of one pair.
+// Integral image of |cur - prev|, banded: a workgroup owns a band of kBandGroup x kBandRows rows of one pair.
 //   pass A (FINAL=false): band_totals[band] = column sums of the band's row-prefix sums
 //   pass B: exclusive scan of band_totals over bands (band_scan_kernel)
 //   pass C (FINAL=true):  integral rows = band carry + running column sums, 16-byte stores
@@ -33,11 +33,27 @@ __global__ __launch_bounds__(256) void band_kernel(IntegralArgs a)
     for (int item = blockIdx.x; item < a.n_bands * a.n_pairs; item += gridDim.x) {
     const int band = item % a.n_bands, pair = item / a.n_bands;
     const int W = a.f.W, pitch = a.pitch;
-    const int y0 = band * kBandRows;
-    const int rows = min(kBandRows, a.f.H - y0);
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const uint8_t *cur = a.f.cur + (int64_t)pair * a.f.pair_stride;
     const uint8_t *prev = a.f.prev + (int64_t)pair * a.f.pair_stride;
+    const int64_t bt = ((int64_t)pair * a.n_bands + band) * pitch;
+    int32_t *integ = a.integral + (int64_t)pair * (a.f.H + 1) * pitch;
+    // a band = kBandGroup slabs of kBandRows rows, one after the other through the same LDS buffer, the running column
+    // sums staying in registers: the totals that travel through memory (and the scan over them) are per band
+    int4 acc[kBandColIters];
+#pragma unroll
+    for (int u = 0; u < kBandColIters; ++u) {
+        const int c4 = (threadIdx.x + 256 * u) * 4;
+        acc[u] = make_int4(0, 0, 0, 0);
+        if (FINAL && c4 < pitch) {
+            acc[u] = *reinterpret_cast<const int4 *>(a.band_totals + bt + c4);
+            if (band == 0) *reinterpret_cast<int4 *>(integ + c4) = make_int4(0, 0, 0, 0);  // integral row 0
+        }
+    }
+    for (int slab = 0; slab < kBandGroup; ++slab) {
+    const int y0 = (band * kBandGroup + slab) * kBandRows;
+    if (y0 >= a.f.H) break;
+    const int rows = min(kBandRows, a.f.H - y0);
 
     for (int r = wave; r < rows; r += 4) {
         const uint8_t *c = cur + (int64_t)(y0 + r) * a.f.row_stride;
@@ -87,25 +103,28 @@ __global__ __launch_bounds__(256) void band_kernel(IntegralArgs a)
     }
     __syncthreads();
 
-    const int64_t bt = ((int64_t)pair * a.n_bands + band) * pitch;
-    int32_t *integ = a.integral + (int64_t)pair * (a.f.H + 1) * pitch;
-    for (int c4 = threadIdx.x * 4; c4 < pitch; c4 += 1024) {
-        int4 acc = make_int4(0, 0, 0, 0);
-        if (FINAL) {
-            acc = *reinterpret_cast<const int4 *>(a.band_totals + bt + c4);
-            if (band == 0) *reinterpret_cast<int4 *>(integ + c4) = make_int4(0, 0, 0, 0);  // integral row 0
-        }
+#pragma unroll
+    for (int u = 0; u < kBandColIters; ++u) {
+        const int c4 = (threadIdx.x + 256 * u) * 4;
+        if (c4 >= pitch) continue;
         for (int r = 0; r < rows; ++r) {
             const int4 v = *reinterpret_cast<const int4 *>(rp + r * pitch + c4);
-            acc.x += v.x;
-            acc.y += v.y;
-            acc.z += v.z;
-            acc.w += v.w;
-            if (FINAL) *reinterpret_cast<int4 *>(integ + (int64_t)(y0 + r + 1) * pitch + c4) = acc;
+            acc[u].x += v.x;
+            acc[u].y += v.y;
+            acc[u].z += v.z;
+            acc[u].w += v.w;
+            if (FINAL) *reinterpret_cast<int4 *>(integ + (int64_t)(y0 + r + 1) * pitch + c4) = acc[u];
         }
-        if (!FINAL) *reinterpret_cast<int4 *>(a.band_totals + bt + c4) = acc;
     }
-    __syncthreads();  // the next item reuses the row-prefix buffer
+    __syncthreads();  // the next slab (or item) reuses the row-prefix buffer
+    }
+    if (!FINAL) {
+#pragma unroll
+        for (int u = 0; u < kBandColIters; ++u) {
+            const int c4 = (threadIdx.x + 256 * u) * 4;
+            if (c4 < pitch) *reinterpret_cast<int4 *>(a.band_totals + bt + c4) = acc[u];
+        }
+    }
     }
 }
 
