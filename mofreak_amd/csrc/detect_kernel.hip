@@ -1240,10 +1240,6 @@ __global__ __launch_bounds__(kTieThreads) void det_tie_chain_kernel(DetArgs a, i
     const int32_t *list = a.wait_list + (int64_t)p * kDetWaitCap;
     const bool listed = n_wait <= kDetWaitCap;  // list overflow: every candidate of the layer
     const int n_items = listed ? n_wait : hi - lo;
-#ifdef MOFREAK_TIE_DEBUG
-    int passes = 0;
-    const long long t_begin = wall_clock64();
-#endif
     // a thread's first two ties stay in registers between passes (there are rarely more than a few hundred per pair and
     // layer): a pass is then one round of neighbourhood loads, not list entry -> record -> neighbourhood
     constexpr int kOwn = 2;
@@ -1261,9 +1257,6 @@ __global__ __launch_bounds__(kTieThreads) void det_tie_chain_kernel(DetArgs a, i
         own_waits[j] = threadIdx.x + j * kTieThreads < n_items && own[j].flag == kDetTie;
     }
     for (;;) {
-#ifdef MOFREAK_TIE_DEBUG
-        ++passes;
-#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // the pass reads what has been published by now
         bool waits = false;
 #pragma unroll
@@ -1291,16 +1284,6 @@ __global__ __launch_bounds__(kTieThreads) void det_tie_chain_kernel(DetArgs a, i
         }
         if (!waits) break;
     }
-#ifdef MOFREAK_TIE_DEBUG
-    {
-        __shared__ int max_passes;
-        if (threadIdx.x == 0) max_passes = 0;
-        __syncthreads();
-        atomicMax(&max_passes, passes);
-        __syncthreads();
-        if (threadIdx.x == 0 && p < 4) printf("pair %d layer %d: %d ties of %d candidates waiting, %d passes, %lld us\n", p, layer, n_wait, hi - lo, max_passes, (wall_clock64() - t_begin) / 100);
-    }
-#endif
 }
 
 // ------------------------------------------------------------------ ordered emission
