@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(kTieThreads) void det_tie_chain_kernel(DetArgs a, i
 #pragma unroll
     for (int j = 0; j < kOwn; ++j) {
         own[j] = tie_cand(a, cb + own_i[j]);
-        own_waits[j] = threadIdx.x + j * kTieThreads < n_items && own[j].flag == kDetTie;
+        own_waits[j] = (int)threadIdx.x + j * kTieThreads < n_items && own[j].flag == kDetTie;
     }
     for (;;) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // the pass reads what has been published by now
