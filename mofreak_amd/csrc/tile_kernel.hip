@@ -34,7 +34,9 @@
 namespace mofreak {
 namespace {
 
-constexpr int kTileThreads = 512;                    // 8 waves; two workgroups per CU = 4 waves per SIMD
+constexpr int kTileThreads = 512;                    // 8 waves; two workgroups per CU = 4 waves per SIMD (ten-wave workgroups at
+                                                     // <= 96 registers were tried: the second one does not fit beside the first)
+constexpr int kStageRows = kTileThreads / 16;        // region rows a staging step takes (16 lanes per row)
 constexpr int kTileLdsLimit = 80 * 1024;             // a workgroup's LDS budget (two per CU); debug builds check accesses against it
 constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kBatch = 96;                           // keypoints described per pass over a tile's list
@@ -44,7 +46,7 @@ constexpr int kIPitch = kTileStagePitch / 2;         // LDS integral pitch (u16)
 constexpr int kIColOff = 7;
 constexpr int kIPitchDw = kIPitch / 2;
 constexpr int kIntegralBytes = (kTileRH + 1) * kTileStagePitch;
-constexpr int kStageIters = (kTileRH + 31) / 32;                               // 32-row steps over the largest region
+constexpr int kStageIters = (kTileRH + kStageRows - 1) / kStageRows;           // staging steps over the largest region
 constexpr int kRowGroupIters = (kTileRH / 4 + kTileWaves - 1) / kTileWaves;   // 4-row groups per wave in the row pass
 constexpr int kColBlockRows = 16;
 constexpr int kMaxColBlocks = kTileRH / kColBlockRows;                         // 10
@@ -67,8 +69,8 @@ constexpr int kOffStamps = kOffDirs + kBatch * 8;                            // 
 constexpr int kTileLdsBytes = kOffStamps + 256;
 static_assert(kP19Wave % 16 == 0 && kOffScratch % 16 == 0 && kOffTheta % 16 == 0, "LDS carve alignment");
 static_assert(2 * kTileLdsBytes <= 160 * 1024 && kTileLdsBytes <= kTileLdsLimit, "two workgroups per CU");
-static_assert(kTileRW % 16 == 0 && kTileRH % kColBlockRows == 0 && kTileRW / 16 <= 16 && kTileThreads == 32 * 16, "region blocking");
-static_assert(kTileH + 2 * kMinHalo >= 32, "a last partial staging step can be shifted up to a full one");
+static_assert(kTileRW % 16 == 0 && kTileRH % kColBlockRows == 0 && kTileRW / 16 <= 16 && kTileThreads % 64 == 0, "region blocking");
+static_assert(kTileH + 2 * kMinHalo >= kStageRows, "a last partial staging step can be shifted up to a full one");
 static_assert(kTileStagePitch % 16 == 0 && 2 * kTileRW <= kTileStagePitch, "a region row's staged bytes fit its integral row");
 static_assert(kMaxColBlocks * kMaxQcols * 8 <= kScratchBytes, "column-block totals fit the scratch area");
 static_assert(kMaxColBlocks * kMaxQcols <= kTileThreads, "one column task per thread");
@@ -553,7 +555,8 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     if (n_tile_kp == 0) return;
 
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // the same in every lane: kept in a scalar register, and so is what is computed from it
     const int W = a.f.W, H = a.f.H;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     // integral halo of this call: the largest pattern the binning pass met, in steps of 8 pixels
@@ -604,7 +607,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
 
     // ================= stage 0: the region's gray bytes -> LDS, 16 per lane and step.  Region row r goes to LDS row
     // r + 1: `current` at byte 0, `previous` at byte kTileRW.  The 16 lanes of a lane row share a region row (as in
-    // the row pass), a workgroup takes 32 rows per step: per-lane offsets are computed once, a step moves the scalar
+    // the row pass), a workgroup takes 32 rows (kStageRows) per step: per-lane offsets are computed once, a step moves the scalar
     // base.  All loads are issued before anything waits on one (a branch per load would make the compiler drain the
     // memory queue at every join); the small tables and the first batch's keypoint records are fetched behind them.
     const int runs = RW >> 4;
@@ -618,7 +621,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             const uint32_t voff = (uint32_t)sr * (uint32_t)a.f.row_stride + 16u * (uint32_t)min(sq, runs - 1);
 #pragma unroll
             for (int u = 0; u < kStageIters; ++u) {
-                const int64_t base = (int64_t)(oy + min(32 * u, RH - 32)) * a.f.row_stride + ox;  // (a last partial step re-reads rows)
+                const int64_t base = (int64_t)(oy + min(kStageRows * u, RH - kStageRows)) * a.f.row_stride + ox;  // (a last partial step re-reads rows)
                 v[0][u] = *reinterpret_cast<const Px16 *>(cur + base + voff);
                 v[1][u] = *reinterpret_cast<const Px16 *>(prev + base + voff);
             }
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             const uint32_t xlo = (uint32_t)min(max(gx, 0), W - 8), xhi = (uint32_t)min(max(gx + 8, 0), W - 8);
 #pragma unroll
             for (int u = 0; u < kStageIters; ++u) {
-                const int gy = min(max(oy + min(32 * u, RH - 32) + sr, 0), H - 1);
+                const int gy = min(max(oy + min(kStageRows * u, RH - kStageRows) + sr, 0), H - 1);
                 const int64_t ro = (int64_t)gy * a.f.row_stride;
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
@@ -679,8 +682,8 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
         if (sq < runs) {
 #pragma unroll
             for (int u = 0; u < kStageIters; ++u) {
-                if (32 * u < RH) {  // a last partial step: the rows it re-read are written again, with the same bytes
-                    const uint32_t d = stage_lds + min(32 * u, RH - 32) * kTileStagePitch;
+                if (kStageRows * u < RH) {  // a last partial step: the rows it re-read are written again, with the same bytes
+                    const uint32_t d = stage_lds + min(kStageRows * u, RH - kStageRows) * kTileStagePitch;
                     lds_st<LdsU4>(d, LdsU4{v[0][u].w[0], v[0][u].w[1], v[0][u].w[2], v[0][u].w[3]});
                     lds_st<LdsU4>(d + kTileRW, LdsU4{v[1][u].w[0], v[1][u].w[1], v[1][u].w[2], v[1][u].w[3]});
                 }
