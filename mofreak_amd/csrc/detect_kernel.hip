@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kDetThreads) void det_score_kernel(DetArgs a, int l
         }
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // the same in every lane: a scalar
     uint8_t *score = a.score + (int64_t)p * a.dg->plane_bytes + L.off;
     uint8_t *touch = a.touch + (int64_t)p * a.dg->plane_bytes + L.off, *status = a.status + (int64_t)p * a.dg->plane_bytes + L.off;
     int32_t *row_count = a.row_count + (int64_t)p * (a.dg->total_rows + 1) + L.row_base;
@@ -356,7 +356,8 @@ __global__ __launch_bounds__(kDetThreads) void det_scan_kernel(DetArgs a)
 // one wave per layer row: the row's detections in x order, and the strict part of isMax2D (brisk.cpp:838-872)
 __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
 {
-    const int p = blockIdx.y, row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // the wave's row is the same in every lane: kept in a scalar register, and so is everything that follows from it alone
+    const int p = blockIdx.y, row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= a.dg->total_rows) return;
     int layer = 0;
     while (layer + 1 < a.dg->n_layers && row >= a.dg->L[layer + 1].row_base) ++layer;
@@ -1044,7 +1045,7 @@ __global__ __launch_bounds__(kDetThreads) void det_refine_kernel(DetArgs a)
 {
     __shared__ __attribute__((aligned(4))) uint8_t windows[kDetThreads * kWinStride];
     __shared__ int todo[kRefineChunk], wave_cnt[4], n_todo;
-    const int p = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.y, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
     const int n = ls[a.dg->n_layers], c0 = blockIdx.x * kRefineChunk;
     if (c0 >= n) return;
@@ -1347,7 +1348,7 @@ __global__ __launch_bounds__(kDetThreads) void det_emit_scan_kernel(DetArgs a, i
 __global__ __launch_bounds__(kDetThreads) void det_emit_scatter_kernel(DetArgs a)
 {
     __shared__ int wave_cnt[4], chunk_base;
-    const int p = blockIdx.y, c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.y, c = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
     const int n = ls[a.dg->n_layers];
     if (c * kEmitChunk >= n) return;

@@ -29,7 +29,7 @@ struct SmallTables {
 constexpr int kIntegralColOffset = 3;
 constexpr int kBandRows = 4;   // rows of the banded integral kernels' LDS buffer: a wave per row; 31 KB per workgroup at 1080p, five per CU
 constexpr int kBandGroup = 4;  // such slabs per band: a workgroup takes them one after the other; band totals are per band
-constexpr int kBandColIters = 10;  // 1024 columns per iteration of the column pass: pitch <= 10240 (what 160 KB of LDS allow)
+constexpr int kBandColItersMax = 10;  // 1024 columns per iteration of the column pass: pitch <= 10240 (what 160 KB of LDS allow)
 
 struct FrameArgs {
     const uint8_t *cur;

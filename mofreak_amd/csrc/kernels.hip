@@ -23,7 +23,8 @@ namespace {
 //   pass C (FINAL=true):  integral rows = band carry + running column sums, 16-byte stores
 // The u8 frames are read twice (1 B/px each time); the int32 integral is written once.
 // ------------------------------------------------------------------------------------------------
-template <bool FINAL>
+// COLS: column-pass iterations of 1024 columns the running sums are kept for (registers): 2 covers full HD
+template <bool FINAL, int COLS>
 __global__ __launch_bounds__(256) void band_kernel(IntegralArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t rp[];  // [kBandRows][pitch] row-prefix sums
@@ -33,16 +34,16 @@ __global__ __launch_bounds__(256) void band_kernel(IntegralArgs a)
     for (int item = blockIdx.x; item < a.n_bands * a.n_pairs; item += gridDim.x) {
     const int band = item % a.n_bands, pair = item / a.n_bands;
     const int W = a.f.W, pitch = a.pitch;
-    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();  // the wave index: the same in every lane, a scalar
     const uint8_t *cur = a.f.cur + (int64_t)pair * a.f.pair_stride;
     const uint8_t *prev = a.f.prev + (int64_t)pair * a.f.pair_stride;
     const int64_t bt = ((int64_t)pair * a.n_bands + band) * pitch;
     int32_t *integ = a.integral + (int64_t)pair * (a.f.H + 1) * pitch;
     // a band = kBandGroup slabs of kBandRows rows, one after the other through the same LDS buffer, the running column
     // sums staying in registers: the totals that travel through memory (and the scan over them) are per band
-    int4 acc[kBandColIters];
+    int4 acc[COLS];
 #pragma unroll
-    for (int u = 0; u < kBandColIters; ++u) {
+    for (int u = 0; u < COLS; ++u) {
         const int c4 = (threadIdx.x + 256 * u) * 4;
         acc[u] = make_int4(0, 0, 0, 0);
         if (FINAL && c4 < pitch) {
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void band_kernel(IntegralArgs a)
     __syncthreads();
 
 #pragma unroll
-    for (int u = 0; u < kBandColIters; ++u) {
+    for (int u = 0; u < COLS; ++u) {
         const int c4 = (threadIdx.x + 256 * u) * 4;
         if (c4 >= pitch) continue;
         for (int r = 0; r < rows; ++r) {
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void band_kernel(IntegralArgs a)
     }
     if (!FINAL) {
 #pragma unroll
-        for (int u = 0; u < kBandColIters; ++u) {
+        for (int u = 0; u < COLS; ++u) {
             const int c4 = (threadIdx.x + 256 * u) * 4;
             if (c4 < pitch) *reinterpret_cast<int4 *>(a.band_totals + bt + c4) = acc[u];
         }
@@ -246,7 +247,9 @@ __global__ __launch_bounds__(256, 4) void describe_kernel(DescribeArgs a)
     __syncthreads();
 
     const int lane = lane_id();
-    const int wave_in_block = threadIdx.x >> 6;
+    // the same in every lane: in a scalar register, and with it the item index, the keypoint's id and record, its pair,
+    // its ROI -- everything below that is per keypoint rather than per lane
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveScratch &ws = scratch[wave_in_block];
     const int W = a.f.W, H = a.f.H;
 
@@ -592,14 +595,16 @@ int launch_integral(const IntegralArgs &a, void *stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)std::min<int64_t>((int64_t)a.n_bands * a.n_pairs, 4096));
     const size_t lds = (size_t)kBandRows * a.pitch * sizeof(int32_t);
+    const auto first = a.pitch <= 2048 ? &band_kernel<false, 2> : a.pitch <= 4096 ? &band_kernel<false, 4> : &band_kernel<false, kBandColItersMax>;
+    const auto final = a.pitch <= 2048 ? &band_kernel<true, 2> : a.pitch <= 4096 ? &band_kernel<true, 4> : &band_kernel<true, kBandColItersMax>;
     if (lds > 64 * 1024) {  // more than the default dynamic-LDS limit: opt in (a CU has 160 KiB)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&band_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&band_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(first), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(final), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    hipLaunchKernelGGL(band_kernel<false>, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(first, grid, dim3(256), lds, s, a);
     hipLaunchKernelGGL(band_scan_kernel, dim3((a.pitch + 255) / 256, a.n_pairs), dim3(256), 0, s, a.band_totals,
                        a.pitch, a.n_bands, a.gate);
-    hipLaunchKernelGGL(band_kernel<true>, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(final, grid, dim3(256), lds, s, a);
     return (int)hipGetLastError();
 }
 
