@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kBowThreads) void bow_assign_kernel(const uint8_t *
                                                                  unsigned int *counts)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];  // two stages of codeword tiles
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave index: a scalar
     const int col = lane & 31, g = lane >> 5;
     const int n_stages = n_tiles / kBowStageTiles;  // n_tiles is a multiple of kBowStageTiles (launcher)
     const uint4 *src = reinterpret_cast<const uint4 *>(expanded);
