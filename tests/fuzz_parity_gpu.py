@@ -39,6 +39,7 @@ def main():
                 frames = synth.synth_stack(n_pairs + 5, W, H)
             kps = synth.random_keypoints(rng, n_kp, W, H, sizes=sizes, integer_xy=integer_xy)
             desc, valid = ctx.extract_pairs_host(frames[5:], frames[:n_pairs], kps)
+            ctx.check_status()  # (the bounds-checking library reports an access outside its limits here)
             for p in range(n_pairs):
                 d, v = f.extract_pair(frames[5 + p], frames[p], kps)
                 got_d, got_v = desc[p * n_kp:(p + 1) * n_kp], valid[p * n_kp:(p + 1) * n_kp]
