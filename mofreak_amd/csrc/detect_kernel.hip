@@ -358,9 +358,12 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
 {
     // the wave's row is the same in every lane: kept in a scalar register, and so is everything that follows from it alone
     const int p = blockIdx.y, row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= a.dg->total_rows) return;
+    if (row >= a.g.total_rows) return;
+    // which layer the row belongs to: from the argument block's copy of the geometry with constant indices (scalar
+    // registers, no memory) -- the same search on the device copy is a chain of dependent loads
     int layer = 0;
-    while (layer + 1 < a.dg->n_layers && row >= a.dg->L[layer + 1].row_base) ++layer;
+#pragma unroll
+    for (int k = 1; k < kDetMaxLayers; ++k) layer += (k < a.g.n_layers && row >= a.g.L[k].row_base) ? 1 : 0;
     const DetLayer L = a.dg->L[layer];
     const int y = row - L.row_base;
     if (y < 3 || y >= L.h - 3) return;
