@@ -2,7 +2,8 @@
 """Randomised parity run, GPU against the oracle (a tool, not part of the test suites: `python tests/fuzz_parity_gpu.py
 [seconds] [seed]` on a GPU box).  Every round draws a frame size, a keypoint population (counts, sizes, integer or
 fractional coordinates, shared list or one list per pair), random byte frames or the synthetic ones, and compares
-descriptors and validity flags byte for byte; every few rounds also the detector's keypoints on a moving-object pair."""
+descriptors and validity flags byte for byte; every few rounds also the detector's keypoints on a moving-object pair.
+A new context every 20 s, a third of them with random FREAK parameters (bit mode, orientation / scale normalisation)."""
 import os
 import sys
 import time
@@ -22,45 +23,54 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
-    f = O.Freak()
     t_end = time.time() + budget
     rounds = descriptors = detector_rounds = 0
-    with M.Context(0) as ctx:
-        while time.time() < t_end:
-            W = int(rng.choice([97, 160, 203, 320, 417, 640, 731, 1024, 1283]))
-            H = int(rng.choice([80, 121, 240, 301, 480, 577]))
-            n_pairs = int(rng.integers(1, 4))
-            n_kp = int(rng.choice([1, 7, 60, 400, 2500, 9000]))
-            sizes = [(7.0, 9.0, 12.0), (8.4, 12.0, 18.0, 27.0, 40.5), (12.0,), (13.3, 14.9, 15.2, 22.7, 31.0, 55.5, 71.9), (6.9, 100.0)][int(rng.integers(0, 5))]
-            integer_xy = bool(rng.integers(0, 2))
-            if rng.integers(0, 2):
-                frames = rng.integers(0, 256, (n_pairs + 5, H, W), dtype=np.uint8)
-            else:
-                frames = synth.synth_stack(n_pairs + 5, W, H)
-            kps = synth.random_keypoints(rng, n_kp, W, H, sizes=sizes, integer_xy=integer_xy)
-            desc, valid = ctx.extract_pairs_host(frames[5:], frames[:n_pairs], kps)
-            ctx.check_status()  # (the bounds-checking library reports an access outside its limits here)
-            for p in range(n_pairs):
-                d, v = f.extract_pair(frames[5 + p], frames[p], kps)
-                got_d, got_v = desc[p * n_kp:(p + 1) * n_kp], valid[p * n_kp:(p + 1) * n_kp]
-                if not (np.array_equal(got_v, v) and np.array_equal(got_d, d)):
-                    bad = np.nonzero((got_d != d).any(1) | (got_v != v))[0]
-                    print(f"MISMATCH round {rounds} seed {seed}: {W}x{H} pairs {n_pairs} kp {n_kp} sizes {sizes} integer {integer_xy}: "
-                          f"{len(bad)} keypoints, first {bad[:5]}, kp {kps[bad[0]]}")
-                    sys.exit(1)
-            rounds += 1
-            descriptors += n_pairs * n_kp
-            if rounds % 5 == 0:
-                Wd, Hd = int(rng.choice([160, 320, 481, 640])), int(rng.choice([120, 240, 360]))
-                fr = synth.moving_objects_stack(6, Wd, Hd, seed=int(rng.integers(0, 1 << 30)))
-                octaves = int(rng.integers(0, 4))
-                k, offs, resp, layer = ctx.detect_pairs_host(fr[5], fr[0], 30, octaves)
-                want = O.brisk_detect(O.absdiff(fr[5], fr[0]), 30, octaves)
-                wk = np.stack([want["x"], want["y"], want["size"]], 1).astype(np.float32).reshape(-1, 3)
-                if not (len(k) == len(wk) and k.tobytes() == wk.tobytes() and resp.tobytes() == want["response"].tobytes()):
-                    print(f"DETECTOR MISMATCH round {rounds} seed {seed}: {Wd}x{Hd} octaves {octaves}: {len(k)} vs {len(wk)} keypoints")
-                    sys.exit(1)
-                detector_rounds += 1
+    while time.time() < t_end:
+        # a context (and an oracle) per parameter set: the default one most of the time
+        if rng.integers(0, 3) == 0:
+            par = dict(freak_bit_mode=int(rng.integers(0, 3)), freak_orientation_normalized=int(rng.integers(0, 2)),
+                       freak_scale_normalized=int(rng.integers(0, 2)))
+        else:
+            par = {}
+        f = O.Freak(orientation_normalized=bool(par.get("freak_orientation_normalized", 1)),
+                    scale_normalized=bool(par.get("freak_scale_normalized", 1)), bit_mode=par.get("freak_bit_mode", O.BITS_SSE))
+        t_ctx = min(t_end, time.time() + 20)
+        with M.Context(0, **par) as ctx:
+          while time.time() < t_ctx:
+              W = int(rng.choice([97, 160, 203, 320, 417, 640, 731, 1024, 1283]))
+              H = int(rng.choice([80, 121, 240, 301, 480, 577]))
+              n_pairs = int(rng.integers(1, 4))
+              n_kp = int(rng.choice([1, 7, 60, 400, 2500, 9000]))
+              sizes = [(7.0, 9.0, 12.0), (8.4, 12.0, 18.0, 27.0, 40.5), (12.0,), (13.3, 14.9, 15.2, 22.7, 31.0, 55.5, 71.9), (6.9, 100.0)][int(rng.integers(0, 5))]
+              integer_xy = bool(rng.integers(0, 2))
+              if rng.integers(0, 2):
+                  frames = rng.integers(0, 256, (n_pairs + 5, H, W), dtype=np.uint8)
+              else:
+                  frames = synth.synth_stack(n_pairs + 5, W, H)
+              kps = synth.random_keypoints(rng, n_kp, W, H, sizes=sizes, integer_xy=integer_xy)
+              desc, valid = ctx.extract_pairs_host(frames[5:], frames[:n_pairs], kps)
+              ctx.check_status()  # (the bounds-checking library reports an access outside its limits here)
+              for p in range(n_pairs):
+                  d, v = f.extract_pair(frames[5 + p], frames[p], kps)
+                  got_d, got_v = desc[p * n_kp:(p + 1) * n_kp], valid[p * n_kp:(p + 1) * n_kp]
+                  if not (np.array_equal(got_v, v) and np.array_equal(got_d, d)):
+                      bad = np.nonzero((got_d != d).any(1) | (got_v != v))[0]
+                      print(f"MISMATCH round {rounds} seed {seed}: {W}x{H} pairs {n_pairs} kp {n_kp} sizes {sizes} integer {integer_xy}: "
+                            f"{len(bad)} keypoints, first {bad[:5]}, kp {kps[bad[0]]}")
+                      sys.exit(1)
+              rounds += 1
+              descriptors += n_pairs * n_kp
+              if rounds % 5 == 0:
+                  Wd, Hd = int(rng.choice([160, 320, 481, 640])), int(rng.choice([120, 240, 360]))
+                  fr = synth.moving_objects_stack(6, Wd, Hd, seed=int(rng.integers(0, 1 << 30)))
+                  octaves = int(rng.integers(0, 4))
+                  k, offs, resp, layer = ctx.detect_pairs_host(fr[5], fr[0], 30, octaves)
+                  want = O.brisk_detect(O.absdiff(fr[5], fr[0]), 30, octaves)
+                  wk = np.stack([want["x"], want["y"], want["size"]], 1).astype(np.float32).reshape(-1, 3)
+                  if not (len(k) == len(wk) and k.tobytes() == wk.tobytes() and resp.tobytes() == want["response"].tobytes()):
+                      print(f"DETECTOR MISMATCH round {rounds} seed {seed}: {Wd}x{Hd} octaves {octaves}: {len(k)} vs {len(wk)} keypoints")
+                      sys.exit(1)
+                  detector_rounds += 1
     print(f"fuzz ok: {rounds} rounds, {descriptors} descriptors, {detector_rounds} detector rounds, seed {seed}")
 
 
