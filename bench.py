@@ -23,6 +23,7 @@ import json
 import math
 import os
 import sys
+import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -30,6 +31,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+from mofreak_amd import launch  # noqa: E402  (no GPU call, no torch: safe in the parent of the rank processes)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 PCIE_GBS = 63.0        # host link, same guide
@@ -48,17 +51,63 @@ def make_stack(T, W, H, t0, workers):
     return out
 
 
-def cpu_baselines(frames, kps, n_pairs, cores, shape):
+class Verifier:
+    """Checks the descriptors the timed steps left in HBM against the CPU oracle, pair by pair: the bench line proves
+    its bytes (`verified`), not only its flags.  The oracle is the checker here, never the thing measured."""
+
+    def __init__(self, desc, valid, n_kp):
+        self.desc, self.valid, self.n_kp = desc, valid, n_kp  # device tensors of the last timed step
+        self.pairs = self.descriptors = self.mismatches = 0
+        self.host = {}
+        self.lock = threading.Lock()  # check() is called from the baseline's worker threads
+
+    def fetch(self, pairs):
+        """One device-to-host copy per pair that will be compared."""
+        for p in pairs:
+            sl = slice(p * self.n_kp, (p + 1) * self.n_kp)
+            self.host[p] = (self.desc[sl].cpu().numpy(), self.valid[sl].cpu().numpy())
+
+    def check(self, p, want_desc, want_valid):
+        got_d, got_v = self.host.pop(p)
+        bad = int((got_v != want_valid).sum()) + int((got_d != want_desc).any(axis=1).sum())
+        with self.lock:
+            self.pairs += 1
+            self.descriptors += len(want_valid)
+            self.mismatches += bad
+
+    def report(self):
+        return {"pairs": self.pairs, "descriptors": self.descriptors, "mismatches": self.mismatches,
+                "against": "oracle/mofreak_oracle.c on the same frames and keypoints, 16 bytes + validity flag per keypoint"}
+
+
+def verify_sample(ver, frames, kps, pairs):
+    """No cpu_baseline leg (N > 1, --no-cpu-baseline): the oracle on a few pairs of this rank's stack."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    f = oracle_lib.Freak()
+    ver.fetch(pairs)
+    for p in pairs:
+        d, v = f.extract_pair(frames[p + 5], frames[p], kps)
+        ver.check(p, d, v)
+
+
+def cpu_baselines(frames, kps, n_pairs, cores, shape, ver=None):
     """The CPU oracle (a port, not the reference binary) on bounded samples of the same workload: all host cores, one
     thread, and one thread with the FREAK pattern tables rebuilt for every frame pair as the reference does by
-    constructing cv::FREAK inside its frame loop (MoFREAKUtilities.cpp:427)."""
+    constructing cv::FREAK inside its frame loop (MoFREAKUtilities.cpp:427).  The descriptors of the first leg are
+    not thrown away: `ver` compares each pair's with what the GPU wrote for it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     f = oracle_lib.Freak()
     f.extract_pair(frames[5], frames[0], kps[:64])  # warm the library
+    if ver is not None:
+        ver.fetch(range(n_pairs))
+    first_leg = [True]
 
     def one(p):
         d, v = f.extract_pair(frames[p + 5], frames[p], kps)  # ctypes releases the GIL
+        if ver is not None and first_leg[0]:
+            ver.check(p, d, v)
         return int(v.sum())
 
     def one_ref(p):
@@ -73,6 +122,7 @@ def cpu_baselines(frames, kps, n_pairs, cores, shape):
     dt = time.perf_counter() - t
     out = {"cpu_baseline": {"value": n / dt, "unit": "descriptors/s", "cores": cores, "kind": "port",
                             "sample": f"{n_pairs} of {what}, {cores} threads over pairs, {dt:.1f} s wall"}}
+    first_leg[0] = False
     # one thread: a sample sized from the rate just measured, about 4 s each
     per_pair_1t = dt * cores / max(n_pairs, 1)
     n1 = int(min(n_pairs, max(2, round(4.0 / max(per_pair_1t, 1e-3)))))
@@ -155,9 +205,13 @@ def dist_setup(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if world != args.gpus:  # main() starts the ranks itself when nobody else has; this is a launcher of someone else's
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus disagree")
     if args.share_device:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible "
+                         "(one process per GPU; --share-device rehearses N > 1 on one)")
     torch.cuda.set_device(local_rank)
     on_device = args.backend == "nccl"  # gloo moves its (small) control tensors and the gathered rows through the host
     if world > 1:
@@ -165,7 +219,25 @@ def dist_setup(args):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+        assert dist.get_world_size() == world
     return torch, dist, rank, local_rank, world, on_device
+
+
+def library_id(M):
+    """Which build produced the line: the in-tree library only (no MOFREAK_HIP_LIBRARY override in a bench run)."""
+    import hashlib
+    path = M.api.LIB_PATH
+    want = os.path.join(ROOT, "mofreak_amd", "libmofreak_hip.so")
+    if os.path.realpath(path) != os.path.realpath(want):
+        raise SystemExit(f"bench.py measures the in-tree build {want}, not {path} (unset MOFREAK_HIP_LIBRARY)")
+    with open(path, "rb") as f:
+        return {"path": os.path.relpath(path, ROOT), "sha256_16": hashlib.sha256(f.read()).hexdigest()[:16],
+                "build_flags": M.load().mofreak_build_flags()}
+
+
+def ranks_seen(dist, world):
+    """What the process group itself says (not the flag): goes into every line."""
+    return dist.get_world_size() if world > 1 else 1
 
 
 def fence(torch, dist, world):
@@ -238,8 +310,18 @@ def bench_resident(args):
     ctx.check_status()
     elapsed = max_over_ranks(torch, dist, world, on_device, elapsed)
     n_valid = int(valid.sum().item())
-    if os.environ.get("MOFREAK_BENCH_ABLATION") != "1":  # ablation builds of the kernel skip stages on purpose
-        assert n_valid == n_desc, f"{n_desc - n_valid} keypoints were erased: the grid is supposed to be border-safe"
+    assert n_valid == n_desc, f"{n_desc - n_valid} keypoints were erased: the grid is supposed to be border-safe"
+    # every rank proves the bytes of its last timed step against the oracle: rank 0 at N = 1 on all the pairs of the
+    # cpu_baseline leg (below), otherwise on a few pairs spread over the stack
+    ver = Verifier(desc, valid, n_kp)
+    full_leg = world == 1 and not args.no_cpu_baseline
+    if not full_leg:
+        verify_sample(ver, frames, kps, sorted({0, n_pairs // 3, (2 * n_pairs) // 3, n_pairs - 1})[: max(1, args.verify_pairs)])
+    ver_all = [ver.pairs, ver.descriptors, ver.mismatches]
+    if world > 1:  # the line carries the sum over ranks
+        t = torch.tensor(ver_all, dtype=torch.int64, device="cuda" if on_device else "cpu")
+        dist.all_reduce(t)
+        ver_all = [int(x) for x in t.tolist()]
 
     # the path's one exchange step: gather the compacted 32-byte rows to rank 0 (not part of a step)
     rows = torch.empty(n_desc * 32, dtype=torch.uint8, device="cuda")
@@ -305,11 +387,14 @@ def bench_resident(args):
                          "binning_avg_ms": prof["bin_ms"] / launches, "gather_path_avg_ms": prof["gather_ms"] / launches,
                          "pipeline_achieved_GBs": pipeline_gbs, "pipeline_frac": pipeline_gbs / HBM_PEAK_GBS,
                          "valu_issue": valu},
-            "gather_ms": gather_ms,
+            "gather_ms": gather_ms, "ranks_seen": ranks_seen(dist, world), "library": library_id(M),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if full_leg:
             cp = min(args.cpu_pairs, n_pairs)
-            out.update(cpu_baselines(frames, kps, cp, cores=min(ncpu, 16), shape=f"{W}x{H}"))
+            out.update(cpu_baselines(frames, kps, cp, cores=min(ncpu, 16), shape=f"{W}x{H}", ver=ver))
+            ver_all = [ver.pairs, ver.descriptors, ver.mismatches]
+        out["verified"] = dict(ver.report(), pairs=ver_all[0], descriptors=ver_all[1], mismatches=ver_all[2])
+        failed = ver_all[2] != 0
         if world == 1 and not args.no_detector and args.config == "C3":
             # Outside the metric and its timed region: the row in front of the path, for the record.
             try:
@@ -325,6 +410,8 @@ def bench_resident(args):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and failed:
+        raise SystemExit(f"bench: {ver_all[2]} descriptors differ from the oracle")
 
 
 # ------------------------------------------------------------------------------------------------ C4: a dataset of clips
@@ -346,13 +433,14 @@ def bench_dataset(args):
         pool = pinned
     clips = [pool[i % len(pool)][: lengths[i]] for i in range(n_clips)]
     names = [f"clip{i:05d}.avi" for i in range(n_clips)]
-    harness.run_dataset(clips[: 4 * world * args.workers], names[: 4 * world * args.workers], None, mo, rank, world, on_device=on_device,
-                        workers=args.workers)  # warm-up
+    batched = not args.per_clip_calls
+    harness.run_dataset(clips[: 64 * world], names[: 64 * world], None, mo, rank, world, on_device=on_device,
+                        workers=args.workers, batched=batched)  # warm-up
     steps = args.steps or 1
     fence(torch, dist, world)
     t0 = time.perf_counter()
     for _ in range(steps):
-        res = harness.run_dataset(clips, names, None, mo, rank, world, on_device=on_device, workers=args.workers)
+        res = harness.run_dataset(clips, names, None, mo, rank, world, on_device=on_device, workers=args.workers, batched=batched)
     fence(torch, dist, world)
     elapsed = max_over_ranks(torch, dist, world, on_device, time.perf_counter() - t0)
     gather_s = max_over_ranks(torch, dist, world, on_device, res["gather_s"])
@@ -368,9 +456,13 @@ def bench_dataset(args):
             "config": {"workload": f"C4: {n_clips} clips {W}x{H}, seeded log-normal lengths {int(lengths.min())}..{int(lengths.max())} "
                                    f"frames (median {int(np.median(lengths))}), dense {cfg['step']}-px grid, {n_kp} keypoints/pair",
                        "descriptors_per_step": n_desc,
-                       "parallelism": f"LPT shard of whole clips over {world} rank(s), {args.workers} host thread(s) with a context each per rank"},
-            "gather_ms": gather_s * 1e3, "frames_in_MB_per_step": float(lengths.sum() * W * H / 1e6),
-            "note": f"host frames in ({'pageable' if args.pageable else 'page-locked'} memory), rows back: every clip is one synchronous C-ABI call (mofreak_extract_stream)"}), flush=True)
+                       "parallelism": f"LPT shard of whole clips over {world} rank(s); " + (
+                           "every rank's clips in ONE pipelined mofreak_extract_clips call, rows gathered device to device" if res["batched"]
+                           else f"{args.workers} host thread(s) with a context each per rank, one synchronous C-ABI call per clip")},
+            "frames_in_GBs": float(lengths.sum() * W * H * steps / elapsed / 1e9),
+            "gather_ms": gather_s * 1e3, "ranks_seen": ranks_seen(dist, world), "frames_in_MB_per_step": float(lengths.sum() * W * H / 1e6),
+            "note": f"host frames in ({'pageable' if args.pageable else 'page-locked'} memory) -> rows on rank 0's host; "
+                    "compute, gather and the root's device-to-host copy are all inside the timed region"}), flush=True)
     mo.close()
     if world > 1:
         dist.barrier()
@@ -435,7 +527,7 @@ def bench_stream(args):
             "config": {"workload": f"C5: one {W}x{H} stream of {T} frames per GPU from page-locked host memory, dense {cfg['step']}-px grid, "
                                    f"{len(kps)} keypoints/frame, chunks of {args.chunk} frames", "descriptors_per_step_per_gpu": n_desc,
                        "parallelism": f"one stream per GPU x{world}"},
-            "frames_per_s": world * (T - 5) * steps / elapsed, "resident_descriptors_per_s": resident,
+            "ranks_seen": ranks_seen(dist, world), "frames_per_s": world * (T - 5) * steps / elapsed, "resident_descriptors_per_s": resident,
             "pcie_bound_descriptors_per_s": pcie_bound, "frac_of_min_bound": value / world / min(pcie_bound, resident),
             "h2d_GBs": (T * W * H * steps / elapsed) / 1e9, "d2h_GBs": (n_desc * 32 * steps / elapsed) / 1e9}), flush=True)
     ctx.host_free(frames)
@@ -458,6 +550,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=256, help="C5: frames per pipelined chunk")
     ap.add_argument("--clips", type=int, default=512, help="C4: clips in the batch (HMDB51 has 6766)")
     ap.add_argument("--workers", type=int, default=4, help="C4: host threads per rank, each with a context of its own, taking the rank's clips in turn")
+    ap.add_argument("--per-clip-calls", action="store_true", help="C4: one synchronous mofreak_extract_stream call per clip (round 2's path) instead of "
+                    "one mofreak_extract_clips call per rank")
     ap.add_argument("--pageable", action="store_true", help="C4: clips in ordinary (pageable) host memory instead of page-locked buffers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=192, help="pairs of the workload the CPU oracle is timed on (about 25 core-seconds)")
@@ -465,7 +559,14 @@ def main():
                     "--share-device rehearses the N > 1 control flow on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
     ap.add_argument("--no-detector", action="store_true", help="skip the (untimed-region) keypoint detector figures")
+    ap.add_argument("--verify-pairs", type=int, default=4, help="pairs per rank checked against the oracle when there is no "
+                    "cpu_baseline leg (N > 1, --no-cpu-baseline); with the leg, all of its pairs are checked")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="N > 1 started by this script: seconds before the ranks are stopped")
     args = ap.parse_args()
+    if args.gpus > 1 and not launch.launched_by_a_launcher():
+        # `python bench.py --gpus N` by itself: N fresh rank processes, started before this one has made any GPU call
+        # (it never makes one); rank 0's line is the job's, a failing rank fails the job.
+        raise SystemExit(launch.self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:], timeout_s=args.launch_timeout))
     if args.config in ("C2", "C3"):
         bench_resident(args)
     elif args.config == "C4":

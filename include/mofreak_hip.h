@@ -45,6 +45,7 @@ extern "C" {
 /* flags */
 #define MOFREAK_MEM_DEVICE 0u
 #define MOFREAK_MEM_HOST 1u
+#define MOFREAK_ROWS_DEVICE 2u /* mofreak_extract_clips: rows_out is a device pointer (frames and keypoints stay host pointers) */
 
 /* FREAK pair-bit layout; OpenCV 2.4.2's binary is not available to pin it */
 #define MOFREAK_BITS_SSE 0        /* v[i] >= v[j], SSE byte order: OpenCV >= 2.4.3, and 2.4.2 built with CV_SSE2 */
@@ -186,14 +187,39 @@ int mofreak_extract_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W
  * list of n_kp keypoints for every processed frame) and rows_out are HOST pointers; frames / rows_out in memory
  * from mofreak_host_alloc (page-locked) are copied by DMA straight from / to the caller's buffer, any other host
  * memory goes through the library's own page-locked staging buffers (one more host copy).  Rows are those of
- * mofreak_extract_stream on the whole stack, byte for byte.  chunk_frames <= gap selects a default (256).
+ * mofreak_extract_stream on the whole stack, byte for byte.  chunk_frames <= gap selects a default (256).  Returns only
+ * after every copy from / to the caller's buffers has finished (on errors too); on MOFREAK_ERR_CAPACITY *n_rows_out holds
+ * the number of rows a retry needs.
  */
 int mofreak_extract_stream_pipelined(mofreak_ctx *ctx, const uint8_t *frames, int T, int W, int H, int chunk_frames,
                                      const mofreak_keypoint *kps, int64_t n_kp, mofreak_row *rows_out,
                                      int64_t rows_capacity, int64_t *n_rows_out);
+/*
+ * Many videos in one call: the body of the dataset loop of computeMoFREAKFiles (main.cpp:862-921), which hands one video
+ * at a time to computeMoFREAKFromFile (MoFREAKUtilities.cpp:374-498), for n_clips decoded videos at once.  Clip c is
+ * clip_n_frames[c] contiguous W x H gray frames at clip_frames[c] (HOST pointers; page-locked memory from
+ * mofreak_host_alloc is copied by DMA straight from the caller's buffer, other memory through the library's page-locked
+ * staging).  Every clip is treated exactly as mofreak_extract_stream treats a stack -- pairs never cross a clip boundary,
+ * frame numbers restart at gap - 1 in every clip (:401, :488), clips of <= gap frames yield no rows -- but the clips
+ * share the launches and the three-stream pipeline of mofreak_extract_stream_pipelined (copies of the next window of
+ * frames under the kernels of this one, rows of the previous one on their way back), so that short clips cost bandwidth,
+ * not one synchronous round trip each.  kps: one shared list of n_kp keypoints for every processed frame (host pointer).
+ *
+ *   rows_out               rows of clip 0, then clip 1, ... (inside a clip: frames ascending, keypoints in input order):
+ *                          a HOST pointer, or with MOFREAK_ROWS_DEVICE in flags a DEVICE pointer (rows stay in HBM, e.g.
+ *                          for the RCCL gather to the root rank)
+ *   clip_row_offsets_out   optional, n_clips + 1 host integers: rows of clip c are [offsets[c], offsets[c + 1])
+ *   n_rows_out             total rows; more than rows_capacity: MOFREAK_ERR_CAPACITY, nothing beyond the capacity is
+ *                          written and *n_rows_out holds the size a retry needs
+ *   chunk_frames <= gap    selects a default window (about 96 MiB of frames)
+ * Returns only after every copy from / to the caller's buffers has finished, on errors too.
+ */
+int mofreak_extract_clips(mofreak_ctx *ctx, const uint8_t *const *clip_frames, const int32_t *clip_n_frames, int n_clips,
+                          int W, int H, int chunk_frames, const mofreak_keypoint *kps, int64_t n_kp, mofreak_row *rows_out,
+                          int64_t rows_capacity, int64_t *clip_row_offsets_out, int64_t *n_rows_out, unsigned flags);
 /* Page-locked host memory for frames decoded by the caller and for rows (hipHostMalloc / hipHostFree). */
 int mofreak_host_alloc(mofreak_ctx *ctx, size_t bytes, void **out);
-int mofreak_host_free(mofreak_ctx *ctx, void *ptr);
+int mofreak_host_free(mofreak_ctx *ctx, void *ptr); /* ctx may be NULL: the memory may outlive its context */
 
 /* ------------------------------------------------------------------ frame preparation */
 /* cv::cvtColor(frame, frame, CV_BGR2GRAY) on 8UC3 frames (MoFREAKUtilities.cpp:395, :410): interleaved B,G,R bytes,

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -17,7 +18,7 @@ LIB_PATH = os.environ.get("MOFREAK_HIP_LIBRARY") or os.path.join(PKG_DIR, "libmo
 
 OK = 0
 ERR_BAD_ARG, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_ROI, ERR_CAPACITY = -1, -2, -3, -4, -5, -6, -7
-MEM_DEVICE, MEM_HOST = 0, 1
+MEM_DEVICE, MEM_HOST, ROWS_DEVICE = 0, 1, 2
 BITS_SSE, BITS_NATURAL, BITS_SSE_SIGNED = 0, 1, 2
 TABLES_ONLY = -1
 PATH_AUTO, PATH_GATHER = 0, 1
@@ -33,7 +34,7 @@ EXPORTS = [
     "mofreak_set_stream", "mofreak_synchronize", "mofreak_reserve", "mofreak_check_status",
     "mofreak_set_profiling", "mofreak_get_profile", "mofreak_set_path", "mofreak_get_tile_stamps", "mofreak_bgr_to_gray", "mofreak_bow_assign", "mofreak_bow_histogram",
     "mofreak_extract_pairs", "mofreak_compact_rows", "mofreak_extract_stream", "mofreak_format_rows",
-    "mofreak_extract_stream_pipelined", "mofreak_host_alloc", "mofreak_host_free",
+    "mofreak_extract_stream_pipelined", "mofreak_extract_clips", "mofreak_host_alloc", "mofreak_host_free",
     "mofreak_parse_rows", "mofreak_diff_integral", "mofreak_mip19", "mofreak_roi19", "mofreak_freak_info",
     "mofreak_theta_index", "mofreak_pattern_sizes", "mofreak_scale_index", "mofreak_table_pattern",
     "mofreak_table_orientation", "mofreak_table_bit_pairs", "mofreak_table_resize",
@@ -60,6 +61,11 @@ class MoFREAKError(RuntimeError):
 
 
 _lib = None
+_PINNED: dict = {}  # address of a host_alloc() array -> the finalizer that releases its pages
+
+
+def _free_pinned(lib, address: int) -> None:
+    lib.mofreak_host_free(None, C.c_void_p(address))  # ctx NULL: page-locked memory outlives the context it came from
 
 
 def load() -> C.CDLL:
@@ -112,6 +118,7 @@ def load() -> C.CDLL:
     L.mofreak_compact_rows.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, i64, C.POINTER(i64), C.c_uint]
     L.mofreak_extract_stream.argtypes = [vp, vp, i32, i32, i32, vp, vp, i64, vp, i64, C.POINTER(i64), C.c_uint]
     L.mofreak_extract_stream_pipelined.argtypes = [vp, vp, i32, i32, i32, i32, vp, i64, vp, i64, C.POINTER(i64)]
+    L.mofreak_extract_clips.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, i64, vp, i64, vp, C.POINTER(i64), C.c_uint]
     L.mofreak_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.mofreak_host_free.argtypes = [vp, vp]
     L.mofreak_format_rows.argtypes = [vp, i64, vp, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -197,9 +204,6 @@ class Context:
         if getattr(self, "_h", None):
             for st in list(self._streams):  # a stream must be closed before its context (mofreak_hip.h)
                 st.close()
-            for p in list(self._pinned.values()):
-                self._lib.mofreak_host_free(self._h, C.c_void_p(p))
-            self._pinned.clear()
             self._lib.mofreak_destroy(self._h)
             self._h = None
 
@@ -466,20 +470,57 @@ class Context:
 
     def host_alloc(self, shape, dtype=np.uint8) -> np.ndarray:
         """A page-locked host array (mofreak_host_alloc): frames decoded into it, or rows received into it, move by DMA
-        straight from / to it in extract_stream_pipelined.  Free it with host_free (or let the context's close do it)."""
+        straight from / to it in extract_stream_pipelined / extract_clips.  The memory belongs to the ARRAY, not to the
+        context: it is released when the last view of it is gone (or by host_free), never by close() under a live view."""
         dtype = np.dtype(dtype)
         n = int(np.prod(shape)) * dtype.itemsize
         p = C.c_void_p()
         self._check(self._lib.mofreak_host_alloc(self._h, n, C.byref(p)))
         buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
         arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
-        self._pinned[arr.ctypes.data] = p.value
+        # every view of arr keeps `buf` alive through its base chain; when buf goes, the pages go
+        fin = weakref.finalize(buf, _free_pinned, self._lib, p.value)
+        _PINNED[arr.ctypes.data] = fin
         return arr
 
     def host_free(self, arr: np.ndarray) -> None:
-        p = self._pinned.pop(arr.ctypes.data, None)
-        if p is not None and self._h:
-            self._check(self._lib.mofreak_host_free(self._h, C.c_void_p(p)))
+        """Release a host_alloc() array now (the caller promises that no view of it is used afterwards)."""
+        fin = _PINNED.pop(arr.ctypes.data, None)
+        if fin is not None:
+            fin()
+
+    def extract_clips(self, clips, kps: np.ndarray, chunk_frames: int = 0, rows_out=None):
+        """Many gray stacks (each (T_c, H, W) u8, C-contiguous, same H x W) in one pipelined pass: mofreak_extract_clips.
+        rows_out: None (a new numpy array), a numpy ROW_DTYPE array (page-locked from host_alloc: DMA in place), or a
+        torch uint8 CUDA tensor (rows stay on the device, 32 bytes each).  Returns (rows or row count, clip_row_offsets):
+        rows of clip c are rows[offsets[c]:offsets[c + 1]]; with a device tensor the first item is the number of rows."""
+        n = len(clips)
+        kps = np.ascontiguousarray(kps, np.float32).reshape(-1, 3)
+        gap = self.params.gap_for_frame_difference
+        H, W = (clips[0].shape[1], clips[0].shape[2]) if n else (1, 1)
+        ptrs = (C.c_void_p * max(n, 1))()
+        counts = np.zeros(max(n, 1), np.int32)
+        for i, c in enumerate(clips):
+            assert c.dtype == np.uint8 and c.ndim == 3 and c.flags.c_contiguous and c.shape[1:] == (H, W), "clip: (T, H, W) uint8, C-contiguous"
+            ptrs[i] = c.ctypes.data
+            counts[i] = c.shape[0]
+        cap = int(sum(max(int(t) - gap, 0) for t in counts[:n])) * kps.shape[0]
+        on_device = rows_out is not None and not isinstance(rows_out, np.ndarray)
+        if on_device:
+            assert rows_out.is_cuda and rows_out.is_contiguous() and rows_out.element_size() == 1
+            rows_ptr, rows_cap = C.c_void_p(rows_out.data_ptr()), rows_out.numel() // 32
+        else:
+            rows = rows_out if rows_out is not None else np.zeros(max(cap, 1), ROW_DTYPE)
+            assert rows.dtype == ROW_DTYPE and rows.flags.c_contiguous
+            rows_ptr, rows_cap = _ptr(rows), rows.shape[0]
+        offs = np.zeros(n + 1, np.int64)
+        total = C.c_int64(0)
+        self._check(self._lib.mofreak_extract_clips(self._h, C.cast(ptrs, C.c_void_p), _ptr(counts), n, W, H, chunk_frames, _ptr(kps),
+                                                    kps.shape[0], rows_ptr, rows_cap, _ptr(offs), C.byref(total),
+                                                    ROWS_DEVICE if on_device else 0))
+        if on_device:
+            return total.value, offs
+        return (rows[:total.value] if rows_out is not None else rows[:total.value].copy()), offs
 
     def extract_stream_pipelined_host(self, frames: np.ndarray, kps: np.ndarray, chunk_frames: int = 256,
                                       rows_out: np.ndarray | None = None) -> np.ndarray:

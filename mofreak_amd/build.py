@@ -24,10 +24,10 @@ def hipcc() -> str:
     return exe
 
 
-def is_stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+def is_stale(lib: str = LIB_PATH) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
@@ -35,6 +35,8 @@ def build_native(force: bool = False, verbose: bool = False, debug: bool = False
     """Compile the shared library if it is missing or older than its sources; returns its path.
     debug=True: the bounds-checking build of the same sources (tests only; never what api.load() picks up)."""
     if debug:
+        if not force and not is_stale(DEBUG_LIB_PATH):
+            return DEBUG_LIB_PATH
         cmd = [hipcc(), *FLAGS, "-DMOFREAK_DEBUG_BOUNDS", "-o", DEBUG_LIB_PATH, *[os.path.join(CSRC, s) for s in SOURCES]]
         if verbose:
             print(" ".join(cmd))

@@ -38,7 +38,7 @@ struct mofreak_ctx {
     // workspace (grown on demand, never shrunk)
     DeviceBuffer integral, band_totals, scratch_desc, scratch_valid, compact_offsets, stage[6], offsets_dev;
     DeviceBuffer kp_key, sorted_idx, slow_list, slow_count;  // keypoint binning (slow_count: all its counters, BinArgs)
-    DeviceBuffer bow_counts, bow_expanded;
+    DeviceBuffer bow_counts, bow_expanded, pair_label;
     // keypoint detector workspace
     DeviceBuffer det_img, det_score, det_touch, det_status, det_rows, det_cand_xy, det_cand_flag, det_cand_emit, det_cand_spec, det_cand_asked, det_cand_win, det_cand_res, det_layer_start,
         det_emit_count, det_emit_chunks, det_wait_list, det_geom, det_emit_offsets, det_out_kps, det_out_offsets, det_out_resp, det_out_layer, det_planes_out;
@@ -55,10 +55,10 @@ struct mofreak_ctx {
     struct Pipe {
         hipStream_t s_in = nullptr, s_out = nullptr;
         hipEvent_t ev_in[2]{}, ev_comp[2]{}, ev_out[2]{};
-        void *h_frames[2]{}, *h_rows[2]{};
+        void *h_frames[2]{}, *h_rows[2]{}, *h_pair_rows[2]{};
         int64_t *h_count[2]{};
-        size_t h_frames_bytes = 0, h_rows_bytes = 0;
-        DeviceBuffer d_frames[2], d_rows[2];
+        size_t h_frames_bytes = 0, h_rows_bytes = 0, h_pair_rows_bytes = 0;
+        DeviceBuffer d_frames[2], d_rows[2], d_pair_rows[2];
         bool ready = false;
     } pipe;
     int path_mode = MOFREAK_PATH_AUTO;
@@ -643,6 +643,12 @@ void mofreak_destroy(mofreak_ctx *ctx)
     if (ctx->d_mip_pos) (void)hipFree(ctx->d_mip_pos);
     if (ctx->d_tile_lanes) (void)hipFree(ctx->d_tile_lanes);
     if (ctx->d_lut_int) (void)hipFree(ctx->d_lut_int);
+    for (int b = 0; b < 2; ++b) {
+        release(ctx->pipe.d_frames[b]);
+        release(ctx->pipe.d_rows[b]);
+        release(ctx->pipe.d_pair_rows[b]);
+    }
+    release(ctx->pair_label);
     if (ctx->pipe.ready) {
         (void)hipStreamSynchronize(ctx->pipe.s_in);
         (void)hipStreamSynchronize(ctx->pipe.s_out);
@@ -653,8 +659,7 @@ void mofreak_destroy(mofreak_ctx *ctx)
             (void)hipHostFree(ctx->pipe.h_count[b]);
             if (ctx->pipe.h_frames[b]) (void)hipHostFree(ctx->pipe.h_frames[b]);
             if (ctx->pipe.h_rows[b]) (void)hipHostFree(ctx->pipe.h_rows[b]);
-            release(ctx->pipe.d_frames[b]);
-            release(ctx->pipe.d_rows[b]);
+            if (ctx->pipe.h_pair_rows[b]) (void)hipHostFree(ctx->pipe.h_pair_rows[b]);
         }
         (void)hipStreamDestroy(ctx->pipe.s_in);
         (void)hipStreamDestroy(ctx->pipe.s_out);
@@ -955,115 +960,218 @@ int mofreak_host_alloc(mofreak_ctx *ctx, size_t bytes, void **out)
 
 int mofreak_host_free(mofreak_ctx *ctx, void *ptr)
 {
-    if (!ctx) return MOFREAK_ERR_BAD_ARG;
-    NEED_DEVICE(ctx);
+    // ctx may be NULL: page-locked memory is not tied to the context that allocated it and may outlive it
+    if (ctx) NEED_DEVICE(ctx);
     if (ptr) HIP_TRY(ctx, hipHostFree(ptr));
     return MOFREAK_OK;
 }
 
-int mofreak_extract_stream_pipelined(mofreak_ctx *ctx, const uint8_t *frames, int T, int W, int H, int chunk_frames,
-                                     const mofreak_keypoint *kps, int64_t n_kp, mofreak_row *rows_out,
-                                     int64_t rows_capacity, int64_t *n_rows_out)
-{
-    if (!ctx) return MOFREAK_ERR_BAD_ARG;
-    if (n_rows_out) *n_rows_out = 0;
-    if (T < 0 || n_kp < 0 || rows_capacity < 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "negative count");
-    const int gap = ctx->params.gap_for_frame_difference;
-    if (T - gap <= 0 || n_kp == 0) return MOFREAK_OK;
-    const int64_t fsz = (int64_t)W * H;
-    int rc = validate_frames(ctx, frames, frames, W, H, W, fsz, T - gap);
-    if (rc) return rc;
-    if (!kps || !rows_out) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null pointer");
-    NEED_DEVICE(ctx);
-    if (chunk_frames <= gap) chunk_frames = 256;
-    chunk_frames = std::min(chunk_frames, T);
-    const int chunk_pairs = chunk_frames - gap;
-    const int n_chunks = (T - gap + chunk_pairs - 1) / chunk_pairs;
-    const Geometry g{W, H, W, fsz};
-    const bool frames_pinned = is_pinned_host(frames), rows_pinned = is_pinned_host(rows_out);
-    mofreak_ctx::Pipe &P = ctx->pipe;
-    if (!P.ready) {
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&P.s_in, hipStreamNonBlocking));
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&P.s_out, hipStreamNonBlocking));
-        for (int b = 0; b < 2; ++b) {
-            HIP_TRY(ctx, hipEventCreateWithFlags(&P.ev_in[b], hipEventDisableTiming));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&P.ev_comp[b], hipEventDisableTiming));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&P.ev_out[b], hipEventDisableTiming));
-            HIP_TRY(ctx, hipHostMalloc((void **)&P.h_count[b], sizeof(int64_t), hipHostMallocDefault));
-        }
-        P.ready = true;
+namespace {
+
+// Every exit of the pipelined frame loop after its first asynchronous operation goes through this: a copy may still be
+// reading the caller's page-locked frames or writing the caller's rows, so the three streams are drained before the
+// caller gets control (and possibly frees or reuses those buffers) -- on errors as on success.
+struct PipeDrain {
+    mofreak_ctx *ctx;
+    bool armed = false;
+    ~PipeDrain()
+    {
+        if (!armed) return;
+        (void)hipStreamSynchronize(ctx->pipe.s_in);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->pipe.s_out);
     }
+};
+
+// Copy streams, events and the page-locked count words of the pipeline: created into locals and committed as a whole, so
+// that a failure half way leaves nothing behind and nothing half-initialised.
+int pipe_setup(mofreak_ctx *ctx)
+{
+    mofreak_ctx::Pipe &P = ctx->pipe;
+    if (P.ready) return MOFREAK_OK;
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev[6] = {};
+    int64_t *cnt[2] = {};
+    hipError_t e = hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking);
+    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) e = hipHostMalloc((void **)&cnt[b], sizeof(int64_t), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        for (auto c : cnt)
+            if (c) (void)hipHostFree(c);
+        for (auto v : ev)
+            if (v) (void)hipEventDestroy(v);
+        if (s_in) (void)hipStreamDestroy(s_in);
+        if (s_out) (void)hipStreamDestroy(s_out);
+        return fail(ctx, e == hipErrorOutOfMemory ? MOFREAK_ERR_OOM : MOFREAK_ERR_HIP, std::string("pipeline setup: ") + hipGetErrorString(e));
+    }
+    P.s_in = s_in;
+    P.s_out = s_out;
+    for (int b = 0; b < 2; ++b) {
+        P.ev_in[b] = ev[3 * b];
+        P.ev_comp[b] = ev[3 * b + 1];
+        P.ev_out[b] = ev[3 * b + 2];
+        P.h_count[b] = cnt[b];
+    }
+    P.ready = true;
+    return MOFREAK_OK;
+}
+
+// (Re)allocate a pair of page-locked staging buffers: the old pointer is forgotten the moment it is freed and the size is
+// recorded only after both allocations succeeded.
+int pipe_host_pair(mofreak_ctx *ctx, void *(&slot)[2], size_t &have, size_t want)
+{
+    if (have >= want && slot[0] && slot[1]) return MOFREAK_OK;
+    have = 0;
+    for (int b = 0; b < 2; ++b) {
+        if (slot[b]) {
+            void *old = slot[b];
+            slot[b] = nullptr;
+            HIP_TRY(ctx, hipHostFree(old));
+        }
+    }
+    for (int b = 0; b < 2; ++b) HIP_TRY(ctx, hipHostMalloc(&slot[b], std::max<size_t>(want, 64), hipHostMallocDefault));
+    have = want;
+    return MOFREAK_OK;
+}
+
+// The frame loop of computeMoFREAKFromFile (MoFREAKUtilities.cpp:391-489) over MANY clips in one pipelined pass -- the
+// dataset loop of computeMoFREAKFiles (main.cpp:862-921) without a synchronous call per video.  The clips are laid end to
+// end in a virtual frame sequence; a window of chunk_frames frames of it is copied down at a time (consecutive windows
+// overlap by `gap` frames), every frame q of the window with q + gap inside it is a pair (previous = q, current = q + gap),
+// and the compaction drops the pairs whose two frames belong to different clips (label < 0) and numbers the others
+// gap - 1, gap, ... inside their clip (:401, :488).  Window k + 1's copies run under window k's kernels while window
+// k - 1's rows travel back.
+int extract_clips_impl(mofreak_ctx *ctx, const uint8_t *const *clip_frames, const int32_t *clip_n_frames, int n_clips, int W,
+                       int H, int chunk_frames, const mofreak_keypoint *kps, int64_t n_kp, mofreak_row *rows_out,
+                       int64_t rows_capacity, int64_t *clip_row_offsets_out, int64_t *n_rows_out, bool rows_on_device)
+{
+    const int gap = ctx->params.gap_for_frame_difference;
+    const int64_t fsz = (int64_t)W * H;
+    // the virtual sequence: clip c occupies frames [start[c], start[c + 1])
+    std::vector<int64_t> start((size_t)n_clips + 1, 0);
+    for (int c = 0; c < n_clips; ++c) {
+        if (clip_n_frames[c] < 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "negative frame count");
+        if (clip_n_frames[c] > 0 && !clip_frames[c]) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null clip pointer");
+        start[c + 1] = start[c] + clip_n_frames[c];
+    }
+    const int64_t T = start[n_clips];
+    if (clip_row_offsets_out) std::fill(clip_row_offsets_out, clip_row_offsets_out + n_clips + 1, (int64_t)0);
+    if (T - gap <= 0 || n_kp == 0) return MOFREAK_OK;
+    if (T - gap >= ((int64_t)1 << 31)) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "more than 2^31 frames in one call");
+    const int64_t n_pairs_all = T - gap;
+    if (chunk_frames <= gap)  // default: windows of about 96 MiB of frames
+        chunk_frames = (int)std::min<int64_t>(4096, std::max<int64_t>(gap + 16, ((int64_t)96 << 20) / fsz));
+    chunk_frames = (int)std::min<int64_t>(chunk_frames, T);
+    const int chunk_pairs = chunk_frames - gap;
+    const int n_chunks = (int)((n_pairs_all + chunk_pairs - 1) / chunk_pairs);
+    const Geometry g{W, H, W, fsz};
+    const uint8_t *some_frame = nullptr;
+    for (int c = 0; c < n_clips && !some_frame; ++c)
+        if (clip_n_frames[c] > 0) some_frame = clip_frames[c];
+    int rc = validate_frames(ctx, some_frame, some_frame, W, H, W, fsz, chunk_pairs);
+    if (rc) return rc;
+
+    // frame labels per pair, and which clip a frame belongs to (for the segment copies)
+    std::vector<int32_t> label((size_t)n_pairs_all);
+    for (int c = 0; c < n_clips; ++c)
+        for (int64_t q = start[c]; q < start[c + 1] && q < n_pairs_all; ++q)
+            label[(size_t)q] = q + gap < start[c + 1] ? (int32_t)(q - start[c]) + gap - 1 : -1;
+    std::vector<char> clip_pinned((size_t)n_clips);
+    bool all_pinned = true;
+    for (int c = 0; c < n_clips; ++c) {
+        clip_pinned[c] = clip_n_frames[c] == 0 || is_pinned_host(clip_frames[c]);
+        all_pinned = all_pinned && clip_pinned[c];
+    }
+    const bool rows_pinned = rows_on_device || is_pinned_host(rows_out);
+
+    if ((rc = pipe_setup(ctx))) return rc;
+    mofreak_ctx::Pipe &P = ctx->pipe;
+    PipeDrain drain{ctx, true};  // from here on every return drains the three streams
     const size_t chunk_bytes = (size_t)chunk_frames * fsz, rows_bytes = (size_t)chunk_pairs * n_kp * sizeof(mofreak_row);
     for (int b = 0; b < 2; ++b) {
         if ((rc = ensure(ctx, P.d_frames[b], chunk_bytes))) return rc;
         if ((rc = ensure(ctx, P.d_rows[b], rows_bytes))) return rc;
+        if ((rc = ensure(ctx, P.d_pair_rows[b], (size_t)chunk_pairs * sizeof(int32_t)))) return rc;
     }
-    if (!frames_pinned && P.h_frames_bytes < chunk_bytes) {
-        for (int b = 0; b < 2; ++b) {
-            if (P.h_frames[b]) HIP_TRY(ctx, hipHostFree(P.h_frames[b]));
-            HIP_TRY(ctx, hipHostMalloc(&P.h_frames[b], chunk_bytes, hipHostMallocDefault));
-        }
-        P.h_frames_bytes = chunk_bytes;
-    }
-    if (!rows_pinned && P.h_rows_bytes < rows_bytes) {
-        for (int b = 0; b < 2; ++b) {
-            if (P.h_rows[b]) HIP_TRY(ctx, hipHostFree(P.h_rows[b]));
-            HIP_TRY(ctx, hipHostMalloc(&P.h_rows[b], rows_bytes, hipHostMallocDefault));
-        }
-        P.h_rows_bytes = rows_bytes;
-    }
+    if (!all_pinned && (rc = pipe_host_pair(ctx, P.h_frames, P.h_frames_bytes, chunk_bytes))) return rc;
+    if (!rows_pinned && (rc = pipe_host_pair(ctx, P.h_rows, P.h_rows_bytes, rows_bytes))) return rc;
+    if ((rc = pipe_host_pair(ctx, P.h_pair_rows, P.h_pair_rows_bytes, (size_t)chunk_pairs * sizeof(int32_t)))) return rc;
     if ((rc = upload(ctx, ctx->stage[2], kps, (size_t)n_kp * sizeof(mofreak_keypoint)))) return rc;
+    if ((rc = upload(ctx, ctx->pair_label, label.data(), label.size() * sizeof(int32_t)))) return rc;
     const mofreak_keypoint *d_kps = static_cast<const mofreak_keypoint *>(ctx->stage[2].ptr);
+    const int32_t *d_label = static_cast<const int32_t *>(ctx->pair_label.ptr);
     const int64_t items_max = (int64_t)chunk_pairs * n_kp;
     if ((rc = ensure(ctx, ctx->scratch_desc, (size_t)items_max * 16))) return rc;
     if ((rc = ensure(ctx, ctx->scratch_valid, (size_t)items_max))) return rc;
     if ((rc = ensure(ctx, ctx->compact_offsets, ((size_t)(items_max + kCompactItemsPerBlock - 1) / kCompactItemsPerBlock + 1) * sizeof(int64_t)))) return rc;
     uint8_t *desc = static_cast<uint8_t *>(ctx->scratch_desc.ptr);
     uint8_t *valid = static_cast<uint8_t *>(ctx->scratch_valid.ptr);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the uploads above; from here on nothing below allocates
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the uploads above (they read `label` and the caller's kps)
 
-    int64_t total_rows = 0;          // rows handed back so far
-    int64_t chunk_total[2] = {0, 0};  // row count of the chunk in each slot, once known
+    std::vector<int32_t> rows_of_pair(clip_row_offsets_out ? (size_t)n_pairs_all : 0);
+    int64_t total_rows = 0;           // rows produced so far (keeps counting past rows_capacity: the caller learns the size)
+    bool overflow = false;
+    int64_t chunk_total[2] = {0, 0};  // row count of the window in each slot, once known
     int64_t chunk_dst[2] = {0, 0};    // where its rows go in rows_out
+    int64_t chunk_q0[2] = {0, 0};     // its first pair
+    int chunk_np[2] = {0, 0};
     int state[2] = {0, 0};            // 0 free, 1 computing (count unknown), 2 rows on their way back
-    // hand chunk `b`'s rows over: count known -> D2H issued; D2H done -> (copied to the caller)
+    // hand window `b`'s rows over: count known -> copy issued; copy done -> (copied to the caller)
     auto advance = [&](int b, bool finish) -> int {
         if (state[b] == 1) {
             HIP_TRY(ctx, hipEventSynchronize(P.ev_comp[b]));
             chunk_total[b] = *P.h_count[b];
             chunk_dst[b] = total_rows;
             total_rows += chunk_total[b];
-            if (total_rows > rows_capacity) return fail(ctx, MOFREAK_ERR_CAPACITY, "rows_out too small: need at least " + std::to_string(total_rows));
-            if (chunk_total[b]) {
+            if (!rows_of_pair.empty())
+                std::memcpy(rows_of_pair.data() + chunk_q0[b], P.h_pair_rows[b], (size_t)chunk_np[b] * sizeof(int32_t));
+            if (total_rows > rows_capacity) overflow = true;  // no further row leaves the device; the counting goes on
+            if (chunk_total[b] && !overflow) {
                 void *dst = rows_pinned ? static_cast<void *>(rows_out + chunk_dst[b]) : P.h_rows[b];
-                HIP_TRY(ctx, hipMemcpyAsync(dst, P.d_rows[b].ptr, (size_t)chunk_total[b] * sizeof(mofreak_row), hipMemcpyDeviceToHost, P.s_out));
+                HIP_TRY(ctx, hipMemcpyAsync(dst, P.d_rows[b].ptr, (size_t)chunk_total[b] * sizeof(mofreak_row),
+                                            rows_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, P.s_out));
             }
             HIP_TRY(ctx, hipEventRecord(P.ev_out[b], P.s_out));
             state[b] = 2;
         }
         if (state[b] == 2 && finish) {
             HIP_TRY(ctx, hipEventSynchronize(P.ev_out[b]));
-            if (!rows_pinned && chunk_total[b]) std::memcpy(rows_out + chunk_dst[b], P.h_rows[b], (size_t)chunk_total[b] * sizeof(mofreak_row));
+            if (!rows_pinned && chunk_total[b] && !overflow)
+                std::memcpy(rows_out + chunk_dst[b], P.h_rows[b], (size_t)chunk_total[b] * sizeof(mofreak_row));
             state[b] = 0;
         }
         return MOFREAK_OK;
     };
 
+    int clip_lo = 0;  // first clip that reaches into the current window
     for (int k = 0; k < n_chunks; ++k) {
         const int b = k & 1;
-        const int f0 = k * chunk_pairs, nf = std::min(chunk_frames, T - f0), np = nf - gap;
-        if ((rc = advance(b, true))) return rc;  // slot b: chunk k-2 is through (its buffers are free again)
-        const uint8_t *src = frames + (int64_t)f0 * fsz;
-        if (!frames_pinned) {
-            HIP_TRY(ctx, hipEventSynchronize(P.ev_in[b]));  // chunk k-2's copy out of this staging buffer
-            std::memcpy(P.h_frames[b], src, (size_t)nf * fsz);
-            src = static_cast<const uint8_t *>(P.h_frames[b]);
+        const int64_t f0 = (int64_t)k * chunk_pairs;
+        const int nf = (int)std::min<int64_t>(chunk_frames, T - f0), np = nf - gap;
+        if ((rc = advance(b, true))) return rc;  // slot b: window k-2 is through (its buffers are free again)
+        bool staged_wait = false;
+        HIP_TRY(ctx, hipStreamWaitEvent(P.s_in, P.ev_comp[b], 0));  // the device frames of window k-2 are no longer read
+        while (clip_lo < n_clips && start[clip_lo + 1] <= f0) ++clip_lo;
+        for (int c = clip_lo; c < n_clips && start[c] < f0 + nf; ++c) {  // the pieces of clips inside [f0, f0 + nf)
+            const int64_t lo = std::max(start[c], f0), hi = std::min(start[c + 1], f0 + nf);
+            if (hi <= lo) continue;
+            const uint8_t *src = clip_frames[c] + (lo - start[c]) * fsz;
+            uint8_t *dst = static_cast<uint8_t *>(P.d_frames[b].ptr) + (lo - f0) * fsz;
+            if (!clip_pinned[c]) {
+                if (!staged_wait) {
+                    HIP_TRY(ctx, hipEventSynchronize(P.ev_in[b]));  // window k-2's copies out of this staging buffer
+                    staged_wait = true;
+                }
+                uint8_t *stage = static_cast<uint8_t *>(P.h_frames[b]) + (lo - f0) * fsz;
+                std::memcpy(stage, src, (size_t)(hi - lo) * fsz);
+                src = stage;
+            }
+            HIP_TRY(ctx, hipMemcpyAsync(dst, src, (size_t)(hi - lo) * fsz, hipMemcpyHostToDevice, P.s_in));
         }
-        HIP_TRY(ctx, hipStreamWaitEvent(P.s_in, P.ev_comp[b], 0));  // the device frames of chunk k-2 are no longer read
-        HIP_TRY(ctx, hipMemcpyAsync(P.d_frames[b].ptr, src, (size_t)nf * fsz, hipMemcpyHostToDevice, P.s_in));
         HIP_TRY(ctx, hipEventRecord(P.ev_in[b], P.s_in));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, P.ev_in[b], 0));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, P.ev_out[b], 0));  // the device rows of chunk k-2 have left
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, P.ev_out[b], 0));  // the device rows of window k-2 have left
         const uint8_t *d_fr = static_cast<const uint8_t *>(P.d_frames[b].ptr);
         rc = extract_device(ctx, d_fr + (int64_t)gap * fsz, d_fr, g, np, d_kps, nullptr, nullptr, n_kp, desc, valid, nullptr, nullptr);
         if (rc) return rc;
@@ -1076,26 +1184,75 @@ int mofreak_extract_stream_pipelined(mofreak_ctx *ctx, const uint8_t *frames, in
             c.n_kp = n_kp;
             c.n_items = n_items;
             c.n_pairs = np;
-            c.first_frame_number = gap - 1 + f0;  // frame labels run on across chunks (:401, :488)
+            c.first_frame_number = 0;
+            c.pair_label = d_label + f0;  // labels restart with every clip (:401, :488); < 0: the pair straddles two clips
+            c.pair_rows = static_cast<int32_t *>(P.d_pair_rows[b].ptr);
             c.desc = desc;
             c.valid = valid;
             c.rows = static_cast<mofreak_row *>(P.d_rows[b].ptr);
             c.capacity = n_items;
             c.block_offsets = static_cast<int64_t *>(ctx->compact_offsets.ptr);
             c.n_blocks = n_blocks;
+            HIP_TRY(ctx, hipMemsetAsync(c.pair_rows, 0, (size_t)np * sizeof(int32_t), ctx->stream));
             const int e = launch_compact(c, ctx->stream);
             if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("compact launch: ") + hipGetErrorString((hipError_t)e));
             HIP_TRY(ctx, hipMemcpyAsync(P.h_count[b], c.block_offsets + n_blocks, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+            if (!rows_of_pair.empty())
+                HIP_TRY(ctx, hipMemcpyAsync(P.h_pair_rows[b], c.pair_rows, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         }
         HIP_TRY(ctx, hipEventRecord(P.ev_comp[b], ctx->stream));
         state[b] = 1;
-        if ((rc = advance(b ^ 1, false))) return rc;  // chunk k-1: its count is in (or we wait for it) -> rows start travelling
+        chunk_q0[b] = f0;
+        chunk_np[b] = np;
+        if ((rc = advance(b ^ 1, false))) return rc;  // window k-1: its count is in (or we wait for it) -> rows start travelling
     }
     for (int k = n_chunks; k < n_chunks + 2; ++k)
         if ((rc = advance(k & 1, true))) return rc;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (n_rows_out) *n_rows_out = total_rows;
+    if (clip_row_offsets_out) {
+        int64_t acc = 0;
+        for (int c = 0; c < n_clips; ++c) {
+            for (int64_t q = start[c]; q < start[c + 1] && q < n_pairs_all; ++q) acc += rows_of_pair[(size_t)q];
+            clip_row_offsets_out[c + 1] = acc;
+        }
+    }
+    if (overflow)
+        return fail(ctx, MOFREAK_ERR_CAPACITY, "rows_out too small: " + std::to_string(total_rows) + " rows needed (returned through n_rows_out)");
     return MOFREAK_OK;
+}
+
+}  // namespace
+
+int mofreak_extract_clips(mofreak_ctx *ctx, const uint8_t *const *clip_frames, const int32_t *clip_n_frames, int n_clips, int W, int H,
+                          int chunk_frames, const mofreak_keypoint *kps, int64_t n_kp, mofreak_row *rows_out, int64_t rows_capacity,
+                          int64_t *clip_row_offsets_out, int64_t *n_rows_out, unsigned flags)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    if (n_rows_out) *n_rows_out = 0;
+    if (n_clips < 0 || n_kp < 0 || rows_capacity < 0 || W <= 0 || H <= 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "negative count or empty frame");
+    if (n_clips == 0) return MOFREAK_OK;
+    if (!clip_frames || !clip_n_frames) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null clip table");
+    if (n_kp > 0 && !kps) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null keypoint pointer");
+    if (rows_capacity > 0 && !rows_out) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null rows_out");
+    NEED_DEVICE(ctx);
+    return extract_clips_impl(ctx, clip_frames, clip_n_frames, n_clips, W, H, chunk_frames, kps, n_kp, rows_out, rows_capacity,
+                              clip_row_offsets_out, n_rows_out, (flags & MOFREAK_ROWS_DEVICE) != 0);
+}
+
+int mofreak_extract_stream_pipelined(mofreak_ctx *ctx, const uint8_t *frames, int T, int W, int H, int chunk_frames,
+                                     const mofreak_keypoint *kps, int64_t n_kp, mofreak_row *rows_out,
+                                     int64_t rows_capacity, int64_t *n_rows_out)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    if (n_rows_out) *n_rows_out = 0;
+    if (T < 0 || n_kp < 0 || rows_capacity < 0 || W <= 0 || H <= 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "negative count or empty frame");
+    const int gap = ctx->params.gap_for_frame_difference;
+    if (T - gap <= 0 || n_kp == 0) return MOFREAK_OK;
+    if (!frames || !kps || !rows_out) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null pointer");
+    NEED_DEVICE(ctx);
+    if (chunk_frames <= gap) chunk_frames = 256;
+    const int32_t n_frames = T;  // one clip: the stream
+    return extract_clips_impl(ctx, &frames, &n_frames, 1, W, H, chunk_frames, kps, n_kp, rows_out, rows_capacity, nullptr, n_rows_out, false);
 }
 
 int mofreak_bgr_to_gray(mofreak_ctx *ctx, const uint8_t *bgr, int W, int H, int64_t row_stride, int64_t frame_stride,
@@ -1609,6 +1766,7 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (n_out) *n_out = total;
     if (st & 16) return fail(ctx, MOFREAK_ERR_HIP, "detector: a refinement walk left its staged window (internal error)");
+    if (st & 32) return fail(ctx, MOFREAK_ERR_HIP, "detector: a chain of tied scores did not resolve within its pass budget (internal error)");
     if (st & 4) return fail(ctx, MOFREAK_ERR_CAPACITY, "more corner candidates in one pair than the detector reserved (mofreak_detect_set_capacity)");
     if (host) {
         const int64_t n_copy = std::min(total, capacity);

@@ -1260,7 +1260,11 @@ __global__ __launch_bounds__(kTieThreads) void det_tie_chain_kernel(DetArgs a, i
         own[j] = tie_cand(a, cb + own_i[j]);
         own_waits[j] = (int)threadIdx.x + j * kTieThreads < n_items && own[j].flag == kDetTie;
     }
-    for (;;) {
+    // The earliest pending tie of a layer is always ready, so a pass decides at least one tie and n_items + 1 passes
+    // are enough for the longest possible chain.  Should that invariant ever break (a status byte left pending by a
+    // candidate nobody lists), the thread gives up and says so (status bit 32 -> MOFREAK_ERR_HIP) instead of hanging
+    // the device.
+    for (int pass = 0;; ++pass) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // the pass reads what has been published by now
         bool waits = false;
 #pragma unroll
@@ -1287,6 +1291,10 @@ __global__ __launch_bounds__(kTieThreads) void det_tie_chain_kernel(DetArgs a, i
                 waits = true;
         }
         if (!waits) break;
+        if (pass > n_items) {
+            atomicOr(a.status_word, 32);
+            break;
+        }
     }
 }
 

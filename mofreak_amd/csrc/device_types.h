@@ -165,6 +165,11 @@ struct CompactArgs {
     int64_t capacity;
     int64_t *block_offsets;  // [n_blocks + 1]; last = total
     int32_t n_blocks;
+    // Many clips in one call (mofreak_extract_clips; shared keypoint list only): pair p carries frame number pair_label[p]
+    // instead of first_frame_number + p, and a pair whose label is negative (its two frames belong to different clips)
+    // yields no rows.  pair_rows[p] (zeroed by the caller) receives the number of rows pair p produced.  Both may be null.
+    const int32_t *pair_label = nullptr;
+    int32_t *pair_rows = nullptr;
 };
 
 constexpr int kCompactItemsPerBlock = 1024;

@@ -504,13 +504,37 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int *total)
     return base + incl - v;
 }
 
+// Is item `item` of a shared-list call a row?  With pair labels (many clips in one call) a pair that straddles two clips
+// has a negative label and none of its keypoints is one.
+__device__ __forceinline__ bool compact_keeps(const CompactArgs &a, int64_t item, int *pair_out)
+{
+    if (item >= a.n_items || a.valid[item] == 0) return false;
+    if (a.pair_label == nullptr && a.pair_rows == nullptr) return true;
+    const int pair = (int)(item / a.n_kp);  // shared keypoint list: n_kp items per pair
+    *pair_out = pair;
+    return a.pair_label == nullptr || a.pair_label[pair] >= 0;
+}
+
 __global__ __launch_bounds__(256) void compact_count_kernel(CompactArgs a)
 {
     const int64_t base = (int64_t)blockIdx.x * kCompactItemsPerBlock + threadIdx.x * 4;
     int cnt = 0;
+    int run_pair = -1, run = 0;  // rows of the pair this thread's items are in, flushed when the pair changes
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (base + k < a.n_items) cnt += a.valid[base + k] != 0;
+    for (int k = 0; k < 4; ++k) {
+        int pair = -1;
+        const bool keep = compact_keeps(a, base + k, &pair);
+        cnt += keep;
+        if (a.pair_rows != nullptr && keep) {
+            if (pair != run_pair) {
+                if (run) atomicAdd(a.pair_rows + run_pair, run);
+                run_pair = pair;
+                run = 0;
+            }
+            ++run;
+        }
+    }
+    if (run) atomicAdd(a.pair_rows + run_pair, run);
     int total;
     block_exclusive_scan_256(cnt, &total);
     if (threadIdx.x == 0) a.block_offsets[blockIdx.x] = total;
@@ -542,7 +566,8 @@ __global__ __launch_bounds__(256) void compact_scatter_kernel(CompactArgs a)
     int flags[4], cnt = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        flags[k] = (base + k < a.n_items) && a.valid[base + k] != 0;
+        int unused;
+        flags[k] = compact_keeps(a, base + k, &unused);
         cnt += flags[k];
     }
     int total;
@@ -574,7 +599,7 @@ __global__ __launch_bounds__(256) void compact_scatter_kernel(CompactArgs a)
             uint4 lo4, hi4;
             lo4.x = __float_as_uint(kp.x);
             lo4.y = __float_as_uint(kp.y);
-            lo4.z = (uint32_t)(a.first_frame_number + pair);
+            lo4.z = (uint32_t)(a.pair_label != nullptr ? a.pair_label[pair] : a.first_frame_number + pair);
             lo4.w = __float_as_uint(kp.size);
             hi4 = d;
             uint4 *dst = reinterpret_cast<uint4 *>(a.rows + pos);

@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
+#include <string>
 
 namespace mofreak {
 
@@ -359,7 +361,8 @@ void build_tables(const FreakParams &p, Tables &t)
         }
         t.mip_pos.clear();
         const int n_dw = static_cast<int>(dwords.size());
-        if (n_dw < 65 || n_dw > 80) std::abort();  // the kernel's five passes assume 64 full dwords plus a partial pass
+        if (n_dw < 65 || n_dw > 80)  // the kernel's five passes assume 64 full dwords plus a partial pass
+            throw std::logic_error("MIP sample table: " + std::to_string(n_dw) + " dwords, the tile kernel expects 65..80");
         for (int u = 0; u < 4; ++u)
             for (int lane = 0; lane < 64; ++lane) t.mip_pos.push_back(static_cast<uint16_t>(4 * dwords[lane] + u));
         for (int d = 64; d < n_dw; ++d)
@@ -378,7 +381,8 @@ void build_tables(const FreakParams &p, Tables &t)
                 const int pos = std::min(t.mip_pos[j] % kP19Pad, kPatch * kPatch - 1), dy = pos / kPatch, dx = pos % kPatch;
                 MipSample &m = t.mip_samples[static_cast<size_t>(L) * t.mip_stride + j];
                 // the tile kernel reads a row pair as (off, off + 1): a clamped column has to carry a zero weight
-                if (tx[dx].ofs1 != tx[dx].ofs + 1 && tx[dx].c1 != 0) std::abort();
+                if (tx[dx].ofs1 != tx[dx].ofs + 1 && tx[dx].c1 != 0)
+                    throw std::logic_error("MIP sample table: a clamped resize column carries a weight");
                 m.off_row0 = static_cast<uint16_t>(frame * kTileRW + ty[dy].ofs * kTileStagePitch + tx[dx].ofs);
                 m.off_row1 = static_cast<uint16_t>(frame * kTileRW + ty[dy].ofs1 * kTileStagePitch + tx[dx].ofs);
                 m.cx = static_cast<uint32_t>(static_cast<uint16_t>(tx[dx].c0)) | static_cast<uint32_t>(static_cast<uint16_t>(tx[dx].c1)) << 16;

@@ -146,9 +146,7 @@ class MoFREAKUtilities:
         self.features.clear()
 
     def writeMoFREAKFeaturesToFile(self, output_file: str) -> None:
-        with open(output_file, "wb") as f:
-            for chunk in self.features:
-                f.write(api.format_rows(chunk))
+        write_atomic(output_file, (api.format_rows(chunk) for chunk in self.features))
 
     def readMoFREAKFeatures(self, filename: str, num_to_sample: int = 0) -> None:
         with open(filename, "rb") as f:
@@ -173,6 +171,20 @@ class MoFREAKUtilities:
             c.close()
         self._clones = []
         self._ctx.close()
+
+
+def write_atomic(path: str, chunks) -> None:
+    """Write `chunks` (bytes objects) to `path` through `<path>.tmp` + fsync + rename: the target either does not exist
+    or is complete.  The per-video .mofreak file is the pipeline's checkpoint (compute_mofreak_files(skip_existing=True)),
+    and an empty file is a legitimate result (a clip no longer than the frame gap), so size cannot tell a finished file
+    from one whose writer was killed -- existence has to mean "complete"."""
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as f:
+        for c in chunks:
+            f.write(c)
+        f.flush()
+        os.fsync(f.fileno())
+    os.replace(tmp, path)
 
 
 # ------------------------------------------------------------------ sharding (SURVEY.md 8(e))
@@ -201,9 +213,9 @@ def gather_rows(rows, n_rows: int, dst: int = 0, group=None):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = rows.device
     cnt = torch.tensor([n_rows], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, cnt, group=group)
-    counts = [int(c.item()) for c in counts]
+    all_counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_counts, cnt, group=group)
+    counts = [int(c) for c in all_counts.cpu().tolist()]  # ONE host copy for all ranks' counts
     mine = rows.reshape(-1)[: n_rows * 32]
     if rank == dst:
         out = torch.empty(sum(counts) * 32, dtype=torch.uint8, device=dev)
@@ -246,15 +258,17 @@ def compute_mofreak_files(video_paths: Sequence[str], out_dir: str, mofreak: MoF
 
 def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mofreak: MoFREAKUtilities, rank: int = 0,
                 world_size: int = 1, costs: Sequence[float] | None = None, group=None, on_device: bool = False,
-                workers: int = 1) -> dict:
+                workers: int = 1, batched: bool = True, keep_rows: bool = True) -> dict:
     """BASELINE config 4 end to end (main.cpp:854-924 over a whole dataset).
 
     videos[i]: a (T, H, W) uint8 gray stack or the path of a .npy file holding one; names[i]: its output stem.
     1. shard: longest-processing-time-first over `costs` (default: frame counts), one video per GPU at a time;
-    2. every rank extracts its videos' rows (no collective on the data path); workers > 1: that many host threads, each
-       with a context of its own (mofreak.clone()), take the rank's videos in turn, so that one clip's copies run under
-       another's kernels -- a clip is one synchronous C-ABI call, and short clips are all latency;
-    3. the one exchange: counts per video (all_gather) + gather_rows of the 32-byte rows to rank 0;
+    2. every rank extracts its videos' rows (no collective on the data path).  batched (a shared keypoint list, i.e. a
+       dense grid): ALL of the rank's clips in one mofreak_extract_clips call -- the clips share launches and the
+       three-stream copy/compute pipeline, and the rows stay in HBM (`on_device`).  Otherwise (detector keypoints,
+       per-frame providers): one C-ABI call per clip, `workers` host threads with a context each;
+    3. the one exchange: counts per video (all_reduce) + gather_rows of the 32-byte rows to rank 0 -- device to device
+       over RCCL when on_device, then ONE device-to-host copy on the root;
     4. rank 0 writes <out_dir>/<name>.mofreak for every video, rows in (video, frame, keypoint) order -- the bytes a
        1-rank run writes (out_dir None: nothing is written, the gathered rows are still returned on rank 0).
     Returns timings and, on rank 0, `rows_per_video`.
@@ -273,47 +287,78 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
     mine = shard_videos(costs, world_size)[rank]
     t0 = time.perf_counter()
     counts = np.zeros(n, np.int64)
-    if workers > 1 and len(mine) > 1:
-        import queue
-        from concurrent.futures import ThreadPoolExecutor
+    prov = getattr(mofreak, "keypoint_provider", None)
+    use_batched = batched and not isinstance(prov, str) and getattr(prov, "shared", False) and len(mine) > 0
+    d_rows = None  # this rank's rows in HBM (batched + a CUDA device)
+    if use_batched:
+        stacks = [np.ascontiguousarray(stack_of(videos[i])) for i in mine]
+        gap = mofreak._ctx.params.gap_for_frame_difference
+        H, W = stacks[0].shape[1:]
+        kps = prov(gap, W, H)
+        cap = int(sum(max(s.shape[0] - gap, 0) for s in stacks)) * len(kps)
+        if torch.cuda.is_available():
+            d_rows = torch.empty(max(cap, 1) * 32, dtype=torch.uint8, device=torch.device("cuda", mofreak._device))
+            n_local, offs = mofreak._ctx.extract_clips(stacks, kps, rows_out=d_rows)
+            local = None
+        else:  # no device: the C ABI says so (MOFREAK_ERR_NO_DEVICE); there is no CPU path
+            local, offs = mofreak._ctx.extract_clips(stacks, kps)
+            n_local = len(local)
+        for j, i in enumerate(mine):
+            counts[i] = offs[j + 1] - offs[j]
+    else:
+        if workers > 1 and len(mine) > 1:
+            import queue
+            from concurrent.futures import ThreadPoolExecutor
 
-        pool = queue.SimpleQueue()
-        for m in mofreak.workers(min(workers, len(mine))):
-            pool.put(m)
-
-        def one(i):
-            m = pool.get()  # an instance nobody else is using
-            try:
-                return m.extract_rows(np.ascontiguousarray(stack_of(videos[i])))
-            finally:
+            pool = queue.SimpleQueue()
+            for m in mofreak.workers(min(workers, len(mine))):
                 pool.put(m)
 
-        with ThreadPoolExecutor(max_workers=min(workers, len(mine))) as ex:
-            parts = list(ex.map(one, mine))  # in the order of `mine`, whichever thread did what
-    else:
-        parts = [mofreak.extract_rows(np.ascontiguousarray(stack_of(videos[i]))) for i in mine]
-    for i, rows in zip(mine, parts):
-        counts[i] = len(rows)
-    local = np.concatenate(parts) if parts else np.zeros(0, api.ROW_DTYPE)
+            def one(i):
+                m = pool.get()  # an instance nobody else is using
+                try:
+                    return m.extract_rows(np.ascontiguousarray(stack_of(videos[i])))
+                finally:
+                    pool.put(m)
+
+            with ThreadPoolExecutor(max_workers=min(workers, len(mine))) as ex:
+                parts = list(ex.map(one, mine))  # in the order of `mine`, whichever thread did what
+        else:
+            parts = [mofreak.extract_rows(np.ascontiguousarray(stack_of(videos[i]))) for i in mine]
+        for i, rows in zip(mine, parts):
+            counts[i] = len(rows)
+        local = np.concatenate(parts) if parts else np.zeros(0, api.ROW_DTYPE)
+        n_local = len(local)
     t_compute = time.perf_counter() - t0
 
     t1 = time.perf_counter()
+    all_rows = None
     if world_size > 1:
         dev = torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu")
         c = torch.from_numpy(counts).to(dev)
         dist.all_reduce(c, group=group)  # every video belongs to exactly one rank: the sum is the per-video count
         counts = c.cpu().numpy()
-        buf = torch.from_numpy(local.view(np.uint8).reshape(-1).copy()).to(dev)
-        gathered, per_rank = gather_rows(buf, len(local), dst=0, group=group)
+        if d_rows is not None:
+            buf = d_rows if on_device else d_rows[: n_local * 32].cpu()
+        else:
+            buf = torch.from_numpy(local.view(np.uint8).reshape(-1).copy()).to(dev)
+        gathered, per_rank = gather_rows(buf, n_local, dst=0, group=group)
         if on_device:
             torch.cuda.synchronize()
-        all_rows = gathered.cpu().numpy().view(api.ROW_DTYPE).reshape(-1) if rank == 0 else None
+        if rank == 0 and keep_rows:
+            all_rows = gathered.cpu().numpy().view(api.ROW_DTYPE).reshape(-1)  # the root's one device-to-host copy
     else:
-        all_rows, per_rank = local, [len(local)]
+        per_rank = [n_local]
+        if keep_rows:
+            all_rows = local if d_rows is None else d_rows[: n_local * 32].cpu().numpy().view(api.ROW_DTYPE).reshape(-1)
     t_gather = time.perf_counter() - t1
 
-    out = {"compute_s": t_compute, "gather_s": t_gather, "videos_here": len(mine), "rows_here": int(len(local))}
+    out = {"compute_s": t_compute, "gather_s": t_gather, "videos_here": len(mine), "rows_here": int(n_local),
+           "batched": bool(use_batched)}
     if rank == 0:
+        out["total_rows"] = int(sum(per_rank))
+        assert out["total_rows"] == int(counts.sum())
+    if rank == 0 and keep_rows:
         # rank r's rows sit at offset sum(per_rank[:r]), its videos in ascending index order
         shards = shard_videos(costs, world_size)
         start = {}
@@ -331,11 +376,9 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
             seg = all_rows[start[i]: start[i] + int(counts[i])]
             rows_per_video[i] = seg
             if out_dir is not None:
-                with open(os.path.join(out_dir, names[i] + ".mofreak"), "wb") as f:
-                    f.write(api.format_rows(seg))
+                write_atomic(os.path.join(out_dir, names[i] + ".mofreak"), [api.format_rows(seg)])
         out["write_s"] = time.perf_counter() - t2
         out["rows_per_video"] = rows_per_video
-        out["total_rows"] = int(len(all_rows))
     return out
 
 

@@ -267,64 +267,91 @@ bool MoFREAKUtilities::buildMoFREAKFeature(const uint8_t *current_frame, const u
 }
 
 // ---------------------------------------------------------------------------------------------- files
+// Both directions go through the library's row text (mofreak_format_rows / mofreak_parse_rows, the byte-exact
+// counterparts of :691-719 and :1146-1190): the facade only converts between MoFREAKFeature and the 32-byte row.
+namespace {
+
+mofreak_row row_of(const MoFREAKFeature &f)
+{
+    mofreak_row r;
+    r.x = f.x;
+    r.y = f.y;
+    r.frame_number = f.frame_number;
+    r.scale = f.scale;  // motion_x / motion_y are always 0 on this path (:476-477) and are printed as such
+    for (int b = 0; b < MOFREAK_APPEARANCE_BYTES; ++b) r.appearance[b] = static_cast<uint8_t>(f.appearance[b]);
+    for (int b = 0; b < MOFREAK_MOTION_BYTES; ++b) r.motion[b] = static_cast<uint8_t>(f.motion[b]);
+    return r;
+}
+
+}  // namespace
+
 void MoFREAKUtilities::writeMoFREAKFeaturesToFile(string output_file)
 {
-    // :691-719 verbatim in behaviour: default ostream formatting, one space after every value
-    std::ofstream f(output_file.c_str());
-    for (auto it = features.begin(); it != features.end(); ++it) {
-        f << it->x << " " << it->y << " " << it->frame_number << " " << it->scale << " " << it->motion_x << " "
-          << it->motion_y << " ";
-        for (int i = 0; i < NUMBER_OF_BYTES_FOR_APPEARANCE; ++i) f << it->appearance[i] << " ";
-        for (int i = 0; i < NUMBER_OF_BYTES_FOR_MOTION; ++i) {
-            int z = it->motion[i];
-            f << z << " ";
+    // The text goes to <output_file>.tmp and is renamed over the target once it is complete: a run killed while writing
+    // leaves no truncated .mofreak file behind (the per-video file is what a resumed run takes for "done").
+    const std::string tmp = output_file + ".tmp";
+    FILE *out = std::fopen(tmp.c_str(), "wb");
+    if (!out) throw std::runtime_error("cannot write " + tmp);
+    const size_t batch = 1 << 16;
+    std::vector<mofreak_row> rows;
+    std::vector<char> text;
+    for (size_t at = 0; at < features.size(); at += batch) {
+        const size_t n = std::min(batch, features.size() - at);
+        rows.resize(n);
+        for (size_t k = 0; k < n; ++k) rows[k] = row_of(features[at + k]);
+        size_t need = 0;
+        check(nullptr, mofreak_format_rows(rows.data(), (int64_t)n, nullptr, 0, &need), "mofreak_format_rows");
+        text.resize(need);
+        check(nullptr, mofreak_format_rows(rows.data(), (int64_t)n, text.data(), text.size(), &need), "mofreak_format_rows");
+        if (std::fwrite(text.data(), 1, need, out) != need) {
+            std::fclose(out);
+            throw std::runtime_error("short write to " + tmp);
         }
-        f << "\n";
     }
-    f.close();
+    if (std::fclose(out) != 0 || std::rename(tmp.c_str(), output_file.c_str()) != 0)
+        throw std::runtime_error("cannot finish " + output_file);
 }
 
 void MoFREAKUtilities::readMoFREAKFeatures(std::string filename, int num_to_sample)
 {
-    // :1136-1212
-    std::deque<MoFREAKFeature> new_features;
     int action = 0, video_number = 0, person = 0;
     readMetadata(filename, action, video_number, person);
 
-    std::ifstream stream;
-    stream.open(filename.c_str());
-    while (stream.good() && !stream.eof()) {
+    std::string text;
+    if (FILE *in = std::fopen(filename.c_str(), "rb")) {
+        char buf[1 << 16];
+        size_t got;
+        while ((got = std::fread(buf, 1, sizeof buf, in)) > 0) text.append(buf, got);
+        std::fclose(in);
+    }  // a file that does not open reads as no features, like the reference's stream that is never good()
+    int64_t n = 0;
+    check(nullptr, mofreak_parse_rows(text.data(), text.size(), nullptr, 0, &n), "mofreak_parse_rows");
+    std::vector<mofreak_row> rows((size_t)n);
+    if (n) check(nullptr, mofreak_parse_rows(text.data(), text.size(), rows.data(), n, &n), "mofreak_parse_rows");
+
+    // file order -> the order the reference leaves in `features`: it collects the file in a scratch deque and moves
+    // it over back to front (:1206-1210), or, when sampling, shuffles the scratch deque and moves num_to_sample
+    // entries over from its back (:1194-1203)
+    std::vector<size_t> order(rows.size());
+    for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+    size_t take = order.size();
+    if (num_to_sample && (int)order.size() > num_to_sample) {
+        std::random_shuffle(order.begin(), order.end());
+        take = (size_t)num_to_sample;
+    }
+    for (size_t k = 0; k < take; ++k) {
+        const mofreak_row &r = rows[order[order.size() - 1 - k]];
         MoFREAKFeature ftr(NUMBER_OF_BYTES_FOR_MOTION, NUMBER_OF_BYTES_FOR_APPEARANCE);
-        stream >> ftr.x >> ftr.y >> ftr.frame_number >> ftr.scale >> ftr.motion_x >> ftr.motion_y;
-        if (stream.eof() || stream.fail()) break;  // trailing whitespace, not an actual feature point
-        for (unsigned i = 0; i < (unsigned)NUMBER_OF_BYTES_FOR_APPEARANCE; ++i) {
-            unsigned int a = 0;
-            stream >> a;
-            ftr.appearance[i] = a;
-        }
-        for (unsigned i = 0; i < (unsigned)NUMBER_OF_BYTES_FOR_MOTION; ++i) {
-            unsigned int a = 0;
-            stream >> a;
-            ftr.motion[i] = a;
-        }
+        ftr.x = r.x;
+        ftr.y = r.y;
+        ftr.frame_number = r.frame_number;
+        ftr.scale = r.scale;
+        for (int b = 0; b < MOFREAK_APPEARANCE_BYTES; ++b) ftr.appearance[b] = r.appearance[b];
+        for (int b = 0; b < MOFREAK_MOTION_BYTES; ++b) ftr.motion[b] = r.motion[b];
         ftr.action = action;
         ftr.video_number = video_number;
         ftr.person = person;
-        new_features.push_back(ftr);
-    }
-    stream.close();
-
-    if (num_to_sample && ((int)new_features.size() > num_to_sample)) {
-        std::random_shuffle(new_features.begin(), new_features.end());
-        for (int i = 0; i < num_to_sample; ++i) {
-            features.push_back(new_features.back());
-            new_features.pop_back();
-        }
-    } else {
-        while (!new_features.empty()) {  // reverse order, as the reference (:1206-1210)
-            features.push_back(new_features.back());
-            new_features.pop_back();
-        }
+        features.push_back(ftr);
     }
 }
 

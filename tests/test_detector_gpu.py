@@ -304,8 +304,7 @@ def test_tie_chains_when_the_waiting_list_overflows():
     a list of 8, so tie-heavy images take the scanning path on every layer: same keypoints as the oracle."""
     import subprocess
     from mofreak_amd import build
-    if not os.path.exists(build.DEBUG_LIB_PATH):
-        build.build_native(debug=True)
+    build.build_native(debug=True)  # rebuilt whenever a source is newer than it (same check as the product build)
     here = os.path.dirname(os.path.abspath(__file__))
     code = r"""
 import sys, numpy as np

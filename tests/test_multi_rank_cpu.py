@@ -149,3 +149,42 @@ def test_compute_mofreak_files_skips_existing(tmp_path):
     m2 = Rec()
     assert harness.compute_mofreak_files(vids, str(out), m2, skip_existing=True) == [str(out / "a2.npy.mofreak")]
     assert m2.calls == [vids[2]]
+
+
+def test_a_killed_writer_leaves_no_file_that_resume_would_skip(tmp_path, monkeypatch):
+    """The per-video .mofreak file is the checkpoint of a resumed run, and an empty file is a legitimate result, so a
+    file must never exist half written: the text goes to <name>.tmp and is renamed when complete.  A writer that dies
+    mid-way leaves only the .tmp behind, and skip_existing recomputes that video."""
+    target = tmp_path / "v.mofreak"
+    calls = []
+
+    def chunks():
+        yield b"1 2 3 "
+        calls.append("about to die")
+        raise KeyboardInterrupt  # the process is killed between two chunks
+
+    with pytest.raises(KeyboardInterrupt):
+        harness.write_atomic(str(target), chunks())
+    assert calls and not target.exists() and (tmp_path / "v.mofreak.tmp").exists()
+
+    class Rec(_FakeMoFREAK):
+        def __init__(self):
+            self.calls = []
+
+        def computeMoFREAKFromFile(self, video, out, clear):
+            self.calls.append(video)
+            harness.write_atomic(out, [b"rows\n"])
+
+    vid = tmp_path / "v.npy"
+    np.save(vid, np.zeros((9, 2, 2), np.uint8))
+    out = tmp_path / "out"
+    os.makedirs(out)
+    (out / "v.npy.mofreak.tmp").write_bytes(b"trunc")  # what the killed run left
+    m = Rec()
+    assert harness.compute_mofreak_files([str(vid)], str(out), m, skip_existing=True) == [str(out / "v.npy.mofreak")]
+    assert m.calls == [str(vid)] and (out / "v.npy.mofreak").read_bytes() == b"rows\n"
+    assert not (out / "v.npy.mofreak.tmp").exists()
+    # a complete file -- even an empty one -- is a finished video
+    (out / "v.npy.mofreak").write_bytes(b"")
+    m2 = Rec()
+    assert harness.compute_mofreak_files([str(vid)], str(out), m2, skip_existing=True) == [] and m2.calls == []

@@ -420,8 +420,7 @@ def test_bounds_checking_build_of_the_tile_kernel(oracle):
     import subprocess
     import sys
     from mofreak_amd import build
-    if not os.path.exists(build.DEBUG_LIB_PATH):
-        build.build_native(debug=True)
+    build.build_native(debug=True)  # rebuilt whenever a source is newer than it (same check as the product build)
     code = r"""
 import sys, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r)
@@ -480,6 +479,68 @@ def test_pipelined_stream_rows_equal_the_whole_stack_call(gpu_ctx, oracle, pinne
     with pytest.raises(M.api.MoFREAKError) as e:
         gpu_ctx.extract_stream_pipelined_host(src, kps, chunk_frames=16, rows_out=small)
     assert e.value.code == M.api.ERR_CAPACITY
+    assert str((T - 5) * len(kps)) in str(e.value)  # the error names the size a retry needs
+
+
+# ------------------------------------------------------------------ many clips in one call (BASELINE config 4)
+def _clip_set(rng, W, H, lengths):
+    pool = synth.synth_stack(max(lengths) + 7, W, H)
+    return [np.ascontiguousarray(pool[(3 * i) % 7: (3 * i) % 7 + t]) for i, t in enumerate(lengths)]
+
+
+@pytest.mark.parametrize("chunk", [0, 9, 23, 64])
+def test_clips_in_one_call_equal_one_call_per_clip(gpu_ctx, chunk):
+    """mofreak_extract_clips: the dataset loop's body (main.cpp:862-921) for many videos at once.  Rows and per-clip
+    offsets equal those of mofreak_extract_stream clip by clip -- pairs never cross a clip boundary, frame numbers restart
+    in every clip, clips no longer than the gap (and empty ones) yield nothing -- whatever the window size (windows
+    that cut clips in the middle, windows that hold several clips), page-locked and ordinary clips mixed."""
+    W, H = 320, 240
+    rng = np.random.default_rng(chunk)
+    lengths = [20, 6, 5, 0, 31, 1, 12, 7, 40, 3, 9]
+    clips = _clip_set(rng, W, H, lengths)
+    pinned = []
+    for i in (0, 4, 7):  # some of them in page-locked memory
+        buf = gpu_ctx.host_alloc(clips[i].shape)
+        buf[:] = clips[i]
+        clips[i] = buf
+        pinned.append(buf)
+    kps = synth.random_keypoints(rng, 300, W, H, sizes=(7.0, 8.4, 12.0))  # some of them erased near the border
+    want = [gpu_ctx.extract_stream_host(c, kps) if len(c) else np.zeros(0, M.api.ROW_DTYPE) for c in clips]
+    rows, offs = gpu_ctx.extract_clips(clips, kps, chunk_frames=chunk)
+    assert offs[0] == 0 and offs[-1] == len(rows) == sum(len(w) for w in want)
+    for i, w in enumerate(want):
+        assert rows[offs[i]:offs[i + 1]].tobytes() == w.tobytes(), f"clip {i}"
+        if len(w):
+            assert w["frame_number"].min() == 4 and w["frame_number"].max() == lengths[i] - 2
+    assert len(want[1]) > 0 and len(want[2]) == 0 and len(want[5]) == 0
+    # rows into a device tensor (what the RCCL gather takes): same bytes
+    import torch
+    d_rows = torch.zeros(len(rows) * 32 + 64, dtype=torch.uint8, device="cuda")
+    n, offs2 = gpu_ctx.extract_clips(clips, kps, chunk_frames=chunk, rows_out=d_rows)
+    assert n == len(rows) and np.array_equal(offs, offs2)
+    assert d_rows[: n * 32].cpu().numpy().tobytes() == rows.tobytes() and int(d_rows[n * 32:].sum()) == 0
+    # a rows buffer that is too small: reported with the size needed, nothing written past the capacity
+    small = np.zeros(len(rows) // 2 + 1, M.api.ROW_DTYPE)
+    guard = small.copy()
+    with pytest.raises(M.api.MoFREAKError) as e:
+        gpu_ctx.extract_clips(clips, kps, chunk_frames=chunk, rows_out=small[:-1])
+    assert e.value.code == M.api.ERR_CAPACITY and str(len(rows)) in str(e.value)
+    assert small[-1:].tobytes() == guard[-1:].tobytes()
+    for buf in pinned:
+        gpu_ctx.host_free(buf)
+
+
+def test_clips_call_edge_cases(gpu_ctx):
+    W, H = 64, 48
+    kps = synth.dense_grid(W, H, 8, 7.0, 24)
+    rows, offs = gpu_ctx.extract_clips([], kps)
+    assert len(rows) == 0 and offs.tolist() == [0]
+    short = [np.zeros((t, H, W), np.uint8) for t in (5, 0, 3)]  # nothing longer than the gap: no pair at all
+    rows, offs = gpu_ctx.extract_clips(short, kps)
+    assert len(rows) == 0 and offs.tolist() == [0, 0, 0, 0]
+    one = synth.synth_stack(11, W, H)
+    rows, offs = gpu_ctx.extract_clips([one], kps)
+    assert rows.tobytes() == gpu_ctx.extract_stream_host(one, kps).tobytes() and offs.tolist() == [0, len(rows)]
 
 
 # ------------------------------------------------------------------ frame preparation (SURVEY 8(f) row 2)
