@@ -1186,14 +1186,14 @@ int extract_clips_impl(mofreak_ctx *ctx, const uint8_t *const *clip_frames, cons
             c.n_pairs = np;
             c.first_frame_number = 0;
             c.pair_label = d_label + f0;  // labels restart with every clip (:401, :488); < 0: the pair straddles two clips
-            c.pair_rows = static_cast<int32_t *>(P.d_pair_rows[b].ptr);
+            c.pair_rows = rows_of_pair.empty() ? nullptr : static_cast<int32_t *>(P.d_pair_rows[b].ptr);  // only when per-clip offsets are asked for
             c.desc = desc;
             c.valid = valid;
             c.rows = static_cast<mofreak_row *>(P.d_rows[b].ptr);
             c.capacity = n_items;
             c.block_offsets = static_cast<int64_t *>(ctx->compact_offsets.ptr);
             c.n_blocks = n_blocks;
-            HIP_TRY(ctx, hipMemsetAsync(c.pair_rows, 0, (size_t)np * sizeof(int32_t), ctx->stream));
+            if (c.pair_rows) HIP_TRY(ctx, hipMemsetAsync(c.pair_rows, 0, (size_t)np * sizeof(int32_t), ctx->stream));
             const int e = launch_compact(c, ctx->stream);
             if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("compact launch: ") + hipGetErrorString((hipError_t)e));
             HIP_TRY(ctx, hipMemcpyAsync(P.h_count[b], c.block_offsets + n_blocks, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));

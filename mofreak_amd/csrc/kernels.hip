@@ -519,22 +519,40 @@ __global__ __launch_bounds__(256) void compact_count_kernel(CompactArgs a)
 {
     const int64_t base = (int64_t)blockIdx.x * kCompactItemsPerBlock + threadIdx.x * 4;
     int cnt = 0;
-    int run_pair = -1, run = 0;  // rows of the pair this thread's items are in, flushed when the pair changes
+    int first_pair = -1, last_pair = -1, first_cnt = 0, last_cnt = 0;  // a thread's four items lie in at most two pairs (n_kp >= 4) ...
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         int pair = -1;
         const bool keep = compact_keeps(a, base + k, &pair);
         cnt += keep;
         if (a.pair_rows != nullptr && keep) {
-            if (pair != run_pair) {
-                if (run) atomicAdd(a.pair_rows + run_pair, run);
-                run_pair = pair;
-                run = 0;
+            if (first_pair < 0 || pair == first_pair) {
+                first_pair = pair;
+                ++first_cnt;
+            } else if (last_pair < 0 || pair == last_pair) {
+                last_pair = pair;
+                ++last_cnt;
+            } else {  // ... unless the list is shorter than that: count the item on its own
+                atomicAdd(a.pair_rows + pair, 1);
             }
-            ++run;
         }
     }
-    if (run) atomicAdd(a.pair_rows + run_pair, run);
+    if (a.pair_rows != nullptr) {
+        // Rows per pair: a wave's 256 items span few pairs, so one atomic per distinct pair and wave, not per thread
+        // (atomics on one address are served one after the other).
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int my_pair = side ? last_pair : first_pair, my_cnt = side ? last_cnt : first_cnt;
+            for (unsigned long long todo = __ballot(my_pair >= 0); todo;) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int pr = __shfl(my_pair, leader);
+                const bool mine = my_pair == pr;
+                const int sum = wave_sum(mine ? my_cnt : 0);
+                if (lane_id() == leader) atomicAdd(a.pair_rows + pr, sum);
+                todo &= ~__ballot(mine);
+            }
+        }
+    }
     int total;
     block_exclusive_scan_256(cnt, &total);
     if (threadIdx.x == 0) a.block_offsets[blockIdx.x] = total;

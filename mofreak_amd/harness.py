@@ -256,6 +256,24 @@ def compute_mofreak_files(video_paths: Sequence[str], out_dir: str, mofreak: MoF
     return written
 
 
+def _pinned_rows(mofreak, n_rows: int) -> np.ndarray:
+    """A page-locked row buffer of at least n_rows rows, kept on the instance (page-locking memory is slow)."""
+    buf = getattr(mofreak, "_row_buf", None)
+    if buf is None or len(buf) < n_rows:
+        if buf is not None:
+            mofreak._ctx.host_free(buf)
+        buf = mofreak._row_buf = mofreak._ctx.host_alloc((max(n_rows, 1),), api.ROW_DTYPE)
+    return buf
+
+
+def _pinned_bytes(mofreak, n: int):
+    import torch
+    buf = getattr(mofreak, "_root_buf", None)
+    if buf is None or buf.numel() < n:
+        buf = mofreak._root_buf = torch.empty(max(n, 1), dtype=torch.uint8, pin_memory=True)
+    return buf[:n]
+
+
 def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mofreak: MoFREAKUtilities, rank: int = 0,
                 world_size: int = 1, costs: Sequence[float] | None = None, group=None, on_device: bool = False,
                 workers: int = 1, batched: bool = True, keep_rows: bool = True) -> dict:
@@ -296,12 +314,15 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
         H, W = stacks[0].shape[1:]
         kps = prov(gap, W, H)
         cap = int(sum(max(s.shape[0] - gap, 0) for s in stacks)) * len(kps)
-        if torch.cuda.is_available():
+        if world_size > 1 and torch.cuda.is_available():
+            # rows stay in HBM until the gather has brought them to the root
             d_rows = torch.empty(max(cap, 1) * 32, dtype=torch.uint8, device=torch.device("cuda", mofreak._device))
             n_local, offs = mofreak._ctx.extract_clips(stacks, kps, rows_out=d_rows)
             local = None
-        else:  # no device: the C ABI says so (MOFREAK_ERR_NO_DEVICE); there is no CPU path
-            local, offs = mofreak._ctx.extract_clips(stacks, kps)
+        else:
+            # one rank: the rows are wanted on this host -- they travel back window by window under the pipeline's
+            # kernels, into page-locked memory (kept across calls).  (No device: the C ABI says so, MOFREAK_ERR_NO_DEVICE.)
+            local, offs = mofreak._ctx.extract_clips(stacks, kps, rows_out=_pinned_rows(mofreak, cap))
             n_local = len(local)
         for j, i in enumerate(mine):
             counts[i] = offs[j + 1] - offs[j]
@@ -346,7 +367,13 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
         if on_device:
             torch.cuda.synchronize()
         if rank == 0 and keep_rows:
-            all_rows = gathered.cpu().numpy().view(api.ROW_DTYPE).reshape(-1)  # the root's one device-to-host copy
+            if gathered.is_cuda:  # the root's one device-to-host copy, into page-locked memory kept across calls
+                host = _pinned_bytes(mofreak, gathered.numel())
+                host.copy_(gathered, non_blocking=True)
+                torch.cuda.synchronize()
+                all_rows = host.numpy().view(api.ROW_DTYPE).reshape(-1)
+            else:
+                all_rows = gathered.numpy().view(api.ROW_DTYPE).reshape(-1)
     else:
         per_rank = [n_local]
         if keep_rows:
