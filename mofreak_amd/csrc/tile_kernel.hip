@@ -27,10 +27,6 @@
 // ROI side exceeds 16 are left to the gather path (describe_kernel over a global integral) by the binning pass.
 #include "device_helpers.h"
 
-#ifndef MOFREAK_EXP_SKIP
-#define MOFREAK_EXP_SKIP 0   // stage ablation builds only (profiles/): bit mask of stages to leave out (1 MIP, 2 integral, 4 FREAK)
-#endif
-
 namespace mofreak {
 namespace {
 
@@ -708,7 +704,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     __syncthreads();  TILE_STAMP(0);
 
     // ================= stage 1: MIP
-    if (!(MOFREAK_EXP_SKIP & 1)) {
+    {  // <stage 1>  (mofreak_amd/tools/ab_tile.py --ablate builds copies of this file with a stage's block disabled)
         // per-lane constants of the bit pass: lane = 8*centre + offset (MoFREAKUtilities.cpp:56-70, 308-316)
         const int mc = lane >> 3, mi = lane & 7;
         const int mcx = (0xDDD99555u >> (4 * mc)) & 15, mcy = (0xD95D5D95u >> (4 * mc)) & 15;
@@ -829,7 +825,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     __syncthreads();  TILE_STAMP(1);
 
     // ================= stage 2: integral of |cur - prev| over tile + halo, modulo 2^16, in LDS
-    if (!(MOFREAK_EXP_SKIP & 2)) {
+    {  // <stage 2>
         // 2a: row pass, no workgroup barrier.  The 16 lanes of a DPP row share one region row: a lane owns 16 pixels,
         //     |cur - prev| and the running sum inside them come from v_sad_u8 on masked dwords, the lane totals are
         //     scanned across the row with four DPP adds.  A wave takes four region rows per step.
@@ -912,7 +908,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     }
 
     // ================= stage 3: FREAK on the difference image, one wave per group of four keypoints
-    if (!(MOFREAK_EXP_SKIP & 4)) {
+    {  // <stage 3>
         const uint32_t vv = lds0 + kOffScratch + wave * (kGroup * kVStride);   // this wave's box means [kGroup][kVStride]
         const uint32_t ibase = lds0 + kOffIntegral + 2 * (kIColOff - oy * kIPitch - ox);
         // per-lane constants (host-built, TileLane): the box-mean tasks of a group -- the outer two rings (whose boxes may

@@ -1,5 +1,7 @@
 """GPU parity: the HIP path, called through the C ABI, against the CPU oracle -- bit-exact, row by row of
 SURVEY.md section 8(a).  Every test needs a real MI355X and fails (never skips or falls back) without one."""
+import os
+
 import numpy as np
 import pytest
 
@@ -152,6 +154,51 @@ def test_c2_dense_grid_bit_exact(ctx_path, oracle):
     assert np.array_equal(desc, want_d)
     ones_app, ones_mot = np.unpackbits(desc[:, :8]).mean(), np.unpackbits(desc[:, 8:]).mean()
     assert 0.3 < ones_app < 0.7 and 0.3 < ones_mot < 0.8  # non-degenerate data
+
+
+def test_c2_all_1000_pairs_bit_exact(gpu_ctx, oracle):
+    """BASELINE.md's gate as it is written: byte-identical on C2 -- ALL 1000 pairs of the 1005-frame 640x480 stack, the
+    875-keypoint 16-px grid (875 000 descriptors), and the mixed-size variant of the same grid (sizes 8.4 .. 40.5 cycling
+    over the grid: tile path and gather path, some keypoints erased by FREAK's border filter) on every 8th pair."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    c = synth.CONFIGS["C2"]
+    W, H, n_pairs = c["W"], c["H"], 1000
+    fr = synth.synth_stack(n_pairs + 5, W, H)
+    kps = synth.config_grid("C2")
+    assert len(kps) == 875
+    d_fr, d_kps = torch.from_numpy(fr).cuda(), torch.from_numpy(kps).cuda()
+    desc = torch.empty((n_pairs * len(kps), 16), dtype=torch.uint8, device="cuda")
+    valid = torch.empty(n_pairs * len(kps), dtype=torch.uint8, device="cuda")
+    gpu_ctx.extract_pairs(d_fr[5:], d_fr[:n_pairs], W, H, n_pairs, d_kps, desc, valid)
+    gpu_ctx.synchronize()
+    gpu_ctx.check_status()
+    got_d, got_v = desc.cpu().numpy().reshape(n_pairs, len(kps), 16), valid.cpu().numpy().reshape(n_pairs, len(kps))
+    f = oracle.Freak()
+    workers = max(1, min(16, len(os.sched_getaffinity(0))))
+
+    def one(p):
+        d, v = f.extract_pair(fr[p + 5], fr[p], kps)  # the C oracle releases the GIL
+        return int((got_v[p] != v).sum()) + int((got_d[p] != d).any(axis=1).sum())
+
+    with ThreadPoolExecutor(workers) as ex:
+        bad = sum(ex.map(one, range(n_pairs)))
+    assert bad == 0, f"{bad} of {n_pairs * len(kps)} descriptors differ from the oracle"
+    assert got_v.all()
+    # the mixed-size variant
+    mixed = kps.copy()
+    mixed[:, 2] = np.float32([8.4, 12.0, 18.0, 27.0, 40.5])[np.arange(len(kps)) % 5]
+    sel = np.arange(0, n_pairs, 8)
+    d2, v2 = gpu_ctx.extract_pairs_host(fr[sel + 5], fr[sel], mixed)
+    d2, v2 = d2.reshape(len(sel), len(kps), 16), v2.reshape(len(sel), len(kps))
+
+    def one_mixed(i):
+        d, v = f.extract_pair(fr[sel[i] + 5], fr[sel[i]], mixed)
+        return int((v2[i] != v).sum()) + int((d2[i] != d).any(axis=1).sum())
+
+    with ThreadPoolExecutor(workers) as ex:
+        bad = sum(ex.map(one_mixed, range(len(sel))))
+    assert bad == 0 and 0.5 < v2.mean() < 1.0
 
 
 def test_mixed_sizes_random_positions_bit_exact(ctx_path, oracle):
