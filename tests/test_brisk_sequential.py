@@ -1,0 +1,76 @@
+"""oracle/brisk_oracle.c against tests/helpers/brisk_sequential.py -- a second, independent reading of the reference's
+keypoint search (brisk.cpp:590-1644) written from the source alone: sequential, one candidate at a time, every score
+the reference asks for stored in a dictionary, pyramid from the literal SSE emulations, scores from the max-min form.
+
+This pins nothing (the reference has no detector vectors and does not build here); it separates "the oracle agrees
+with the kernels" from "the oracle agrees with the reference's control flow": the tie and score-cache logic is the part
+the oracle and the device kernels were written side by side for.  Inputs are the tie-heavy ones of
+tests/test_detector_gpu.py::test_ties_are_broken_like_the_sequential_reference, where the outcome depends on which cache
+cells are filled when each candidate is reached.  The keypoints of this restatement are also frozen in
+tests/golden/brisk_sequential.npz (tests/golden/make_brisk_sequential.py) so that the GPU tests can compare the device
+with them directly."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+import brisk_sequential as BS  # noqa: E402
+from test_brisk_oracle import _halfsample_simd, _twothird_simd  # noqa: E402
+
+from mofreak_amd import synth  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "brisk_sequential.npz")
+TIE_CASES = [(1, 4, 3, 30), (2, 3, 2, 30), (3, 2, 4, 20), (4, 6, 5, 40), (5, 4, 1, 30)]
+
+
+def quantised_noise(seed, h, w, levels=4, block=3):
+    """Blocky few-level noise: plenty of equal corner scores next to each other, i.e. isMax2D ties."""
+    rng = np.random.default_rng(seed)
+    small = rng.integers(0, levels, ((h + block - 1) // block, (w + block - 1) // block)) * (255 // (levels - 1))
+    return np.kron(small, np.ones((block, block), np.int64))[:h, :w].astype(np.uint8)
+
+
+def sequential_keypoints(img, threshold, octaves):
+    ss = BS.ScaleSpace(img, octaves, _halfsample_simd, _twothird_simd)
+    kps = ss.get_keypoints(threshold)
+    out = np.zeros(len(kps), O.KEYPOINT_DTYPE)
+    for i, k in enumerate(kps):
+        out[i] = k
+    return out, ss
+
+
+def cases():
+    for seed, levels, block, thr in TIE_CASES:
+        yield f"ties{seed}", quantised_noise(seed, 180, 240, levels, block), thr, 3
+    fr = synth.moving_objects_stack(6, 320, 240)
+    diff = np.abs(fr[5].astype(np.int16) - fr[0].astype(np.int16)).astype(np.uint8)
+    for octaves in (0, 1, 2, 3, 4):
+        yield f"moving_o{octaves}", diff, 30, octaves
+    yield "ties_o1", quantised_noise(7, 120, 160, 3, 2), 25, 1
+
+
+@pytest.mark.parametrize("name,img,thr,octaves", list(cases()), ids=[c[0] for c in cases()])
+def test_oracle_equals_the_sequential_restatement(name, img, thr, octaves):
+    got, ss = sequential_keypoints(img, thr, octaves)
+    want = O.brisk_detect(img, thr, octaves)
+    assert len(got) == len(want) and len(got) > 10, (len(got), len(want))
+    assert got.tobytes() == want.tobytes(), next(i for i in range(len(got)) if got[i].tobytes() != want[i].tobytes())
+    if name.startswith("ties"):
+        # the input really is about ties: many accepted candidates have an equal neighbour in the cache
+        ties = 0
+        for i, l in enumerate(ss.L):
+            for (x, y), s in list(l.cache.items()):
+                if s >= thr and any(l.raw(x + dx, y + dy) == s for dx in (-1, 0, 1) for dy in (-1, 0, 1) if (dx, dy) != (0, 0)):
+                    ties += 1
+        assert ties > 20
+
+
+def test_golden_file_is_what_the_restatement_produces():
+    z = np.load(GOLDEN)
+    for name, img, thr, octaves in cases():
+        got, _ = sequential_keypoints(img, thr, octaves)
+        assert z[name].tobytes() == got.tobytes(), name

@@ -109,6 +109,22 @@ def test_ties_are_broken_like_the_sequential_reference(ctx, seed, levels, block,
     assert len(want_all) == len(kps)
 
 
+def test_device_equals_the_independent_sequential_restatement(ctx):
+    """The device against tests/golden/brisk_sequential.npz: keypoints of the pure-Python, one-candidate-at-a-time
+    restatement written from brisk.cpp alone (tests/helpers/brisk_sequential.py; the oracle is not involved here).
+    Tie-heavy inputs, a moving-object difference image at every pyramid depth."""
+    import test_brisk_sequential as T
+    z = np.load(T.GOLDEN)
+    n = 0
+    for name, img, thr, octaves in T.cases():
+        kps, offs, resp, layer = ctx.detect_pairs_host(img, None, thr, octaves)
+        w = z[name]
+        want = (np.stack([w["x"], w["y"], w["size"]], 1).astype(np.float32).reshape(-1, 3), w["response"].copy(), w["layer"].copy())
+        _assert_same_keypoints((kps, resp, layer), want, name)
+        n += len(w)
+    assert n > 20000
+
+
 def test_rows_wider_than_one_chunk(ctx):
     """Layer rows longer than the 2048 pixels the candidate kernel takes per chunk (and than one pyramid block row):
     keypoints next to the chunk boundary see their neighbours across it."""
