@@ -409,6 +409,59 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
     return out
 
 
+def split_stream(T: int, world_size: int, gap: int = synth.GAP_FOR_FRAME_DIFFERENCE) -> list[tuple[int, int]]:
+    """One long stream over `world_size` ranks (the optional variant of config 5): contiguous pieces of
+    the T - gap processed frames, as even as possible.  Rank r gets (f0, f1): it loads frames [f0, f1) -- the first
+    `gap` of them are its halo, the frames its first pairs look back to (the reference's frame queue,
+    MoFREAKUtilities.cpp:391-399, 485-487), loaded twice across ranks, never exchanged -- and produces the rows of
+    frames f0 + gap .. f1 - 1.  A rank with nothing to do gets (0, 0)."""
+    n_pairs = max(T - gap, 0)
+    out = []
+    for r in range(world_size):
+        p0, p1 = n_pairs * r // world_size, n_pairs * (r + 1) // world_size
+        out.append((p0, p1 + gap) if p1 > p0 else (0, 0))
+    return out
+
+
+def run_stream_sharded(frames, mofreak: MoFREAKUtilities, rank: int = 0, world_size: int = 1, group=None, on_device: bool = False,
+                       chunk_frames: int = 256) -> dict:
+    """ONE long gray stream (T, H, W) split over the ranks with a gap-frame halo; rows gathered to rank 0 in rank order,
+    i.e. in frame order: byte-identical to a one-rank run over the whole stream.  frames: an array every rank can index
+    (a memory-mapped file, or the rank's own decode of its piece's frame range); only [f0, f1) is touched here.
+    Dense-grid (shared) keypoint providers only: the pipelined frame loop takes one list for every frame."""
+    import time
+
+    import torch
+
+    T, H, W = frames.shape
+    gap = mofreak._ctx.params.gap_for_frame_difference
+    prov = mofreak.keypoint_provider
+    if isinstance(prov, str) or not getattr(prov, "shared", False):
+        raise ValueError("run_stream_sharded needs a shared keypoint list (dense grid)")
+    f0, f1 = split_stream(T, world_size, gap)[rank]
+    t0 = time.perf_counter()
+    if f1 > f0:
+        piece = np.ascontiguousarray(frames[f0:f1])
+        rows = mofreak._ctx.extract_stream_pipelined_host(piece, prov(gap, W, H), chunk_frames=chunk_frames)
+        rows["frame_number"] += f0  # labels run on across the pieces (:401, :488)
+    else:
+        rows = np.zeros(0, api.ROW_DTYPE)
+    t_compute = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    if world_size > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu")
+        buf = torch.from_numpy(rows.view(np.uint8).reshape(-1).copy()).to(dev)
+        gathered, per_rank = gather_rows(buf, len(rows), dst=0, group=group)
+        all_rows = gathered.cpu().numpy().view(api.ROW_DTYPE).reshape(-1) if rank == 0 else None
+    else:
+        all_rows, per_rank = rows, [len(rows)]
+    out = {"compute_s": t_compute, "gather_s": time.perf_counter() - t1, "frames_here": (f0, f1), "rows_here": int(len(rows)),
+           "rows_per_rank": per_rank}
+    if rank == 0:
+        out["rows"] = all_rows
+    return out
+
+
 # ------------------------------------------------------------------ .mofreak file utilities (SURVEY.md 8(f) row 3)
 CHOP_LINES = 40000  # src/merge_mofreak_files.py:96
 

@@ -93,3 +93,45 @@ def test_c4_two_ranks_write_the_bytes_of_one_rank(tmp_path):
         a, b = (one / (name + ".mofreak")).read_bytes(), (two / (name + ".mofreak")).read_bytes()
         assert a == b and len(a) > 0, name
     assert sorted(os.listdir(one)) == sorted(os.listdir(two))
+
+
+# ------------------------------------------------------------------ one long stream split over ranks (optional)
+def _stream_frames():
+    c = synth.CONFIGS["C5"]
+    return synth.synth_stack(31, c["W"], c["H"])
+
+
+def _stream_mofreak():
+    c = synth.CONFIGS["C5"]
+    return harness.MoFREAKUtilities(harness.TRECVID, device=0, keypoint_provider=harness.dense_grid_provider(c["step"], c["size"], c["lo"]))
+
+
+def _stream_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mo = _stream_mofreak()
+        try:
+            res = harness.run_stream_sharded(_stream_frames(), mo, rank, world, chunk_frames=12)
+        finally:
+            mo.close()
+        if rank == 0:
+            np.save(os.path.join(out_dir, "rows.npy"), res["rows"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_stream_over_two_ranks_equals_the_whole_stream(tmp_path):
+    """A 720x576 stream cut into two pieces with a 5-frame halo, one piece per rank (both on device 0 here): the gathered
+    rows are those of the frame loop over the whole stream, byte for byte."""
+    frames = _stream_frames()
+    mo = _stream_mofreak()
+    try:
+        want = mo._ctx.extract_stream_host(frames, synth.config_grid("C5"))
+        one = harness.run_stream_sharded(frames, mo)["rows"]
+    finally:
+        mo.close()
+    assert one.tobytes() == want.tobytes() and len(want) == 26 * 5103
+    mp.spawn(_stream_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert np.load(tmp_path / "rows.npy").tobytes() == want.tobytes()

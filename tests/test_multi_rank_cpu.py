@@ -188,3 +188,63 @@ def test_a_killed_writer_leaves_no_file_that_resume_would_skip(tmp_path, monkeyp
     (out / "v.npy.mofreak").write_bytes(b"")
     m2 = Rec()
     assert harness.compute_mofreak_files([str(vid)], str(out), m2, skip_existing=True) == [] and m2.calls == []
+
+
+# ------------------------------------------------------------------ one long stream over several ranks (gap-frame halo)
+def test_split_stream_pieces_cover_every_processed_frame_once():
+    for T, world in [(2005, 8), (90000, 8), (17, 4), (7, 8), (5, 3), (0, 2), (6, 1)]:
+        pieces = harness.split_stream(T, world, 5)
+        assert len(pieces) == world
+        produced = []
+        for f0, f1 in pieces:
+            if f1 > f0:
+                assert f1 - f0 > 5 and 0 <= f0 and f1 <= T  # at least one pair behind the 5-frame halo
+                produced += list(range(f0 + 5, f1))           # the frames whose rows this rank produces
+        assert produced == list(range(5, T)), (T, world)       # every processed frame exactly once, in rank order
+        sizes = [f1 - f0 - 5 for f0, f1 in pieces if f1 > f0]
+        assert not sizes or max(sizes) - min(sizes) <= 1
+
+
+class _FakeCtx:
+    class params:
+        gap_for_frame_difference = 5
+
+    def extract_stream_pipelined_host(self, frames, kps, chunk_frames=256):
+        T = frames.shape[0]
+        n = max(T - 5, 0) * len(kps)
+        rows = np.zeros(n, api.ROW_DTYPE)
+        rows["frame_number"] = 4 + np.arange(n) // len(kps)
+        rows["x"] = np.tile(kps[:, 0], max(T - 5, 0))
+        # depends on BOTH frames of the pair: a wrong halo shows
+        pairs = (frames[5:].reshape(T - 5, -1).sum(1) * 3 + frames[:T - 5].reshape(T - 5, -1).sum(1)) % 251 if T > 5 else np.zeros(0)
+        rows["appearance"][:, 0] = np.repeat(pairs, len(kps))
+        return rows
+
+
+class _FakeStreamMoFREAK:
+    def __init__(self):
+        self._ctx = _FakeCtx()
+        self.keypoint_provider = harness.dense_grid_provider(16, 12.0, 38)
+
+
+def _stream_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frames = np.random.default_rng(9).integers(0, 256, (43, 96, 128), dtype=np.uint8)
+        res = harness.run_stream_sharded(frames, _FakeStreamMoFREAK(), rank, world)
+        if rank == 0:
+            np.save(os.path.join(outdir, "rows.npy"), res["rows"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_stream_rows_equal_the_one_rank_stream(tmp_path, world):
+    frames = np.random.default_rng(9).integers(0, 256, (43, 96, 128), dtype=np.uint8)
+    want = harness.run_stream_sharded(frames, _FakeStreamMoFREAK())["rows"]
+    assert len(want) == 38 * len(harness.dense_grid_provider(16, 12.0, 38)(5, 128, 96)) > 0
+    mp.spawn(_stream_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "rows.npy")
+    assert got.tobytes() == want.tobytes()
