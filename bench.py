@@ -188,6 +188,25 @@ def detector_figures(ctx, torch, synth, W, H, pairs=32, steps=3, with_cpu=True):
                         "detect_and_describe_achieved": (det_bytes + desc_bytes) / both_s / 1e9,
                         "detect_and_describe_frac": (det_bytes + desc_bytes) / both_s / 1e9 / HBM_PEAK_GBS,
                         "note": "host-timed calls (launch gaps included), wall clock around synchronising calls"}}
+    # the reference's whole frame loop as ONE call (mofreak_compute_stream: detector -> descriptors -> rows) on a stack of
+    # pairs + 5 frames: two lanes side by side by default, one batch after the other for comparison
+    try:
+        T = pairs + 5
+        stack = torch.from_numpy(np.stack([fr[t % len(fr)] for t in range(T)])).cuda()
+        rows = torch.empty(pairs * 12000 * 32, dtype=torch.uint8, device="cuda")
+        loop = {}
+        for mode in (True, False):
+            ctx.set_loop_pipelining(mode)
+            ctx.compute_stream(stack, T, W, H, rows, capacity=rows.numel() // 32)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                n_rows, n_loop_kp = ctx.compute_stream(stack, T, W, H, rows, capacity=rows.numel() // 32)
+            loop["two_lanes" if mode else "one_lane"] = pairs * steps / (time.perf_counter() - t0)
+        out["frame_loop"] = {"pairs_per_s": loop["two_lanes"], "one_lane_pairs_per_s": loop["one_lane"], "rows_per_pair": n_rows / pairs,
+                             "note": "mofreak_compute_stream on a device-resident stack, rows compacted on the device"}
+    finally:
+        ctx.set_loop_pipelining(True)
     if with_cpu:  # part of the cpu_baseline leg: the oracle as a reported baseline, never as the product
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
@@ -401,7 +420,7 @@ def bench_resident(args):
                 out["detector"] = detector_figures(ctx, torch, synth, W, H, with_cpu=not args.no_cpu_baseline)
                 # the detector's tie rounds are chains of short launches per call: more pairs per call share them
                 big = detector_figures(ctx, torch, synth, W, H, pairs=128, steps=2, with_cpu=False)
-                out["detector"]["at_128_pairs_per_call"] = {k: big[k] for k in ("pairs_per_s", "detect_and_describe_pairs_per_s")}
+                out["detector"]["at_128_pairs_per_call"] = {k: big[k] for k in ("pairs_per_s", "detect_and_describe_pairs_per_s", "frame_loop")}
             except Exception as e:  # never let the side figure take the metric line down
                 out["detector"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

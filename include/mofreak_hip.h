@@ -115,6 +115,9 @@ int mofreak_check_status(mofreak_ctx *ctx);
 #define MOFREAK_PATH_AUTO 0
 #define MOFREAK_PATH_GATHER 1
 int mofreak_set_path(mofreak_ctx *ctx, int path);
+/* mofreak_compute_stream's software pipelining (on by default).  0: one batch after the other on the context's stream
+ * (A/B measurements; the rows do not depend on it). */
+int mofreak_set_loop_pipelining(mofreak_ctx *ctx, int enable);
 
 /* Per-call device timing, measured with HIP events on the context's stream around the binning kernels, the tile
  * kernel and the gather path of every extract call.  Off by default. */
@@ -254,7 +257,9 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
  * stack already in memory: for every frame from index gap on, BRISK keypoints on |frame - frame[-gap]|
  * (mofreak_detect_pairs), their MoFREAK descriptors (mofreak_extract_pairs) and the rows FREAK did not erase, in the
  * order the reference appends them (mofreak_compact_rows).  Equivalent to those three calls; frames cross the host
- * boundary once.  Synchronises the stream.
+ * boundary once.  Synchronises the stream.  From 16 processed frames up the loop is software pipelined: the frames are
+ * taken in batches and the detector of batch k + 1 runs on one HIP stream beside the descriptors of batch k on another
+ * (the detector is bound by vector issue, the descriptors of large keypoints by memory latency); the rows are the same.
  */
 int mofreak_compute_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W, int H, int threshold, int octaves,
                            mofreak_row *rows_out, int64_t rows_capacity, int64_t *n_rows_out, int64_t *n_keypoints_out,

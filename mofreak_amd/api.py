@@ -32,7 +32,7 @@ assert ROW_DTYPE.itemsize == 32
 EXPORTS = [
     "mofreak_abi_version", "mofreak_build_flags", "mofreak_default_params", "mofreak_create", "mofreak_destroy", "mofreak_last_error",
     "mofreak_set_stream", "mofreak_synchronize", "mofreak_reserve", "mofreak_check_status",
-    "mofreak_set_profiling", "mofreak_get_profile", "mofreak_set_path", "mofreak_get_tile_stamps", "mofreak_bgr_to_gray", "mofreak_bow_assign", "mofreak_bow_histogram",
+    "mofreak_set_profiling", "mofreak_get_profile", "mofreak_set_path", "mofreak_set_loop_pipelining", "mofreak_get_tile_stamps", "mofreak_bgr_to_gray", "mofreak_bow_assign", "mofreak_bow_histogram",
     "mofreak_extract_pairs", "mofreak_compact_rows", "mofreak_extract_stream", "mofreak_format_rows",
     "mofreak_extract_stream_pipelined", "mofreak_extract_clips", "mofreak_host_alloc", "mofreak_host_free",
     "mofreak_parse_rows", "mofreak_diff_integral", "mofreak_mip19", "mofreak_roi19", "mofreak_freak_info",
@@ -99,6 +99,7 @@ def load() -> C.CDLL:
     L.mofreak_check_status.argtypes = [vp]
     L.mofreak_set_profiling.argtypes = [vp, i32]
     L.mofreak_set_path.argtypes = [vp, i32]
+    L.mofreak_set_loop_pipelining.argtypes = [vp, i32]
     L.mofreak_get_tile_stamps.argtypes = [vp, vp, i32, i32]
     L.mofreak_get_profile.argtypes = [vp, C.POINTER(Profile), i32]
     L.mofreak_bgr_to_gray.argtypes = [vp, vp, i32, i32, i64, i64, i32, vp, C.c_uint]
@@ -243,6 +244,10 @@ class Context:
     def set_path(self, path: int):
         """PATH_AUTO (tile kernel + gather path for large keypoints) or PATH_GATHER (gather path for everything)."""
         self._check(self._lib.mofreak_set_path(self._h, path))
+
+    def set_loop_pipelining(self, enable: bool):
+        """compute_stream's software pipelining (detector of batch k + 1 beside the descriptors of batch k): on by default."""
+        self._check(self._lib.mofreak_set_loop_pipelining(self._h, 1 if enable else 0))
 
     def get_tile_stamps(self, reset: bool = True) -> np.ndarray:
         out = np.zeros(32, np.uint64)

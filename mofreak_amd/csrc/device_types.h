@@ -170,6 +170,9 @@ struct CompactArgs {
     // yields no rows.  pair_rows[p] (zeroed by the caller) receives the number of rows pair p produced.  Both may be null.
     const int32_t *pair_label = nullptr;
     int32_t *pair_rows = nullptr;
+    // Rows appended behind the rows of earlier launches without a host round trip in between (the pipelined frame loop):
+    // *row_base (device) is added to every row position of this launch and advanced by its total.  May be null.
+    int64_t *row_base = nullptr;
 };
 
 constexpr int kCompactItemsPerBlock = 1024;

@@ -558,11 +558,12 @@ __global__ __launch_bounds__(256) void compact_count_kernel(CompactArgs a)
     if (threadIdx.x == 0) a.block_offsets[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(256) void compact_scan_kernel(int64_t *block_offsets, int n_blocks)
+__global__ __launch_bounds__(256) void compact_scan_kernel(int64_t *block_offsets, int n_blocks, int64_t *row_base)
 {
-    // single workgroup: exclusive scan of the per-block counts; block_offsets[n_blocks] = total
+    // single workgroup: exclusive scan of the per-block counts; block_offsets[n_blocks] = total.  With row_base the
+    // positions start behind the rows of earlier launches (*row_base), which this launch's total is added to.
     __shared__ int64_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
+    if (threadIdx.x == 0) carry_s = row_base ? *row_base : 0;
     __syncthreads();
     for (int b0 = 0; b0 < n_blocks; b0 += 256) {
         const int b = b0 + threadIdx.x;
@@ -575,7 +576,10 @@ __global__ __launch_bounds__(256) void compact_scan_kernel(int64_t *block_offset
         if (threadIdx.x == 0) carry_s = carry + total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) block_offsets[n_blocks] = carry_s;
+    if (threadIdx.x == 0) {
+        block_offsets[n_blocks] = carry_s;
+        if (row_base) *row_base = carry_s;
+    }
 }
 
 __global__ __launch_bounds__(256) void compact_scatter_kernel(CompactArgs a)
@@ -680,7 +684,7 @@ int launch_compact(const CompactArgs &a, void *stream)
     if (a.n_blocks > 0) {
         hipLaunchKernelGGL(compact_count_kernel, dim3(a.n_blocks), dim3(256), 0, s, a);
     }
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(256), 0, s, a.block_offsets, a.n_blocks);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(256), 0, s, a.block_offsets, a.n_blocks, a.row_base);
     if (a.n_blocks > 0) {
         hipLaunchKernelGGL(compact_scatter_kernel, dim3(a.n_blocks), dim3(256), 0, s, a);
     }

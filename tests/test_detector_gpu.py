@@ -125,6 +125,48 @@ def test_device_equals_the_independent_sequential_restatement(ctx):
     assert n > 20000
 
 
+@pytest.mark.parametrize("T,W,H", [(21, 320, 240), (25, 400, 300), (60, 320, 240), (72, 212, 160)])
+def test_pipelined_frame_loop_rows_equal_the_sequential_loop_and_the_oracle(ctx, T, W, H):
+    """mofreak_compute_stream from 16 processed frames up: batches of frames, the detector of batch k + 1 on one stream
+    beside the descriptors of batch k on another.  Rows byte-identical to the same call without pipelining and to the oracle's
+    frame loop (detector -> FREAK + MIP -> rows), for two even batches, two uneven ones, and several batches of 32 with a
+    short last one."""
+    fr = synth.moving_objects_stack(T, W, H, seed=T)
+    ctx.set_loop_pipelining(True)
+    got = ctx.compute_stream_host(fr)
+    ctx.set_loop_pipelining(False)
+    try:
+        plain = ctx.compute_stream_host(fr)
+    finally:
+        ctx.set_loop_pipelining(True)
+    assert got.tobytes() == plain.tobytes() and len(got) > 200
+    lists = [O.brisk_detect(O.absdiff(fr[t], fr[t - 5])) for t in range(5, T)]
+    kps = np.concatenate([np.stack([k["x"], k["y"], k["size"]], 1) for k in lists]).astype(np.float32)
+    offs = np.concatenate([[0], np.cumsum([len(k) for k in lists])]).astype(np.int64)
+    want = O.Freak().extract_stream(fr, kps, offs)
+    assert got.tobytes() == want.tobytes()
+    assert got["frame_number"].min() == 4 and got["frame_number"].max() == T - 2
+    # again on the same context: the buffers and events of the first call are reused
+    assert ctx.compute_stream_host(fr).tobytes() == want.tobytes()
+
+
+def test_pipelined_frame_loop_grows_its_keypoint_buffers(ctx):
+    """More keypoints per frame than the batch buffers were made for (8192): reported inside the call, buffers grown, same rows."""
+    rng = np.random.default_rng(3)
+    T, W, H = 22, 640, 480
+    fr = rng.integers(0, 2, (T, H // 4, W // 4)).astype(np.uint8) * 200
+    fr = np.kron(fr, np.ones((1, 4, 4), np.uint8))  # blocky binary noise: corners everywhere
+    ctx.set_detect_capacity(1 << 20)
+    try:
+        got = ctx.compute_stream_host(fr, capacity=T * 40000)
+        ctx.set_loop_pipelining(False)
+        plain = ctx.compute_stream_host(fr, capacity=T * 40000)
+    finally:
+        ctx.set_loop_pipelining(True)
+        ctx.set_detect_capacity(131072)
+    assert len(got) > 17 * 8192 and got.tobytes() == plain.tobytes()
+
+
 def test_rows_wider_than_one_chunk(ctx):
     """Layer rows longer than the 2048 pixels the candidate kernel takes per chunk (and than one pyramid block row):
     keypoints next to the chunk boundary see their neighbours across it."""
