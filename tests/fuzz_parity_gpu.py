@@ -2,7 +2,9 @@
 """Randomised parity run, GPU against the oracle (a tool, not part of the test suites: `python tests/fuzz_parity_gpu.py
 [seconds] [seed]` on a GPU box).  Every round draws a frame size, a keypoint population (counts, sizes, integer or
 fractional coordinates, shared list or one list per pair), random byte frames or the synthetic ones, and compares
-descriptors and validity flags byte for byte; every few rounds also the detector's keypoints on a moving-object pair.
+descriptors and validity flags byte for byte; every few rounds also the detector's keypoints on a moving-object pair,
+a set of clips of random lengths through mofreak_extract_clips (against one call per clip), and the whole frame loop
+(mofreak_compute_stream) on two lanes against the one-lane loop.
 A new context every 20 s, a third of them with random FREAK parameters (bit mode, orientation / scale normalisation)."""
 import os
 import sys
@@ -24,7 +26,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
-    rounds = descriptors = detector_rounds = 0
+    rounds = descriptors = detector_rounds = clip_rounds = loop_rounds = 0
     while time.time() < t_end:
         # a context (and an oracle) per parameter set: the default one most of the time
         if rng.integers(0, 3) == 0:
@@ -71,7 +73,32 @@ def main():
                       print(f"DETECTOR MISMATCH round {rounds} seed {seed}: {Wd}x{Hd} octaves {octaves}: {len(k)} vs {len(wk)} keypoints")
                       sys.exit(1)
                   detector_rounds += 1
-    print(f"fuzz ok: {rounds} rounds, {descriptors} descriptors, {detector_rounds} detector rounds, seed {seed}")
+              if rounds % 7 == 0 and not par:  # many clips in one pipelined call == one call per clip
+                  Wc, Hc = int(rng.choice([96, 160, 320])), int(rng.choice([80, 120, 240]))
+                  lengths = [int(x) for x in rng.choice([0, 1, 5, 6, 7, 9, 14, 23, 40], int(rng.integers(1, 9)))]
+                  pool = rng.integers(0, 256, (max(lengths) + 3, Hc, Wc), dtype=np.uint8)
+                  clips = [np.ascontiguousarray(pool[i % 3: i % 3 + t]) for i, t in enumerate(lengths)]
+                  ck = synth.random_keypoints(rng, int(rng.choice([3, 150, 700])), Wc, Hc, sizes=(7.0, 8.4, 12.0))
+                  rows_c, offs_c = ctx.extract_clips(clips, ck, chunk_frames=int(rng.choice([0, 6, 11, 30])))
+                  want_c = [ctx.extract_stream_host(c, ck) if len(c) else np.zeros(0, M.api.ROW_DTYPE) for c in clips]
+                  if rows_c.tobytes() != (np.concatenate(want_c).tobytes() if want_c else b"") or \
+                          offs_c.tolist() != np.concatenate([[0], np.cumsum([len(w) for w in want_c])]).tolist():
+                      print(f"CLIPS MISMATCH round {rounds} seed {seed}: {Wc}x{Hc} lengths {lengths}")
+                      sys.exit(1)
+                  clip_rounds += 1
+              if rounds % 11 == 0 and not par:  # the frame loop on two lanes == on one lane
+                  Wl, Hl, Tl = int(rng.choice([160, 320, 400])), int(rng.choice([120, 240])), int(rng.choice([21, 26, 38, 70]))
+                  frl = synth.moving_objects_stack(Tl, Wl, Hl, seed=int(rng.integers(0, 1 << 30)))
+                  two = ctx.compute_stream_host(frl)
+                  ctx.set_loop_pipelining(False)
+                  one = ctx.compute_stream_host(frl)
+                  ctx.set_loop_pipelining(True)
+                  if two.tobytes() != one.tobytes():
+                      print(f"FRAME LOOP MISMATCH round {rounds} seed {seed}: {Wl}x{Hl} T {Tl}: {len(two)} vs {len(one)} rows")
+                      sys.exit(1)
+                  loop_rounds += 1
+    print(f"fuzz ok: {rounds} rounds, {descriptors} descriptors, {detector_rounds} detector rounds, {clip_rounds} clip-set rounds, "
+          f"{loop_rounds} frame-loop rounds, seed {seed}")
 
 
 if __name__ == "__main__":
