@@ -68,9 +68,10 @@ def test_python_mirror_io_semantics(native_lib, tmp_path):
 
 @pytest.mark.gpu
 def test_cpp_facade_extracts_a_clip_like_the_reference(facade, oracle, tmp_path):
-    """BASELINE config 1 shape: one 320x240 clip, DETECT_MOFREAK: .mofreak text identical to the oracle's."""
+    """BASELINE config 1 as it is specified: one 320x240 clip of 100 frames (95 processed frames, 204 keypoints each),
+    DETECT_MOFREAK: .mofreak text identical to the oracle's."""
     c = synth.CONFIGS["C1"]
-    T = 30
+    T = 100
     fr = synth.synth_stack(T, c["W"], c["H"])
     vid, out = tmp_path / "person01_boxing_d1.npy", tmp_path / "clip.mofreak"
     np.save(vid, fr)
