@@ -573,7 +573,7 @@ def main():
                     "one mofreak_extract_clips call per rank")
     ap.add_argument("--pageable", action="store_true", help="C4: clips in ordinary (pageable) host memory instead of page-locked buffers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=192, help="pairs of the workload the CPU oracle is timed on (about 25 core-seconds)")
+    ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs of the workload the CPU oracle is timed on and the GPU output is verified on (default: all 256 of a step, about 35 core-seconds)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL); 'gloo' + "
                     "--share-device rehearses the N > 1 control flow on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
