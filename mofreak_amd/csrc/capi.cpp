@@ -2002,6 +2002,18 @@ int compute_two_lanes(mofreak_ctx *ctx, const uint8_t *d_frames, int n_pairs, in
         if (k + 2 < n_batches && (rc = enqueue_detect(k + 2))) return rc;  // this lane's next batch, behind what was just queued
     }
     for (mofreak_ctx *c : lane) HIP_TRY(ctx, hipStreamSynchronize(c->loop.s_lane));
+    {  // what the helper lane's descriptor kernels flagged (ROI left the image, ...) belongs to the caller's context:
+       // mofreak_check_status(ctx) reads ctx's word only
+        int32_t theirs = 0, ours = 0;
+        HIP_TRY(ctx, hipMemcpy(&theirs, lane[1]->d_status, sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (theirs) {
+            HIP_TRY(ctx, hipMemcpy(&ours, ctx->d_status, sizeof(int32_t), hipMemcpyDeviceToHost));
+            ours |= theirs;
+            theirs = 0;
+            HIP_TRY(ctx, hipMemcpy(ctx->d_status, &ours, sizeof(int32_t), hipMemcpyHostToDevice));
+            HIP_TRY(ctx, hipMemcpy(lane[1]->d_status, &theirs, sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+    }
     int64_t rows = 0;
     HIP_TRY(ctx, hipMemcpy(&rows, row_base, sizeof(int64_t), hipMemcpyDeviceToHost));
     *total_rows = rows;
