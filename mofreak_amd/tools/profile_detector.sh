@@ -40,15 +40,20 @@ for f in sorted(glob.glob(f'{out}/pmc*/*/*counter_collection.csv')):
 calls = 3  # probe: 1 warm-up + 2 timed calls of 32 pairs
 names = sorted({c for k in tot for c in tot[k]})
 with open(f'gpurun_out/{tag}_detector_pmc.csv', 'w') as fh:
-    fh.write('kernel,launches_per_call,' + ','.join(f'{c}_per_call' for c in names) + ',valu_busy,lds_busy,wait_any_over_wave_cycles,hbm_MB_per_call\n')
+    # FETCH_SIZE counts a coalesced read at half its bytes and a scattered 64-byte fetch exactly (profiles/r03_fetch_calibration.txt)
+    scattered = {'describe_kernel', 'det_refine_kernel', 'det_tie_first_kernel', 'det_tie_chain_kernel'}
+    fh.write('kernel,launches_per_call,' + ','.join(f'{c}_per_call' for c in names) + ',valu_busy,lds_busy,wait_any_over_wave_cycles,hbm_MB_per_call,hbm_MB_per_call_fetch_x1,hbm_MB_per_call_fetch_x2,fetch_shape\n')
     for k in sorted(tot, key=lambda k: -tot[k].get('SQ_BUSY_CU_CYCLES', 0)):
         c = tot[k]
         per = {n: c.get(n, 0.0) / calls for n in names}
         busy = per.get('SQ_BUSY_CU_CYCLES', 0) or 1.0
-        hbm = (2 * per.get('FETCH_SIZE', 0) + per.get('WRITE_SIZE', 0)) * 1024 / 1e6
+        lo = (per.get('FETCH_SIZE', 0) + per.get('WRITE_SIZE', 0)) * 1024 / 1e6
+        hi = (2 * per.get('FETCH_SIZE', 0) + per.get('WRITE_SIZE', 0)) * 1024 / 1e6
+        hbm = lo if k in scattered else hi
         nl = len(launches[(k, 'SQ_WAVES')]) / calls if (k, 'SQ_WAVES') in launches else 0
         fh.write(f"{k},{nl:.1f}," + ','.join(f'{per[n]:.0f}' for n in names) +
                  f",{per.get('SQ_ACTIVE_INST_VALU', 0) / busy:.3f},{per.get('SQ_LDS_IDX_ACTIVE', 0) / busy:.3f},"
-                 f"{per.get('SQ_WAIT_ANY', 0) / max(per.get('SQ_WAVE_CYCLES', 0), 1):.3f},{hbm:.1f}\n")
+                 f"{per.get('SQ_WAIT_ANY', 0) / max(per.get('SQ_WAVE_CYCLES', 0), 1):.3f},{hbm:.1f},{lo:.1f},{hi:.1f},"
+                 f"{'scattered 64-B lines (FETCH_SIZE exact)' if k in scattered else 'coalesced (FETCH_SIZE x2)'}\n")
 print(open(f'gpurun_out/{tag}_detector_pmc.csv').read())
 PY
