@@ -347,6 +347,11 @@ int mofreak_table_pattern(const mofreak_ctx *ctx, int scale, int rot, float out[
 int mofreak_table_orientation(const mofreak_ctx *ctx, int32_t out[45 * 4]);
 /* The point pair (i, j) behind each of the 64 bits of descriptor bytes 0..7 (bit b of byte B at index 8B+b). */
 int mofreak_table_bit_pairs(const mofreak_ctx *ctx, uint8_t out[128]);
+/* The tile kernel's MIP sampling order for ROI side L (1..16): out[64 * u + lane], u < 4, = the position (frame * 368 +
+ * row * 19 + col of the (cur19 | prev19) buffer pair) lane resamples in pass u -- the four bytes of one aligned dword --
+ * the remaining entries the last pass, byte by byte; *n_out entries in all.  Which lane takes which dword is chosen per L
+ * so that a pass's LDS reads spread over the banks (mofreak_amd/tools/mip_lane_order.py). */
+int mofreak_table_mip_positions(const mofreak_ctx *ctx, int L, uint16_t out[320], int32_t *n_out);
 /* cv::resize(L -> 19) taps, x axis then y axis: (ofs, ofs1, c0, c1) per output index. */
 int mofreak_table_resize(const mofreak_ctx *ctx, int L, int16_t out[2 * 19 * 4]);
 

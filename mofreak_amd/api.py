@@ -37,7 +37,7 @@ EXPORTS = [
     "mofreak_extract_stream_pipelined", "mofreak_extract_clips", "mofreak_host_alloc", "mofreak_host_free",
     "mofreak_parse_rows", "mofreak_diff_integral", "mofreak_mip19", "mofreak_roi19", "mofreak_freak_info",
     "mofreak_theta_index", "mofreak_pattern_sizes", "mofreak_scale_index", "mofreak_table_pattern",
-    "mofreak_table_orientation", "mofreak_table_bit_pairs", "mofreak_table_resize",
+    "mofreak_table_orientation", "mofreak_table_bit_pairs", "mofreak_table_resize", "mofreak_table_mip_positions",
     "mofreak_detect_pairs", "mofreak_detect_set_capacity", "mofreak_brisk_pyramid", "mofreak_compute_stream", "mofreak_stream_open", "mofreak_stream_push", "mofreak_stream_frames", "mofreak_stream_close",
 ]
 
@@ -135,6 +135,7 @@ def load() -> C.CDLL:
     L.mofreak_table_orientation.argtypes = [vp, vp]
     L.mofreak_table_bit_pairs.argtypes = [vp, vp]
     L.mofreak_table_resize.argtypes = [vp, i32, vp]
+    L.mofreak_table_mip_positions.argtypes = [vp, i32, vp, C.POINTER(C.c_int32)]
     _lib = L
     return L
 
@@ -614,6 +615,13 @@ class Context:
         out = np.zeros((2, 19, 4), np.int16)
         self._check(self._lib.mofreak_table_resize(self._h, L, _ptr(out)))
         return out
+
+    def table_mip_positions(self, L: int) -> np.ndarray:
+        """The tile kernel's MIP sampling order for ROI side L: positions (frame * 368 + row * 19 + col), pass-major."""
+        out = np.zeros(320, np.uint16)
+        n = C.c_int32(0)
+        self._check(self._lib.mofreak_table_mip_positions(self._h, L, _ptr(out), C.byref(n)))
+        return out[:n.value].copy()
 
 
 def format_rows(rows: np.ndarray) -> bytes:

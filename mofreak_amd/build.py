@@ -10,7 +10,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmofreak_hip.so")
 DEBUG_LIB_PATH = os.path.join(PKG_DIR, "libmofreak_hip_debug.so")  # -DMOFREAK_DEBUG_BOUNDS: checked LDS accesses / stores
 SOURCES = ["kernels.hip", "tile_kernel.hip", "bow_kernel.hip", "detect_kernel.hip", "capi.cpp", "tables.cpp", "format.cpp"]
-HEADERS = ["tables.h", "device_types.h", "device_helpers.h", os.path.join("..", "..", "include", "mofreak_hip.h")]
+HEADERS = ["tables.h", "device_types.h", "device_helpers.h", "mip_lane_order.inc", os.path.join("..", "..", "include", "mofreak_hip.h")]
 # -ffp-contract=off / -fno-fast-math: a handful of float/double expressions restate reference
 # expressions whose rounding is part of the result.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",

@@ -1590,6 +1590,16 @@ int mofreak_table_bit_pairs(const mofreak_ctx *ctx, uint8_t out[128])
     return MOFREAK_OK;
 }
 
+int mofreak_table_mip_positions(const mofreak_ctx *ctx, int L, uint16_t out[320], int32_t *n_out)
+{
+    if (!ctx || !out || L < 1 || L > kTileMaxRoi) return MOFREAK_ERR_BAD_ARG;
+    const Tables &t = ctx->tables;
+    if (t.mip_n > 320) return MOFREAK_ERR_UNSUPPORTED;
+    for (int j = 0; j < t.mip_n; ++j) out[j] = t.mip_pos[(size_t)L * t.mip_stride + j];
+    if (n_out) *n_out = t.mip_n;
+    return MOFREAK_OK;
+}
+
 int mofreak_table_resize(const mofreak_ctx *ctx, int L, int16_t out[2 * 19 * 4])
 {
     if (!ctx || !out || L < 1 || L > kMaxRoiSide) return MOFREAK_ERR_BAD_ARG;

@@ -14,6 +14,8 @@ namespace mofreak {
 
 namespace {
 
+#include "mip_lane_order.inc"
+
 constexpr double kCvPi = 3.1415926535897932384626433832795;  // OpenCV's CV_PI
 constexpr double kFreakLog2 = 0.693147180559945;             // freak.cpp FREAK_LOG2
 
@@ -359,26 +361,43 @@ void build_tables(const FreakParams &p, Tables &t)
             }
             if (any) dwords.push_back(d);
         }
-        t.mip_pos.clear();
+        // Which dword a lane takes is chosen per ROI side (kMipLaneOrder, generated by mofreak_amd/tools/mip_lane_order.py): in
+        // ascending order every sampling pass pays a 2-way LDS bank conflict in its first lane group (`current` rows against
+        // `previous` rows staged 48 dwords further); the generated orders are conflict-free at all four ROI alignments.
         const int n_dw = static_cast<int>(dwords.size());
         if (n_dw < 65 || n_dw > 80)  // the kernel's five passes assume 64 full dwords plus a partial pass
             throw std::logic_error("MIP sample table: " + std::to_string(n_dw) + " dwords, the tile kernel expects 65..80");
-        for (int u = 0; u < 4; ++u)
-            for (int lane = 0; lane < 64; ++lane) t.mip_pos.push_back(static_cast<uint16_t>(4 * dwords[lane] + u));
-        for (int d = 64; d < n_dw; ++d)
-            for (int b = 0; b < 4; ++b) t.mip_pos.push_back(static_cast<uint16_t>(4 * dwords[d] + b));
-        t.mip_n = static_cast<int>(t.mip_pos.size());
-        t.mip_n_cur = 0;
-        for (int v : t.mip_pos) t.mip_n_cur += v < kP19Pad ? 1 : 0;
+        t.mip_n = 4 * n_dw;
         t.mip_stride = (t.mip_n + 63) / 64 * 64;
-        t.mip_pos.resize(t.mip_stride, t.mip_pos.back());
+        t.mip_pos.assign(static_cast<size_t>(kTileMaxRoi + 1) * t.mip_stride, 0);
+        for (int L = 0; L <= kTileMaxRoi; ++L) {
+            std::vector<int> order(n_dw);
+            for (int i = 0; i < n_dw; ++i) order[i] = n_dw == kMipOrderDwords ? kMipLaneOrder[L][i] : i;
+            {  // (a permutation, or the table is corrupt)
+                std::vector<char> seen(n_dw, 0);
+                for (int i : order) {
+                    if (i < 0 || i >= n_dw || seen[i]) throw std::logic_error("MIP lane order: not a permutation");
+                    seen[i] = 1;
+                }
+            }
+            uint16_t *pos = &t.mip_pos[static_cast<size_t>(L) * t.mip_stride];
+            int n = 0;
+            for (int u = 0; u < 4; ++u)
+                for (int lane = 0; lane < 64; ++lane) pos[n++] = static_cast<uint16_t>(4 * dwords[order[lane]] + u);
+            for (int d = 64; d < n_dw; ++d)
+                for (int b = 0; b < 4; ++b) pos[n++] = static_cast<uint16_t>(4 * dwords[order[d]] + b);
+            for (; n < t.mip_stride; ++n) pos[n] = pos[t.mip_n - 1];
+        }
+        t.mip_n_cur = 0;
+        for (int j = 0; j < t.mip_n; ++j) t.mip_n_cur += t.mip_pos[j] < kP19Pad ? 1 : 0;
         t.mip_samples.assign(static_cast<size_t>(kTileMaxRoi + 1) * t.mip_stride, MipSample{0, 0, 0, 0, 0});
         for (int L = 1; L <= kTileMaxRoi; ++L) {
             const ResizeTap *tx = &t.resize[(static_cast<size_t>(L) * 2 + 0) * kPatch];
             const ResizeTap *ty = &t.resize[(static_cast<size_t>(L) * 2 + 1) * kPatch];
+            const uint16_t *pos_L = &t.mip_pos[static_cast<size_t>(L) * t.mip_stride];
             for (int j = 0; j < t.mip_stride; ++j) {
-                const int frame = t.mip_pos[j] / kP19Pad;  // 0: current, 1: previous (staged kTileRW bytes further)
-                const int pos = std::min(t.mip_pos[j] % kP19Pad, kPatch * kPatch - 1), dy = pos / kPatch, dx = pos % kPatch;
+                const int frame = pos_L[j] / kP19Pad;  // 0: current, 1: previous (staged kTileRW bytes further)
+                const int pos = std::min(pos_L[j] % kP19Pad, kPatch * kPatch - 1), dy = pos / kPatch, dx = pos % kPatch;
                 MipSample &m = t.mip_samples[static_cast<size_t>(L) * t.mip_stride + j];
                 // the tile kernel reads a row pair as (off, off + 1): a clamped column has to carry a zero weight
                 if (tx[dx].ofs1 != tx[dx].ofs + 1 && tx[dx].c1 != 0)

@@ -107,7 +107,8 @@ struct Tables {
     std::vector<ResizeTap> resize;
     // The bytes of a (cur19 | prev19) buffer pair (kP19Pad bytes each) that the tile kernel resamples: every aligned
     // dword holding a 19x19 position motionInterchangePattern reads at the 8 patch centres (MoFREAKUtilities.cpp:56-70,
-    // 79-88, 308-316).  mip_pos[64 * u + lane] for u < 4 is byte u of the lane's dword; the rest follow byte by byte.
+    // 79-88, 308-316), per ROI side L (which lane takes which dword is chosen per L for LDS bank spread):
+    // mip_pos[L * mip_stride + 64 * u + lane] for u < 4 is byte u of the lane's dword; the rest follow byte by byte.
     // value = frame * kP19Pad + row * 19 + col.  mip_samples[L][j] is entry j's MipSample for ROI side L (L <= kTileMaxRoi).
     // thetaIdx steps (see device_helpers.h theta_index): found by bisection over float angles through the chain
     // angle = (float)(a * (180.0/CV_PI)); thetaIdx = int(256*angle*(1/360.0)+0.5)

@@ -655,9 +655,10 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
         uint32_t c0ys[kMipIters], c1ys[kMipIters];  // the y weights << 12
     } ml;
     const uint32_t p19 = lds0 + kOffScratch + wave * kP19Wave;  // this wave's pair of 19x19 buffers
-    ml.dst_dword = p19 + a.mip_pos[lane];  // byte 0 of the lane's dword: passes 0..3 are its four bytes (tables.cpp)
-    ml.dst_tail = p19 + a.mip_pos[lane + 64 * (kMipIters - 1)];
     auto load_samples = [&](int L) {
+        const uint16_t *pos = a.mip_pos + (int64_t)L * a.mip_stride + lane;  // which dword this lane resamples for this ROI side
+        ml.dst_dword = p19 + pos[0];  // byte 0 of the lane's dword: passes 0..3 are its four bytes (tables.cpp)
+        ml.dst_tail = p19 + pos[64 * (kMipIters - 1)];
         const MipSample *tab = a.mip_samples + (int64_t)L * a.mip_stride + lane;
 #pragma unroll
         for (int u = 0; u < kMipIters; ++u) {

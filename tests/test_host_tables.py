@@ -140,3 +140,59 @@ def test_parse_rows_round_trip(native_lib):
     assert len(M.parse_rows(b"")) == 0 and len(M.parse_rows(b"  \n")) == 0
     with pytest.raises(M.MoFREAKError):
         M.parse_rows(b"1 2 3 4 0 0 1 2 3\n")  # truncated row
+
+
+# ------------------------------------------------------------------ the tile kernel's MIP sampling order
+MIP_CENTRES = [(5, 5), (5, 9), (5, 13), (9, 5), (9, 13), (13, 5), (13, 9), (13, 13)]
+MIP_OFFSETS = [(-4, 0), (-3, 3), (0, 4), (3, 3), (4, 0), (3, -3), (0, -4), (-3, -3)]
+
+
+def _mip_needed_dwords():
+    need = set()
+    for x, y in MIP_CENTRES:
+        need |= {(y - 1) * 19 + (x - 1) + k for k in range(9)}                                        # current strip
+        for dx, dy in MIP_OFFSETS:
+            need |= {368 + (y - 1 + dy) * 19 + (x - 1 + dx) + k for k in range(9)}                    # previous strips
+    return sorted({p // 4 for p in need})
+
+
+def _mip_lds_cycles(tctx, L, positions, pitch=400, rw=192):
+    """The model of mofreak_amd/tools/mip_lane_order.py, restated: LDS cycles of a keypoint's 20 sampling reads (five
+    passes x two source rows x two taps), one cycle per distinct dword on the busiest of the 32 banks per 32-lane group,
+    summed over the four byte alignments of the ROI's first pixel."""
+    taps = tctx.table_resize(L).astype(int)
+    tx, ty = taps[0], taps[1]
+    passes = [positions[64 * u:64 * u + 64] for u in range(4)]
+    tail = list(positions[256:])
+    passes.append(tail + [tail[-1]] * (64 - len(tail)))
+    total = 0
+    for al in range(4):
+        for pl in passes:
+            for row in (0, 1):
+                for tap in (0, 1):
+                    for g in (0, 1):
+                        banks = {}
+                        for p in pl[32 * g:32 * g + 32]:
+                            fr, i = int(p) // 368, min(int(p) % 368, 360)
+                            addr = fr * rw + ty[i // 19][row] * pitch + tx[i % 19][0] + tap + al
+                            banks.setdefault((addr // 4) % 32, set()).add(addr // 4)
+                        total += max(len(v) for v in banks.values())
+    return total
+
+
+@pytest.mark.parametrize("L", range(1, 17))
+def test_mip_sampling_order_covers_the_needed_bytes_and_spreads_over_the_banks(tctx, L):
+    pos = tctx.table_mip_positions(L)
+    dwords = _mip_needed_dwords()
+    assert len(dwords) == 75 and len(pos) == 300
+    lane_dwords = pos[:64] // 4
+    for u in range(4):  # pass u = byte u of the lane's dword: the lane packs four results into one 32-bit LDS store
+        assert np.array_equal(pos[64 * u:64 * u + 64], 4 * lane_dwords + u)
+    tail_dwords = pos[256::4] // 4
+    assert np.array_equal(pos[256:], (4 * tail_dwords[:, None] + np.arange(4)).reshape(-1))
+    assert sorted(lane_dwords.tolist() + tail_dwords.tolist()) == dwords  # every needed dword exactly once
+    cycles = _mip_lds_cycles(tctx, L, pos)
+    in_table_order = _mip_lds_cycles(tctx, L, np.array([4 * d + u for u in range(4) for d in dwords[:64]] + [4 * d + b for d in dwords[64:] for b in range(4)]))
+    assert cycles <= in_table_order and cycles <= (176 if L < 16 else 224), (L, cycles, in_table_order)  # floor: 4 alignments x 20 reads x 2 groups = 160
+    if L == 12:
+        assert in_table_order == 224 and cycles == 160
