@@ -173,6 +173,60 @@ void MoFREAKUtilities::computeMoFREAKFromFile(std::string video_filename, std::s
     if (clear_features_after_computation) features.clear();
 }
 
+void MoFREAKUtilities::computeMoFREAKFromFiles(const std::vector<std::string> &video_filenames, const std::vector<std::string> &mofreak_filenames)
+{
+    if (video_filenames.size() != mofreak_filenames.size()) throw std::runtime_error("computeMoFREAKFromFiles: one output name per video");
+    if (use_brisk_ || !provider_shared_) {  // per-frame keypoints: the plain loop
+        for (size_t i = 0; i < video_filenames.size(); ++i) computeMoFREAKFromFile(video_filenames[i], mofreak_filenames[i], true);
+        return;
+    }
+    struct Clip {
+        std::vector<uint8_t> frames;
+        int T = 0, H = 0, W = 0;
+        bool ok = false;
+    };
+    std::vector<Clip> clips(video_filenames.size());
+    for (size_t i = 0; i < clips.size(); ++i) {
+        clips[i].ok = load_npy_u8_3d(video_filenames[i], clips[i].frames, clips[i].T, clips[i].H, clips[i].W);
+        if (!clips[i].ok) cout << "Could not open file: " << video_filenames[i] << endl;  // :383-386
+    }
+    mofreak_ctx *ctx = context();
+    const int gap = params_.gap_for_frame_difference;
+    std::vector<char> done(clips.size(), 0);
+    for (size_t first = 0; first < clips.size(); ++first) {
+        if (done[first] || !clips[first].ok) continue;
+        // every clip of this frame size, in the order they were given
+        const int W = clips[first].W, H = clips[first].H;
+        std::vector<size_t> idx;
+        for (size_t i = first; i < clips.size(); ++i)
+            if (!done[i] && clips[i].ok && clips[i].W == W && clips[i].H == H) idx.push_back(i);
+        std::vector<const uint8_t *> ptr(idx.size());
+        std::vector<int32_t> len(idx.size());
+        const std::vector<mofreak_keypoint> kps = provider_(gap, W, H);
+        int64_t capacity = 0;
+        for (size_t k = 0; k < idx.size(); ++k) {
+            ptr[k] = clips[idx[k]].frames.data();
+            len[k] = clips[idx[k]].T;
+            capacity += (int64_t)std::max(len[k] - gap, 0) * (int64_t)kps.size();
+        }
+        std::vector<mofreak_row> rows((size_t)std::max<int64_t>(capacity, 1));
+        std::vector<int64_t> offs(idx.size() + 1, 0);
+        int64_t n_rows = 0;
+        check(ctx,
+              mofreak_extract_clips(ctx, ptr.data(), len.data(), (int)idx.size(), W, H, /*chunk_frames*/ 0, kps.data(), (int64_t)kps.size(),
+                                    rows.data(), capacity, offs.data(), &n_rows, 0),
+              "mofreak_extract_clips");
+        for (size_t k = 0; k < idx.size(); ++k) {
+            const size_t i = idx[k];
+            appendRows(rows.data() + offs[k], offs[k + 1] - offs[k], video_filenames[i]);  // behind whatever is there (:374-498 appends)
+            cout << "Writing this mofreak file: " << mofreak_filenames[i] << endl;
+            writeMoFREAKFeaturesToFile(mofreak_filenames[i]);
+            features.clear();  // clear_features_after_computation = true
+            done[i] = 1;
+        }
+    }
+}
+
 void MoFREAKUtilities::computeMoFREAKFromFrames(const uint8_t *frames, int T, int W, int H,
                                                 const std::string &video_filename)
 {

@@ -91,6 +91,12 @@ public:
     void setParams(const mofreak_params &p);          // before the first computation
     // The frame loop of computeMoFREAKFromFile on frames already in memory (T x H x W gray).
     void computeMoFREAKFromFrames(const uint8_t *frames, int T, int W, int H, const std::string &video_filename);
+    // The body of computeMoFREAKFiles' loops (main.cpp:862-921) for many videos at once: what
+    //     for (i...) computeMoFREAKFromFile(video_filenames[i], mofreak_filenames[i], true);
+    // does -- every video's features written to its own file, nothing kept -- with the videos of one frame size going
+    // through ONE mofreak_extract_clips call (shared launches, copies under kernels) when the keypoints are a shared
+    // list (dense grid); other keypoint sources fall back to the loop above.  Files come out byte-identical to it.
+    void computeMoFREAKFromFiles(const std::vector<std::string> &video_filenames, const std::vector<std::string> &mofreak_filenames);
 
 private:
     void readMetadata(const std::string &filename, int &action, int &video_number, int &person);

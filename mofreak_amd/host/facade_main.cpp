@@ -55,19 +55,28 @@ int main(int argc, char **argv)
             const std::string video_path = argv[2], mofreak_path = argv[3];
             MoFREAKUtilities mofreak(MoFREAKUtilities::UCF101);
             mofreak.setDenseGrid(16, 7.0f, 23);
+            // The walk is the reference's; the videos it finds are handed over together (one pipelined call per frame
+            // size instead of one synchronous call per video), which writes the same files.
+            std::vector<std::string> videos, outputs;
             for (const std::string &name : list_dir(video_path)) {
                 const std::string p = video_path + "/" + name;
                 if (!is_dir(p)) {
-                    if (ends_with(name, "npy")) mofreak.computeMoFREAKFromFile(p, mofreak_path + "/" + name + ".mofreak", true);
+                    if (ends_with(name, "npy")) {
+                        videos.push_back(p);
+                        outputs.push_back(mofreak_path + "/" + name + ".mofreak");
+                    }
                 } else {
                     std::cout << "action: " << name << std::endl;
                     mofreak.setCurrentAction(name);
                     mkdir((mofreak_path + "/" + name).c_str(), 0777);
                     for (const std::string &v : list_dir(p))
-                        if (ends_with(v, "npy"))
-                            mofreak.computeMoFREAKFromFile(p + "/" + v, mofreak_path + "/" + name + "/" + v + ".mofreak", true);
+                        if (ends_with(v, "npy")) {
+                            videos.push_back(p + "/" + v);
+                            outputs.push_back(mofreak_path + "/" + name + "/" + v + ".mofreak");
+                        }
                 }
             }
+            mofreak.computeMoFREAKFromFiles(videos, outputs);
             return 0;
         }
         if (mode == "roundtrip" && argc >= 4) {
