@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MOFREAK_ABI_VERSION 1
+#define MOFREAK_ABI_VERSION 2
 
 /* status codes */
 #define MOFREAK_OK 0
@@ -52,6 +52,18 @@ extern "C" {
 #define MOFREAK_BITS_NATURAL 1    /* v[i] >  v[j], std::bitset order: 2.4.2 built without CV_SSE2 */
 #define MOFREAK_BITS_SSE_SIGNED 2 /* (int8)v[i] > (int8)v[j], SSE byte order */
 
+/* What a C `float` expression of the vendored BRISK detector (brisk.cpp, compiled inside the reference's own project) means.
+ * The reference is a 32-bit Visual Studio 2010 project (README.md:13; MoFREAK.vcxproj: Win32 configurations, no /arch option):
+ * that compiler emits x87 code, the CRT runs the FPU at 53-bit precision, and under the default /fp:precise the intermediates
+ * of an expression stay in FPU registers -- values are rounded to float only where they are assigned, cast, passed or
+ * returned.  MOFREAK_FP_X87 restates that and is the default; MOFREAK_FP_SSE rounds every float operation to float (what
+ * /arch:SSE2, a later Visual Studio or a 64-bit build would do).  On tie-heavy and moving-object test images the two
+ * readings give the same NUMBER of keypoints, differ in the last bit of x, y or response for about 30 % of them and by
+ * more than that (up to 2 px, or a different size) for 0.07 %.  OpenCV's own code (cv::FREAK,
+ * cv::resize) lives in the prebuilt OpenCV 2.4.2 libraries, which are SSE2 builds: nothing else depends on this choice. */
+#define MOFREAK_FP_X87 0
+#define MOFREAK_FP_SSE 1
+
 #define MOFREAK_APPEARANCE_BYTES 8 /* MoFREAKUtilities.h:21 */
 #define MOFREAK_MOTION_BYTES 8     /* MoFREAKUtilities.h:20 */
 #define MOFREAK_DESC_BYTES 16
@@ -68,6 +80,7 @@ typedef struct mofreak_params {
     int32_t freak_orientation_normalized; /* 1 */
     int32_t freak_scale_normalized;       /* 1 */
     int32_t freak_bit_mode;               /* MOFREAK_BITS_SSE */
+    int32_t brisk_fp_model;               /* MOFREAK_FP_X87: keypoint detector only (mofreak_detect_pairs, mofreak_compute_stream, streams) */
 } mofreak_params;
 
 /* cv::KeyPoint fields the path reads (pt.x, pt.y, size). */

@@ -20,6 +20,7 @@ OK = 0
 ERR_BAD_ARG, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_ROI, ERR_CAPACITY = -1, -2, -3, -4, -5, -6, -7
 MEM_DEVICE, MEM_HOST, ROWS_DEVICE = 0, 1, 2
 BITS_SSE, BITS_NATURAL, BITS_SSE_SIGNED = 0, 1, 2
+FP_X87, FP_SSE = 0, 1  # mofreak_params.brisk_fp_model
 TABLES_ONLY = -1
 PATH_AUTO, PATH_GATHER = 0, 1
 
@@ -46,7 +47,7 @@ class Params(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("gap_for_frame_difference", C.c_int32), ("mip_theta", C.c_int32),
                 ("freak_pattern_scale", C.c_float), ("freak_n_octaves", C.c_int32),
                 ("freak_orientation_normalized", C.c_int32), ("freak_scale_normalized", C.c_int32),
-                ("freak_bit_mode", C.c_int32)]
+                ("freak_bit_mode", C.c_int32), ("brisk_fp_model", C.c_int32)]
 
 
 class Profile(C.Structure):

@@ -494,6 +494,7 @@ int mofreak_default_params(mofreak_params *p)
     p->freak_orientation_normalized = 1;
     p->freak_scale_normalized = 1;
     p->freak_bit_mode = MOFREAK_BITS_SSE;
+    p->brisk_fp_model = MOFREAK_FP_X87;
     return MOFREAK_OK;
 }
 
@@ -509,7 +510,7 @@ int mofreak_create(int device_id, const mofreak_params *params, mofreak_ctx **ou
         p = *params;
     }
     if (p.gap_for_frame_difference < 1 || p.freak_n_octaves < 1 || !(p.freak_pattern_scale > 0) ||
-        p.freak_bit_mode < 0 || p.freak_bit_mode > 2 || p.mip_theta < 0)
+        p.freak_bit_mode < 0 || p.freak_bit_mode > 2 || p.mip_theta < 0 || p.brisk_fp_model < 0 || p.brisk_fp_model > 1)
         return fail(nullptr, MOFREAK_ERR_BAD_ARG, "parameter out of range");
 
     int n_dev = 0;
@@ -1703,6 +1704,7 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     if ((rc = ensure(ctx, ctx->det_wait_list, (size_t)batch * 4096 * sizeof(int32_t)))) return rc;
     a.wait_list = static_cast<int32_t *>(ctx->det_wait_list.ptr);
     a.status_word = ctx->d_status + 1;  // the detector's own word: clearing it leaves the describe kernels' flags alone
+    a.fp_x87 = ctx->params.brisk_fp_model == MOFREAK_FP_X87 ? 1 : 0;
     return MOFREAK_OK;
 }
 

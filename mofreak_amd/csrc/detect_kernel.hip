@@ -41,6 +41,21 @@ struct PairView {
     const uint8_t *score;
     uint8_t *touch;
     uint8_t *status;
+    bool x87;  // the float expressions' model (mofreak_params.brisk_fp_model, see Fp below)
+};
+
+// What a C `float` expression of brisk.cpp means.  The reference is a 32-bit Visual Studio 2010 project without an /arch
+// option: x87 code, the FPU at 53-bit precision, intermediates of an expression kept in FPU registers and rounded to float
+// only where they are assigned, cast, passed or returned (MOFREAK_FP_X87, the default); MOFREAK_FP_SSE rounds every float
+// operation to float.  Both are computed here in double with the rounding applied per operation or not: rounding a double
+// +, -, *, / of two floats to float equals the float operation (53 >= 2 * 24 + 2 bits), so the second reading is exact too.
+struct Fp {
+    bool x87;
+    __device__ __forceinline__ double op(double v) const { return x87 ? v : (double)(float)v; }
+    __device__ __forceinline__ double mul(double a, double b) const { return op(a * b); }
+    __device__ __forceinline__ double add(double a, double b) const { return op(a + b); }
+    __device__ __forceinline__ double sub(double a, double b) const { return op(a - b); }
+    __device__ __forceinline__ double div(double a, double b) const { return op(a / b); }
 };
 
 __device__ __forceinline__ PairView pair_view(const DetArgs &a, int p)
@@ -52,6 +67,7 @@ __device__ __forceinline__ PairView pair_view(const DetArgs &a, int p)
     v.score = a.score + o;
     v.touch = a.touch + o;
     v.status = a.status + o;
+    v.x87 = a.fp_x87 != 0;
     return v;
 }
 
@@ -550,7 +566,7 @@ __device__ __forceinline__ int score_5_8_block(const unsigned long long (&im)[5]
 }
 
 // BriskScaleSpace::subpixel2D (brisk.cpp:1535-1644); s = s_0_0, s_0_1, s_0_2, s_1_0, ... (first index x)
-__device__ __forceinline__ float subpixel2d(const int (&s)[9], float &delta_x, float &delta_y)
+__device__ __forceinline__ float subpixel2d(const Fp fp, const int (&s)[9], float &delta_x, float &delta_y)
 {
     const int s_0_0 = s[0], s_0_1 = s[1], s_0_2 = s[2], s_1_0 = s[3], s_1_1 = s[4], s_1_2 = s[5], s_2_0 = s[6], s_2_1 = s[7],
               s_2_2 = s[8];
@@ -594,8 +610,8 @@ __device__ __forceinline__ float subpixel2d(const int (&s)[9], float &delta_x, f
         }
         return (float)((double)(float)(tmp_max + coeff1 + coeff2 + coeff6) / 18.0);
     }
-    const float dx = (float)(2 * coeff2 * coeff3 - coeff4 * coeff5) / (float)(-H_det);
-    const float dy = (float)(2 * coeff1 * coeff4 - coeff3 * coeff5) / (float)(-H_det);
+    const float dx = (float)fp.div((float)(2 * coeff2 * coeff3 - coeff4 * coeff5), (float)(-H_det));
+    const float dy = (float)fp.div((float)(2 * coeff1 * coeff4 - coeff3 * coeff5), (float)(-H_det));
     bool tx = false, tx_ = false, ty = false, ty_ = false;
     if ((double)dx > 1.0)
         tx = true;
@@ -604,28 +620,37 @@ __device__ __forceinline__ float subpixel2d(const int (&s)[9], float &delta_x, f
     if ((double)dy > 1.0) ty = true;
     if ((double)dy < -1.0) ty_ = true;
     const float c1 = (float)coeff1, c2 = (float)coeff2, c3 = (float)coeff3, c4 = (float)coeff4, c5 = (float)coeff5, c6 = (float)coeff6;
+    // c1*x*x + c2*y*y + c3*x + c4*y + c5*x*y + c6: products and sums of floats, left to right (then divided in double)
+    auto quad = [&](float x, float y) -> double {
+        double v = fp.mul(fp.mul(c1, x), x);
+        v = fp.add(v, fp.mul(fp.mul(c2, y), y));
+        v = fp.add(v, fp.mul(c3, x));
+        v = fp.add(v, fp.mul(c4, y));
+        v = fp.add(v, fp.mul(fp.mul(c5, x), y));
+        return fp.add(v, c6);
+    };
     if (tx || tx_ || ty || ty_) {
         float dx1 = 0.0f, dx2 = 0.0f, dy1 = 0.0f, dy2 = 0.0f;
         if (tx) {
             dx1 = 1.0f;
-            dy1 = -(float)(coeff4 + coeff5) / (float)(2 * coeff2);
+            dy1 = (float)fp.div(-(float)(coeff4 + coeff5), (float)(2 * coeff2));
             if ((double)dy1 > 1.0) dy1 = 1.0f; else if ((double)dy1 < -1.0) dy1 = -1.0f;
         } else if (tx_) {
             dx1 = -1.0f;
-            dy1 = -(float)(coeff4 - coeff5) / (float)(2 * coeff2);
+            dy1 = (float)fp.div(-(float)(coeff4 - coeff5), (float)(2 * coeff2));
             if ((double)dy1 > 1.0) dy1 = 1.0f; else if ((double)dy1 < -1.0) dy1 = -1.0f;
         }
         if (ty) {
             dy2 = 1.0f;
-            dx2 = -(float)(coeff3 + coeff5) / (float)(2 * coeff1);
+            dx2 = (float)fp.div(-(float)(coeff3 + coeff5), (float)(2 * coeff1));
             if ((double)dx2 > 1.0) dx2 = 1.0f; else if ((double)dx2 < -1.0) dx2 = -1.0f;
         } else if (ty_) {
             dy2 = -1.0f;
-            dx2 = -(float)(coeff3 - coeff5) / (float)(2 * coeff1);
+            dx2 = (float)fp.div(-(float)(coeff3 - coeff5), (float)(2 * coeff1));
             if ((double)dx2 > 1.0) dx2 = 1.0f; else if ((double)dx2 < -1.0) dx2 = -1.0f;
         }
-        const float max1 = (float)((double)(c1 * dx1 * dx1 + c2 * dy1 * dy1 + c3 * dx1 + c4 * dy1 + c5 * dx1 * dy1 + c6) / 18.0);
-        const float max2 = (float)((double)(c1 * dx2 * dx2 + c2 * dy2 * dy2 + c3 * dx2 + c4 * dy2 + c5 * dx2 * dy2 + c6) / 18.0);
+        const float max1 = (float)(quad(dx1, dy1) / 18.0);
+        const float max2 = (float)(quad(dx2, dy2) / 18.0);
         if (max1 > max2) {
             delta_x = dx1;
             delta_y = dx1;  // sic (:1629)
@@ -637,11 +662,11 @@ __device__ __forceinline__ float subpixel2d(const int (&s)[9], float &delta_x, f
     }
     delta_x = dx;
     delta_y = dy;
-    return (float)((double)(c1 * dx * dx + c2 * dy * dy + c3 * dx + c4 * dy + c5 * dx * dy + c6) / 18.0);
+    return (float)(quad(dx, dy) / 18.0);
 }
 
 // refine1D (variant 0, :1418), refine1D_1 (1, :1459), refine1D_2 (2, :1499)
-__device__ __forceinline__ float refine1d(int variant, float s_05, float s0, float s05, float &max)
+__device__ __forceinline__ float refine1d(const Fp fp, int variant, float s_05, float s0, float s05, float &max)
 {
     const int i_05 = (int)(1024.0 * (double)s_05 + 0.5);
     const int i0 = (int)(1024.0 * (double)s0 + 0.5);
@@ -681,12 +706,12 @@ __device__ __forceinline__ float refine1d(int variant, float s_05, float s0, flo
             return (float)(variant == 1 ? 1.3333333333333333333333333333 : 1.5);
         }
     }
-    float ret_val = -(float)qb / (float)(2 * qa);
+    float ret_val = (float)fp.div(-(float)qb, (float)(2 * qa));
     if ((double)ret_val < lo_d)
         ret_val = (float)lo_d;
     else if ((double)ret_val > hi_d)
         ret_val = (float)hi_d;
-    float m = (float)qc + (float)qa * ret_val * ret_val + (float)qb * ret_val;
+    float m = (float)fp.add(fp.add((float)qc, fp.mul(fp.mul((float)qa, ret_val), ret_val)), fp.mul((float)qb, ret_val));
     if (variant == 2)
         m = m / 1024.0f;
     else
@@ -751,7 +776,8 @@ __device__ __forceinline__ float neighbour_layer_max(const PairView &v, Window &
     float x_1, x1, y_1, y1;
     walk_square<ABOVE>(layer, x_layer, y_layer, x_1, x1, y_1, y1);
     const float thr = (float)threshold;
-    const int xa = (int)(x_1 + 1), xb = (int)x1, ya = (int)(y_1 + 1), yb = (int)y1;
+    const Fp fp{v.x87};
+    const int xa = (int)fp.add(x_1, 1.0f), xb = (int)x1, ya = (int)fp.add(y_1, 1.0f), yb = (int)y1;
     auto S = [&](int x, int y) { return window_at<ABOVE>(v, win, x, y); };  // getAgastScore(int, int, 1)
     auto Q = [&](int x, int y) { return window_at<false>(v, win, x, y); };  // same, for the layer below (no bookkeeping)
     auto F = [&](float xf, float yf) {                                      // getAgastScore(float, float, 1): bilinear through uint8_t
@@ -762,7 +788,8 @@ __device__ __forceinline__ float neighbour_layer_max(const PairView &v, Window &
         const float ry1 = yf - (float)y;
         const float ry = 1.0f - ry1;
         const float s00 = (float)S(x, y), s10 = (float)S(x + 1, y), s01 = (float)S(x, y + 1), s11 = (float)S(x + 1, y + 1);
-        const float r = rx * ry * s00 + rx1 * ry * s10 + rx * ry1 * s01 + rx1 * ry1 * s11;
+        const double r = fp.add(fp.add(fp.add(fp.mul(fp.mul(rx, ry), s00), fp.mul(fp.mul(rx1, ry), s10)), fp.mul(fp.mul(rx, ry1), s01)),
+                                fp.mul(fp.mul(rx1, ry1), s11));  // one expression, converted to uint8_t
         return (int)r & 0xff;
     };
 
@@ -851,14 +878,14 @@ __device__ __forceinline__ float neighbour_layer_max(const PairView &v, Window &
     int patch[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) patch[k] = S(max_x + k / 3 - 1, max_y + k % 3 - 1);  // s_0_0, s_0_1, s_0_2, s_1_0, ... (first index x)
-    const float refined_max = subpixel2d(patch, dx_1, dy_1);
-    const float real_x = (float)max_x + dx_1;
-    const float real_y = (float)max_y + dy_1;
+    const float refined_max = subpixel2d(fp, patch, dx_1, dy_1);
+    const float real_x = (float)fp.add((float)max_x, dx_1);
+    const float real_y = (float)fp.add((float)max_y, dy_1);
     bool returnrefined = true;
     if (ABOVE) {
         if (octave) {  // float arithmetic (:1228-1229)
-            dx = (real_x * 6.0f + 1.0f) / 4.0f - (float)x_layer;
-            dy = (real_y * 6.0f + 1.0f) / 4.0f - (float)y_layer;
+            dx = (float)fp.sub(fp.div(fp.add(fp.mul(real_x, 6.0f), 1.0f), 4.0f), (float)x_layer);
+            dy = (float)fp.sub(fp.div(fp.add(fp.mul(real_y, 6.0f), 1.0f), 4.0f), (float)y_layer);
         } else {  // double arithmetic (:1232-1233)
             dx = (float)(((double)real_x * 8.0 + 1.0) / 6.0 - (double)(float)x_layer);
             dy = (float)(((double)real_y * 8.0 + 1.0) / 6.0 - (double)(float)y_layer);
@@ -895,6 +922,7 @@ __device__ __forceinline__ Refined refine_maximum(const PairView &v, uint8_t *ld
     // One walk above, one below, one own patch -- in the reference's order (above, below, patch), each at a single
     // call site so that everything inlines and no argument goes through the stack.
     const float basicSize = 12.0f;
+    const Fp fp{v.x87};
     const DetGeom &g = *v.g;
     const DetLayer &L = g.L[layer];
     Refined out;
@@ -956,28 +984,28 @@ __device__ __forceinline__ Refined refine_maximum(const PairView &v, uint8_t *ld
             s[k] = score_5_8_block(im, k / 3 - 1, k % 3 - 1);
             mb = max(mb, s[k]);
         }
-        (void)subpixel2d(s, delta_x_below, delta_y_below);
+        (void)subpixel2d(fp, s, delta_x_below, delta_y_below);
         max_below = (float)mb;
     }
     int own_patch[9];  // s_0_0, s_0_1, s_0_2, s_1_0, ... (first index x): getAgastScore(int, int, 1) on the own layer (:1685-1694)
 #pragma unroll
     for (int k = 0; k < 9; ++k) own_patch[k] = (int)((own[k % 3] >> (8 * (k / 3))) & 0xff);
-    const float max_layer = subpixel2d(own_patch, delta_x_layer, delta_y_layer);
+    const float max_layer = subpixel2d(fp, own_patch, delta_x_layer, delta_y_layer);
     out.reached = true;
     if (single) {  // :609-638
         out.emit = true;
-        out.r = DetResult{(float)px + delta_x_layer, (float)py + delta_y_layer, basicSize, max_layer};
+        out.r = DetResult{(float)fp.add((float)px, delta_x_layer), (float)fp.add((float)py, delta_y_layer), basicSize, max_layer};
         return out;
     }
     if (last) {  // :659-678
         out.emit = true;
-        out.r = DetResult{((float)px + delta_x_layer) * L.scale + L.offset, ((float)py + delta_y_layer) * L.scale + L.offset, basicSize * L.scale,
-                          max_layer};
+        out.r = DetResult{(float)fp.add(fp.mul(fp.add((float)px, delta_x_layer), L.scale), L.offset),
+                          (float)fp.add(fp.mul(fp.add((float)py, delta_y_layer), L.scale), L.offset), basicSize * L.scale, max_layer};
         return out;
     }
     const float s0 = ((float)center < max_layer) ? max_layer : (float)center;  // std::max(float(center), max_layer)
     float best;
-    float scale = refine1d(octave ? (layer == 0 ? 2 : 0) : 1, max_below, s0, max_above, best);
+    float scale = refine1d(fp, octave ? (layer == 0 ? 2 : 0) : 1, max_below, s0, max_above, best);
     float r0, r1;
     bool up;
     if (octave) {
@@ -994,12 +1022,14 @@ __device__ __forceinline__ Refined refine_maximum(const PairView &v, uint8_t *ld
     }
     r1 = (float)(1.0 - (double)r0);
     const float ox = up ? delta_x_above : delta_x_below, oy = up ? delta_y_above : delta_y_below;
-    float x = r0 * delta_x_layer + r1 * ox + (float)px;
-    float y = r0 * delta_y_layer + r1 * oy + (float)py;
+    // (r0 * delta_layer + r1 * delta_other + float(c)) [* scale + offset]: one expression each in the reference
+    double xe = fp.add(fp.add(fp.mul(r0, delta_x_layer), fp.mul(r1, ox)), (float)px);
+    double ye = fp.add(fp.add(fp.mul(r0, delta_y_layer), fp.mul(r1, oy)), (float)py);
     if (up || layer != 0) {  // layer 0 interpolating towards the guessed layer below stays in image coordinates (:1031-1032)
-        x = x * L.scale + L.offset;
-        y = y * L.scale + L.offset;
+        xe = fp.add(fp.mul(xe, L.scale), L.offset);
+        ye = fp.add(fp.mul(ye, L.scale), L.offset);
     }
+    const float x = (float)xe, y = (float)ye;
     scale *= L.scale;
     if (best > (float)threshold) {  // :698
         out.emit = true;

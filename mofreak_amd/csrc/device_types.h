@@ -204,6 +204,7 @@ struct DetArgs {
     FrameArgs f;  // cur / prev of the batch's first pair (prev == nullptr: cur already is the image to search)
     int32_t n_pairs;
     int32_t threshold, safe_threshold;
+    int32_t fp_x87;     // 1: float expressions as the reference's x87 build evaluates them (mofreak_params.brisk_fp_model)
     uint8_t *img, *score, *touch, *status;  // [n_pairs][plane_bytes]
     int32_t *row_count;                     // [n_pairs][total_rows + 1]: counts, then exclusive offsets
     int32_t cand_cap;                       // per pair

@@ -170,6 +170,22 @@ static int layer_score_5_8(const layer_t *l, int x, int y, int threshold)
     return score;
 }
 
+/* What a C `float` expression means.  The reference is a 32-bit Visual Studio 2010 project (README.md:13, MoFREAK.vcxproj:
+ * Win32 configurations, no /arch option): that compiler emits x87 code, the CRT runs the FPU at 53-bit precision, and
+ * under its default /fp:precise an expression's intermediates stay in FPU registers; values are rounded to float where
+ * they are assigned to a float, cast, passed or returned.  MO_BRISK_FP_X87 (the default) restates that; MO_BRISK_FP_SSE is
+ * the other reading (every float operation rounds to float: what /arch:SSE2 or a 64-bit build would do).  Every
+ * operation below is done in double and OP() rounds its result to float or not: rounding a double +, -, *, / of two
+ * floats to float equals the float operation (53 >= 2 * 24 + 2 bits), so the SSE reading is exact as well. */
+static int g_fp_model = MO_BRISK_FP_X87;
+void mo_brisk_set_fp_model(int model) { g_fp_model = model == MO_BRISK_FP_SSE ? MO_BRISK_FP_SSE : MO_BRISK_FP_X87; }
+int mo_brisk_get_fp_model(void) { return g_fp_model; }
+static inline double OP(double v) { return g_fp_model == MO_BRISK_FP_X87 ? v : (double)(float)v; }
+#define FMUL(a, b) OP((double)(a) * (double)(b))
+#define FADD(a, b) OP((double)(a) + (double)(b))
+#define FSUB(a, b) OP((double)(a) - (double)(b))
+#define FDIV(a, b) OP((double)(a) / (double)(b))
+
 /* brisk.cpp:1705-1738 with scale == 1.0f (every call site passes the default): bilinear inside the layer,
  * returned through uint8_t (truncation).  The scale > 1 branch (value()) is never reached by the detector. */
 static int layer_score_f(layer_t *l, float xf, float yf, int threshold)
@@ -185,7 +201,8 @@ static int layer_score_f(layer_t *l, float xf, float yf, int threshold)
     const float s10 = (float)layer_score(l, x + 1, y, threshold);
     const float s01 = (float)layer_score(l, x, y + 1, threshold);
     const float s11 = (float)layer_score(l, x + 1, y + 1, threshold);
-    const float v = rx * ry * s00 + rx1 * ry * s10 + rx * ry1 * s01 + rx1 * ry1 * s11;
+    /* one expression, converted to uint8_t at the return */
+    const double v = FADD(FADD(FADD(FMUL(FMUL(rx, ry), s00), FMUL(FMUL(rx1, ry), s10)), FMUL(FMUL(rx, ry1), s01)), FMUL(FMUL(rx1, ry1), s11));
     return (uint8_t)v;
 }
 
@@ -307,8 +324,8 @@ float mo_brisk_subpixel2d(const int s[9], float *delta_x, float *delta_y)
         }
         return (float)((double)(float)(tmp_max + coeff1 + coeff2 + coeff6) / 18.0);
     }
-    float dx = (float)(2 * coeff2 * coeff3 - coeff4 * coeff5) / (float)(-H_det);
-    float dy = (float)(2 * coeff1 * coeff4 - coeff3 * coeff5) / (float)(-H_det);
+    float dx = (float)FDIV((float)(2 * coeff2 * coeff3 - coeff4 * coeff5), (float)(-H_det));
+    float dy = (float)FDIV((float)(2 * coeff1 * coeff4 - coeff3 * coeff5), (float)(-H_det));
     int tx = 0, tx_ = 0, ty = 0, ty_ = 0;
     if ((double)dx > 1.0)
         tx = 1;
@@ -320,27 +337,29 @@ float mo_brisk_subpixel2d(const int s[9], float *delta_x, float *delta_y)
         float dx1 = 0.0f, dx2 = 0.0f, dy1 = 0.0f, dy2 = 0.0f;
         if (tx) {
             dx1 = 1.0f;
-            dy1 = -(float)(coeff4 + coeff5) / (float)(2 * coeff2);
+            dy1 = (float)FDIV(-(float)(coeff4 + coeff5), (float)(2 * coeff2));
             if ((double)dy1 > 1.0) dy1 = 1.0f; else if ((double)dy1 < -1.0) dy1 = -1.0f;
         } else if (tx_) {
             dx1 = -1.0f;
-            dy1 = -(float)(coeff4 - coeff5) / (float)(2 * coeff2);
+            dy1 = (float)FDIV(-(float)(coeff4 - coeff5), (float)(2 * coeff2));
             if ((double)dy1 > 1.0) dy1 = 1.0f; else if ((double)dy1 < -1.0) dy1 = -1.0f;
         }
         if (ty) {
             dy2 = 1.0f;
-            dx2 = -(float)(coeff3 + coeff5) / (float)(2 * coeff1);
+            dx2 = (float)FDIV(-(float)(coeff3 + coeff5), (float)(2 * coeff1));
             if ((double)dx2 > 1.0) dx2 = 1.0f; else if ((double)dx2 < -1.0) dx2 = -1.0f;
         } else if (ty_) {
             dy2 = -1.0f;
-            dx2 = -(float)(coeff3 - coeff5) / (float)(2 * coeff1);
+            dx2 = (float)FDIV(-(float)(coeff3 - coeff5), (float)(2 * coeff1));
             if ((double)dx2 > 1.0) dx2 = 1.0f; else if ((double)dx2 < -1.0) dx2 = -1.0f;
         }
-        /* int * float products, summed left to right in float, divided in double (:1619-1626) */
-        const float max1 = (float)((double)((float)coeff1 * dx1 * dx1 + (float)coeff2 * dy1 * dy1 + (float)coeff3 * dx1 + (float)coeff4 * dy1 +
-                                            (float)coeff5 * dx1 * dy1 + (float)coeff6) / 18.0);
-        const float max2 = (float)((double)((float)coeff1 * dx2 * dx2 + (float)coeff2 * dy2 * dy2 + (float)coeff3 * dx2 + (float)coeff4 * dy2 +
-                                            (float)coeff5 * dx2 * dy2 + (float)coeff6) / 18.0);
+        /* int * float products, summed left to right as floats, divided in double (:1619-1626) */
+#define QUAD(X, Y)                                                                                                                    \
+    FADD(FADD(FADD(FADD(FADD(FMUL(FMUL((float)coeff1, X), X), FMUL(FMUL((float)coeff2, Y), Y)), FMUL((float)coeff3, X)), FMUL((float)coeff4, Y)), \
+              FMUL(FMUL((float)coeff5, X), Y)),                                                                                       \
+         (float)coeff6)
+        const float max1 = (float)(QUAD(dx1, dy1) / 18.0);
+        const float max2 = (float)(QUAD(dx2, dy2) / 18.0);
         if (max1 > max2) {
             *delta_x = dx1;
             *delta_y = dx1; /* sic (:1629) */
@@ -352,8 +371,8 @@ float mo_brisk_subpixel2d(const int s[9], float *delta_x, float *delta_y)
     }
     *delta_x = dx;
     *delta_y = dy;
-    return (float)((double)((float)coeff1 * dx * dx + (float)coeff2 * dy * dy + (float)coeff3 * dx + (float)coeff4 * dy + (float)coeff5 * dx * dy +
-                            (float)coeff6) / 18.0);
+    return (float)(QUAD(dx, dy) / 18.0);
+#undef QUAD
 }
 
 /* brisk.cpp:1418-1457 (variant 0), :1459-1497 (1), :1499-1533 (2) */
@@ -400,12 +419,12 @@ float mo_brisk_refine1d(int variant, float s_05, float s0, float s05, float *max
             return (float)(variant == 1 ? 1.3333333333333333333333333333 : 1.5);
         }
     }
-    float ret_val = -(float)b / (float)(2 * a);
+    float ret_val = (float)FDIV(-(float)b, (float)(2 * a));
     if ((double)ret_val < lo_d)
         ret_val = (float)lo_d;
     else if ((double)ret_val > hi_d)
         ret_val = (float)hi_d;
-    float m = (float)c + (float)a * ret_val * ret_val + (float)b * ret_val;
+    float m = (float)FADD(FADD((float)c, FMUL(FMUL((float)a, ret_val), ret_val)), FMUL((float)b, ret_val));
     if (variant == 2)
         m = m / (float)1024; /* max/=1024 (:1531): int divisor, float division */
     else
@@ -514,12 +533,12 @@ static float score_max_neighbour_layer(mo_brisk *b, int layer, int x_layer, int 
     }
 
     /* first row */
-    int max_x = (int)(x_1 + 1);
-    int max_y = (int)(y_1 + 1);
+    int max_x = (int)FADD(x_1, 1.0f);
+    int max_y = (int)FADD(y_1, 1.0f);
     float tmp_max;
     float max = (float)layer_score_f(lay, x_1, y_1, 1);
     if (max > (float)threshold) return 0;
-    for (int x = (int)(x_1 + 1); x <= (int)x1; x++) {
+    for (int x = (int)FADD(x_1, 1.0f); x <= (int)x1; x++) {
         tmp_max = (float)layer_score_f(lay, (float)x, y_1, 1);
         if (tmp_max > (float)threshold) return 0;
         if (tmp_max > max) {
@@ -535,15 +554,15 @@ static float score_max_neighbour_layer(mo_brisk *b, int layer, int x_layer, int 
     }
 
     /* middle rows */
-    for (int y = (int)(y_1 + 1); y <= (int)y1; y++) {
+    for (int y = (int)FADD(y_1, 1.0f); y <= (int)y1; y++) {
         tmp_max = (float)layer_score_f(lay, x_1, (float)y, 1);
         if (tmp_max > (float)threshold) return 0;
         if (tmp_max > max) {
             max = tmp_max;
-            max_x = (int)(x_1 + 1);
+            max_x = (int)FADD(x_1, 1.0f);
             max_y = y;
         }
-        for (int x = (int)(x_1 + 1); x <= (int)x1; x++) {
+        for (int x = (int)FADD(x_1, 1.0f); x <= (int)x1; x++) {
             tmp_max = (float)layer_score(lay, x, y, 1);
             if (tmp_max > (float)threshold) return 0;
             if (!above && tmp_max == max) { /* :1321-1344 */
@@ -579,10 +598,10 @@ static float score_max_neighbour_layer(mo_brisk *b, int layer, int x_layer, int 
     tmp_max = (float)layer_score_f(lay, x_1, y1, 1);
     if (tmp_max > max) {
         max = tmp_max;
-        max_x = (int)(x_1 + 1);
+        max_x = (int)FADD(x_1, 1.0f);
         max_y = (int)y1;
     }
-    for (int x = (int)(x_1 + 1); x <= (int)x1; x++) {
+    for (int x = (int)FADD(x_1, 1.0f); x <= (int)x1; x++) {
         tmp_max = (float)layer_score_f(lay, (float)x, y1, 1);
         if (tmp_max > max) {
             max = tmp_max;
@@ -600,13 +619,13 @@ static float score_max_neighbour_layer(mo_brisk *b, int layer, int x_layer, int 
     float dx_1, dy_1;
     const float refined_max = patch_subpixel(lay, max_x, max_y, &dx_1, &dy_1);
 
-    const float real_x = (float)max_x + dx_1;
-    const float real_y = (float)max_y + dy_1;
+    const float real_x = (float)FADD((float)max_x, dx_1);
+    const float real_y = (float)FADD((float)max_y, dy_1);
     int returnrefined = 1;
     if (above) {
         if (layer % 2 == 0) { /* float arithmetic (:1228-1229) */
-            *dx = (real_x * 6.0f + 1.0f) / 4.0f - (float)x_layer;
-            *dy = (real_y * 6.0f + 1.0f) / 4.0f - (float)y_layer;
+            *dx = (float)FSUB(FDIV(FADD(FMUL(real_x, 6.0f), 1.0f), 4.0f), (float)x_layer);
+            *dy = (float)FSUB(FDIV(FADD(FMUL(real_y, 6.0f), 1.0f), 4.0f), (float)y_layer);
         } else { /* double arithmetic (:1232-1233) */
             *dx = (float)(((double)real_x * 8.0 + 1.0) / 6.0 - (double)(float)x_layer);
             *dy = (float)(((double)real_y * 8.0 + 1.0) / 6.0 - (double)(float)y_layer);
@@ -631,6 +650,9 @@ static float score_max_neighbour_layer(mo_brisk *b, int layer, int x_layer, int 
 }
 
 /* brisk.cpp:937-1103 */
+/* (r0 * delta_layer + r1 * delta_other + float(c)) [* scale + offset]: ONE expression each in the reference (:1022-1092) */
+#define BLEND(R0, DL, R1, DO, C) FADD(FADD(FMUL(R0, DL), FMUL(R1, DO)), (float)(C))
+#define PLACE(R0, DL, R1, DO, C) ((float)FADD(FMUL(BLEND(R0, DL, R1, DO, C), thisLayer->scale), thisLayer->offset))
 static float refine_3d(mo_brisk *b, int layer, int x_layer, int y_layer, float *x, float *y, float *scale, int *ismax)
 {
     *ismax = 1;
@@ -682,18 +704,18 @@ static float refine_3d(mo_brisk *b, int layer, int x_layer, int y_layer, float *
         if ((double)*scale > 1.0) {
             const float r0 = (float)((1.5 - (double)*scale) / .5);
             const float r1 = (float)(1.0 - (double)r0);
-            *x = (r0 * delta_x_layer + r1 * delta_x_above + (float)x_layer) * thisLayer->scale + thisLayer->offset;
-            *y = (r0 * delta_y_layer + r1 * delta_y_above + (float)y_layer) * thisLayer->scale + thisLayer->offset;
+            *x = PLACE(r0, delta_x_layer, r1, delta_x_above, x_layer);
+            *y = PLACE(r0, delta_y_layer, r1, delta_y_above, y_layer);
         } else if (layer == 0) {
             const float r0 = (float)(((double)*scale - 0.5) / 0.5);
             const float r_1 = (float)(1.0 - (double)r0);
-            *x = r0 * delta_x_layer + r_1 * delta_x_below + (float)x_layer;
-            *y = r0 * delta_y_layer + r_1 * delta_y_below + (float)y_layer;
+            *x = (float)BLEND(r0, delta_x_layer, r_1, delta_x_below, x_layer);
+            *y = (float)BLEND(r0, delta_y_layer, r_1, delta_y_below, y_layer);
         } else {
             const float r0 = (float)(((double)*scale - 0.75) / 0.25);
             const float r_1 = (float)(1.0 - (double)r0);
-            *x = (r0 * delta_x_layer + r_1 * delta_x_below + (float)x_layer) * thisLayer->scale + thisLayer->offset;
-            *y = (r0 * delta_y_layer + r_1 * delta_y_below + (float)y_layer) * thisLayer->scale + thisLayer->offset;
+            *x = PLACE(r0, delta_x_layer, r_1, delta_x_below, x_layer);
+            *y = PLACE(r0, delta_y_layer, r_1, delta_y_below, y_layer);
         }
     } else { /* on intra */
         const float max_below = score_max_neighbour_layer(b, layer, x_layer, y_layer, center, ismax, &delta_x_below, &delta_y_below, 0);
@@ -704,13 +726,13 @@ static float refine_3d(mo_brisk *b, int layer, int x_layer, int y_layer, float *
         if ((double)*scale > 1.0) {
             const float r0 = (float)(4.0 - (double)*scale * 3.0);
             const float r1 = (float)(1.0 - (double)r0);
-            *x = (r0 * delta_x_layer + r1 * delta_x_above + (float)x_layer) * thisLayer->scale + thisLayer->offset;
-            *y = (r0 * delta_y_layer + r1 * delta_y_above + (float)y_layer) * thisLayer->scale + thisLayer->offset;
+            *x = PLACE(r0, delta_x_layer, r1, delta_x_above, x_layer);
+            *y = PLACE(r0, delta_y_layer, r1, delta_y_above, y_layer);
         } else {
             const float r0 = (float)((double)*scale * 3.0 - 2.0);
             const float r_1 = (float)(1.0 - (double)r0);
-            *x = (r0 * delta_x_layer + r_1 * delta_x_below + (float)x_layer) * thisLayer->scale + thisLayer->offset;
-            *y = (r0 * delta_y_layer + r_1 * delta_y_below + (float)y_layer) * thisLayer->scale + thisLayer->offset;
+            *x = PLACE(r0, delta_x_layer, r_1, delta_x_below, x_layer);
+            *y = PLACE(r0, delta_y_layer, r_1, delta_y_below, y_layer);
         }
     }
     *scale *= thisLayer->scale;
@@ -774,8 +796,8 @@ int mo_brisk_get_keypoints(mo_brisk *b, int threshold, mo_brisk_keypoint *out, i
                 if (!ismax) continue;
                 float delta_x, delta_y;
                 const float max = patch_subpixel(l, px, py, &delta_x, &delta_y);
-                emit(out, cap, &n, ((float)px + delta_x) * l->scale + l->offset, ((float)py + delta_y) * l->scale + l->offset,
-                     basicSize * l->scale, max, i);
+                emit(out, cap, &n, (float)FADD(FMUL(FADD((float)px, delta_x), l->scale), l->offset),
+                     (float)FADD(FMUL(FADD((float)py, delta_y), l->scale), l->offset), basicSize * l->scale, max, i);
             } else { /* :681-701 */
                 int ismax;
                 float x, y, scale;

@@ -59,6 +59,14 @@ int mo_brisk_layer_points(const mo_brisk *b, int layer, int32_t *xy, int cap);
 /* one-shot: BriskFeatureDetector(threshold, octaves).detect(img) */
 int mo_brisk_detect(const uint8_t *img, int stride, int w, int h, int threshold, int octaves, mo_brisk_keypoint *out, int cap);
 
+/* What a float expression of brisk.cpp means (see brisk_oracle.c): MO_BRISK_FP_X87, the default, is the reference as its
+ * README and project file say it was built (Visual Studio 2010, Win32, no /arch: x87 code, intermediates at the FPU's 53 bits,
+ * rounded to float at assignments); MO_BRISK_FP_SSE rounds every float operation.  Process-wide; set it before detecting. */
+#define MO_BRISK_FP_X87 0
+#define MO_BRISK_FP_SSE 1
+void mo_brisk_set_fp_model(int model);
+int mo_brisk_get_fp_model(void);
+
 /* pieces, for component tests */
 void mo_brisk_halfsample(const uint8_t *src, int w, int h, uint8_t *dst);       /* dst: (w/2) x (h/2) */
 void mo_brisk_twothirdsample(const uint8_t *src, int w, int h, uint8_t *dst);   /* dst: 2*(w/3) x 2*(h/3) */

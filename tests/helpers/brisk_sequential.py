@@ -12,16 +12,45 @@ or data structure with the oracle: the pyramid comes from the literal SSE emulat
 the corner scores from the max-over-arcs-of-min form.  tests/test_brisk_sequential.py compares the two on tie-heavy
 inputs, where the outcome depends on which cache cells are filled when.
 
-Arithmetic: C `float` is numpy.float32, one IEEE operation at a time; an expression with a double literal in it
-(`/6.0`, `*3.0`, `0.75`) is evaluated in double and rounded to float where the reference assigns it to a float
-(SSE2 semantics; an x87 build could differ in the last bit of a few refined coordinates -- an open parity risk that
-DESIGN.md lists, and not what this file is about).
+Arithmetic: C `float` is numpy.float32.  Two readings of "a float expression", selectable with set_fp_model():
+  "sse"  (default; what the oracle and the device implement) every float operation rounds to float, an expression with
+         a double literal in it (`/6.0`, `*3.0`, `0.75`) is evaluated in double; results are rounded to float where the
+         reference assigns them to a float;
+  "x87"  what a 32-bit MSVC 2010 build without /arch:SSE2 does (the reference's project file names no toolset or /arch):
+         every intermediate of an expression is kept at the FPU's 53-bit precision and rounded to float only where it is
+         assigned to a float variable, passed as a float argument or returned as float.
+tests/test_brisk_sequential.py counts how many keypoints differ between the two -- the size of that open parity risk.
 """
 from __future__ import annotations
 
 import numpy as np
 
-f32 = np.float32
+f32 = np.float32   # a value STORED in a C float: rounds in both models
+_X87 = [False]
+
+
+def set_fp_model(name: str) -> None:
+    assert name in ("sse", "x87")
+    _X87[0] = name == "x87"
+
+
+# ONE float-typed operation inside an expression (operands are floats, or ints converted to float): rounded to float
+# under SSE, carried at the FPU's 53 bits under x87.  f32() marks the places where the reference stores into a float.
+def fmul(a, b):
+    return float(a) * float(b) if _X87[0] else np.float32(np.float32(a) * np.float32(b))
+
+
+def fadd(a, b):
+    return float(a) + float(b) if _X87[0] else np.float32(np.float32(a) + np.float32(b))
+
+
+def fsub(a, b):
+    return float(a) - float(b) if _X87[0] else np.float32(np.float32(a) - np.float32(b))
+
+
+def fdiv(a, b):
+    return float(a) / float(b) if _X87[0] else np.float32(np.float32(a) / np.float32(b))
+
 
 C16 = [(-3, 0), (-3, -1), (-2, -2), (-1, -3), (0, -3), (1, -3), (2, -2), (3, -1), (3, 0), (3, 1), (2, 2), (1, 3), (0, 3),
        (-1, 3), (-2, 2), (-3, 1)]
@@ -111,10 +140,10 @@ class Layer:
         y = c_int(yf)
         ry1 = f32(yf - f32(y))
         ry = f32(f32(1.0) - ry1)
-        v = f32(f32(rx * ry) * f32(self.score(x, y, threshold)))
-        v = f32(v + f32(f32(rx1 * ry) * f32(self.score(x + 1, y, threshold))))
-        v = f32(v + f32(f32(rx * ry1) * f32(self.score(x, y + 1, threshold))))
-        v = f32(v + f32(f32(rx1 * ry1) * f32(self.score(x + 1, y + 1, threshold))))
+        v = fmul(fmul(rx, ry), self.score(x, y, threshold))          # one expression: converted to uint8_t at the return
+        v = fadd(v, fmul(fmul(rx1, ry), self.score(x + 1, y, threshold)))
+        v = fadd(v, fmul(fmul(rx, ry1), self.score(x, y + 1, threshold)))
+        v = fadd(v, fmul(fmul(rx1, ry1), self.score(x + 1, y + 1, threshold)))
         return c_int(v) & 0xFF
 
 
@@ -146,8 +175,8 @@ def subpixel2d(s_0_0, s_0_1, s_0_2, s_1_0, s_1_1, s_1_2, s_2_0, s_2_1, s_2_2):
         if tmp > tmp_max:
             tmp_max, dx, dy = tmp, -1.0, -1.0
         return f32(float(f32(tmp_max + coeff1 + coeff2 + coeff6)) / 18.0), f32(dx), f32(dy)
-    delta_x = f32(f32(2 * coeff2 * coeff3 - coeff4 * coeff5) / f32(-H_det))
-    delta_y = f32(f32(2 * coeff1 * coeff4 - coeff3 * coeff5) / f32(-H_det))
+    delta_x = f32(fdiv(2 * coeff2 * coeff3 - coeff4 * coeff5, -H_det))
+    delta_y = f32(fdiv(2 * coeff1 * coeff4 - coeff3 * coeff5, -H_det))
     tx = tx_ = ty = ty_ = False
     if delta_x > 1.0:
         tx = True
@@ -166,28 +195,28 @@ def subpixel2d(s_0_0, s_0_1, s_0_2, s_1_0, s_1_1, s_1_2, s_2_0, s_2_1, s_2_2):
         return v
 
     def quad(dx, dy):  # (c1*dx*dx + c2*dy*dy + c3*dx + c4*dy + c5*dx*dy + c6) / 18.0: float products and sums, double division
-        v = f32(f32(f32(coeff1) * dx) * dx)
-        v = f32(v + f32(f32(f32(coeff2) * dy) * dy))
-        v = f32(v + f32(f32(coeff3) * dx))
-        v = f32(v + f32(f32(coeff4) * dy))
-        v = f32(v + f32(f32(f32(coeff5) * dx) * dy))
-        v = f32(v + f32(coeff6))
+        v = fmul(fmul(coeff1, dx), dx)
+        v = fadd(v, fmul(fmul(coeff2, dy), dy))
+        v = fadd(v, fmul(coeff3, dx))
+        v = fadd(v, fmul(coeff4, dy))
+        v = fadd(v, fmul(fmul(coeff5, dx), dy))
+        v = fadd(v, coeff6)
         return f32(float(v) / 18.0)
 
     if tx or tx_ or ty or ty_:
         dx1 = dx2 = dy1 = dy2 = f32(0.0)
         if tx:
             dx1 = f32(1.0)
-            dy1 = clamp1(f32(-f32(coeff4 + coeff5) / f32(2 * coeff2)))
+            dy1 = clamp1(f32(fdiv(-(coeff4 + coeff5), 2 * coeff2)))
         elif tx_:
             dx1 = f32(-1.0)
-            dy1 = clamp1(f32(-f32(coeff4 - coeff5) / f32(2 * coeff2)))
+            dy1 = clamp1(f32(fdiv(-(coeff4 - coeff5), 2 * coeff2)))
         if ty:
             dy2 = f32(1.0)
-            dx2 = clamp1(f32(-f32(coeff3 + coeff5) / f32(2 * coeff1)))
+            dx2 = clamp1(f32(fdiv(-(coeff3 + coeff5), 2 * coeff1)))
         elif ty_:
             dy2 = f32(-1.0)
-            dx2 = clamp1(f32(-f32(coeff3 - coeff5) / f32(2 * coeff1)))
+            dx2 = clamp1(f32(fdiv(-(coeff3 - coeff5), 2 * coeff1)))
         max1, max2 = quad(dx1, dy1), quad(dx2, dy2)
         if max1 > max2:
             return max1, dx1, dx1
@@ -210,15 +239,14 @@ def _refine1d(s_05, s0, s05, k, lo, hi, div):
         if s05 >= s0 and s05 >= s_05:
             return f32(hi), s05
     b = k[3] * i_05 + k[4] * i0 + k[5] * i05
-    ret = f32(-f32(b) / f32(2 * a))
+    ret = f32(fdiv(-b, 2 * a))
     if float(ret) < lo:
         ret = f32(lo)
     elif float(ret) > hi:
         ret = f32(hi)
     c = k[6] * i_05 + k[7] * i0 + k[8] * i05
-    mx = f32(f32(c) + f32(f32(f32(a) * ret) * ret))
-    mx = f32(mx + f32(f32(b) * ret))
-    return ret, f32(float(mx) / div)
+    mx = fadd(fadd(c, fmul(fmul(a, ret), ret)), fmul(b, ret))  # one expression, stored into `max`
+    return ret, f32(float(f32(mx)) / div)
 
 
 def refine1d(s_05, s0, s05):
@@ -301,12 +329,12 @@ class ScaleSpace:
         """First row, middle rows, bottom row of getScoreMaxAbove / getScoreMaxBelow -> (ok, max, max_x, max_y).
         tie_rule: the smoothed-sum comparison getScoreMaxBelow makes on equal scores inside a middle row (:1316-1339)."""
         S, Sf = other.score, other.score_f
-        max_x = c_int(f32(x_1 + f32(1)))
-        max_y = c_int(f32(y_1 + f32(1)))
+        max_x = c_int(fadd(x_1, 1))
+        max_y = c_int(fadd(y_1, 1))
         mx = f32(Sf(x_1, y_1))
         if mx > threshold:
             return False, mx, max_x, max_y
-        for x in range(c_int(f32(x_1 + f32(1))), c_int(x1) + 1):
+        for x in range(c_int(fadd(x_1, 1)), c_int(x1) + 1):
             t = f32(Sf(f32(x), y_1))
             if t > threshold:
                 return False, mx, max_x, max_y
@@ -317,13 +345,13 @@ class ScaleSpace:
             return False, mx, max_x, max_y
         if t > mx:
             mx, max_x = t, c_int(x1)
-        for y in range(c_int(f32(y_1 + f32(1))), c_int(y1) + 1):
+        for y in range(c_int(fadd(y_1, 1)), c_int(y1) + 1):
             t = f32(Sf(x_1, f32(y)))
             if t > threshold:
                 return False, mx, max_x, max_y
             if t > mx:
-                mx, max_x, max_y = t, c_int(f32(x_1 + f32(1))), y
-            for x in range(c_int(f32(x_1 + f32(1))), c_int(x1) + 1):
+                mx, max_x, max_y = t, c_int(fadd(x_1, 1)), y
+            for x in range(c_int(fadd(x_1, 1)), c_int(x1) + 1):
                 t = f32(S(x, y))
                 if t > threshold:
                     return False, mx, max_x, max_y
@@ -342,8 +370,8 @@ class ScaleSpace:
                 mx, max_x, max_y = t, c_int(x1), y
         t = f32(Sf(x_1, y1))
         if t > mx:
-            mx, max_x, max_y = t, c_int(f32(x_1 + f32(1))), c_int(y1)
-        for x in range(c_int(f32(x_1 + f32(1))), c_int(x1) + 1):
+            mx, max_x, max_y = t, c_int(fadd(x_1, 1)), c_int(y1)
+        for x in range(c_int(fadd(x_1, 1)), c_int(x1) + 1):
             t = f32(Sf(f32(x), y1))
             if t > mx:
                 mx, max_x, max_y = t, x, c_int(y1)
@@ -385,10 +413,10 @@ class ScaleSpace:
         if not ok:
             return f32(0), False, f32(0), f32(0)
         refined_max, dx_1, dy_1 = subpixel2d(*self._patch(above.score, max_x, max_y))
-        real_x, real_y = f32(f32(max_x) + dx_1), f32(f32(max_y) + dy_1)
+        real_x, real_y = f32(fadd(max_x, dx_1)), f32(fadd(max_y, dy_1))
         if layer % 2 == 0:
-            dx = f32(f32(f32(f32(real_x * f32(6.0)) + f32(1.0)) / f32(4.0)) - f32(x_layer))
-            dy = f32(f32(f32(f32(real_y * f32(6.0)) + f32(1.0)) / f32(4.0)) - f32(y_layer))
+            dx = f32(fsub(fdiv(fadd(fmul(real_x, 6.0), 1.0), 4.0), x_layer))
+            dy = f32(fsub(fdiv(fadd(fmul(real_y, 6.0), 1.0), 4.0), y_layer))
         else:
             dx = f32((float(real_x) * 8.0 + 1.0) / 6.0 - float(f32(x_layer)))
             dy = f32((float(real_y) * 8.0 + 1.0) / 6.0 - float(f32(y_layer)))
@@ -410,7 +438,7 @@ class ScaleSpace:
         if not ok:
             return f32(0), False, f32(0), f32(0)
         refined_max, dx_1, dy_1 = subpixel2d(*self._patch(below.score, max_x, max_y))
-        real_x, real_y = f32(f32(max_x) + dx_1), f32(f32(max_y) + dy_1)
+        real_x, real_y = f32(fadd(max_x, dx_1)), f32(fadd(max_y, dy_1))
         if layer % 2 == 0:
             dx = f32((float(real_x) * 6.0 + 1.0) / 8.0 - float(f32(x_layer)))
             dy = f32((float(real_y) * 6.0 + 1.0) / 8.0 - float(f32(y_layer)))
@@ -431,8 +459,8 @@ class ScaleSpace:
 
         def place(r0, d_layer, r1, d_other, c):
             """(r0 * delta_layer + r1 * delta_other + float(c)) * scale + offset, in float."""
-            v = f32(f32(f32(r0 * d_layer) + f32(r1 * d_other)) + c)
-            return f32(f32(v * this.scale) + this.offset)
+            v = fadd(fadd(fmul(r0, d_layer), fmul(r1, d_other)), c)
+            return f32(fadd(fmul(v, this.scale), this.offset))
 
         if layer % 2 == 0:
             if layer == 0:
@@ -454,8 +482,8 @@ class ScaleSpace:
             elif layer == 0:
                 r0 = f32((float(scale) - 0.5) / 0.5)
                 r_1 = f32(1.0 - float(r0))
-                x = f32(f32(f32(r0 * dxl) + f32(r_1 * dxb)) + xl)
-                y = f32(f32(f32(r0 * dyl) + f32(r_1 * dyb)) + yl)
+                x = f32(fadd(fadd(fmul(r0, dxl), fmul(r_1, dxb)), xl))
+                y = f32(fadd(fadd(fmul(r0, dyl), fmul(r_1, dyb)), yl))
             else:
                 r0 = f32((float(scale) - 0.75) / 0.25)
                 r_1 = f32(1.0 - float(r0))
@@ -474,7 +502,7 @@ class ScaleSpace:
                 r0 = f32(float(scale) * 3.0 - 2.0)
                 r_1 = f32(1.0 - float(r0))
                 x, y = place(r0, dxl, r_1, dxb, xl), place(r0, dyl, r_1, dyb, yl)
-        scale = f32(scale * this.scale)
+        scale = f32(fmul(scale, this.scale))
         return mx, x, y, scale, True
 
     # ---- getKeypoints (:590-704)
@@ -489,7 +517,7 @@ class ScaleSpace:
                 if not self.is_max_2d(0, x, y):
                     continue
                 mx, dx, dy = subpixel2d(*self._patch(l.score, x, y))
-                out.append((f32(f32(x) + dx), f32(f32(y) + dy), self.BASIC_SIZE, mx, 0))
+                out.append((f32(fadd(x, dx)), f32(fadd(y, dy)), self.BASIC_SIZE, mx, 0))
             return out
         for i, l in enumerate(self.L):
             if i == self.n_layers - 1:
@@ -500,8 +528,8 @@ class ScaleSpace:
                     if not ismax:
                         continue
                     mx, dx, dy = subpixel2d(*self._patch(l.score, x, y))
-                    out.append((f32(f32(f32(f32(x) + dx) * l.scale) + l.offset), f32(f32(f32(f32(y) + dy) * l.scale) + l.offset),
-                                f32(self.BASIC_SIZE * l.scale), mx, i))
+                    out.append((f32(fadd(fmul(fadd(x, dx), l.scale), l.offset)), f32(fadd(fmul(fadd(y, dy), l.scale), l.offset)),
+                                f32(fmul(self.BASIC_SIZE, l.scale)), mx, i))
             else:
                 for x, y in points[i]:
                     if not self.is_max_2d(i, x, y):
@@ -510,5 +538,5 @@ class ScaleSpace:
                     if not ismax:
                         continue
                     if score > f32(threshold):
-                        out.append((kx, ky, f32(self.BASIC_SIZE * scale), score, i))
+                        out.append((kx, ky, f32(fmul(self.BASIC_SIZE, scale)), score, i))
         return out

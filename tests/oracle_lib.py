@@ -317,6 +317,19 @@ class Brisk:
         return xy[:n]
 
 
+BRISK_FP_X87, BRISK_FP_SSE = 0, 1
+
+
+def brisk_set_fp_model(model: int) -> None:
+    """What a float expression of brisk.cpp means (brisk_oracle.h): BRISK_FP_X87 (default: the reference as built, Visual
+    Studio 2010 Win32) or BRISK_FP_SSE.  Process-wide."""
+    lib().mo_brisk_set_fp_model(int(model))
+
+
+def brisk_get_fp_model() -> int:
+    return int(lib().mo_brisk_get_fp_model())
+
+
 def brisk_detect(img, threshold=30, octaves=3, cap=1 << 20) -> np.ndarray:
     img = np.ascontiguousarray(img, np.uint8)
     H, W = img.shape

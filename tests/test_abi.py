@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(native_lib):
     for n in names:
         assert hasattr(native_lib, n), f"{n} declared in mofreak_hip.h but not exported"
     assert sorted(api.EXPORTS) == names, "api.EXPORTS out of date with the header"
-    assert native_lib.mofreak_abi_version() == 1
+    assert native_lib.mofreak_abi_version() == 2
 
 
 def test_default_params_are_the_reference_constants(native_lib):
@@ -44,6 +44,7 @@ def test_default_params_are_the_reference_constants(native_lib):
     assert p.struct_size == C.sizeof(api.Params)
     assert (p.gap_for_frame_difference, p.mip_theta, p.freak_n_octaves) == (5, 288, 4)  # MoFREAKUtilities.cpp:378, :48
     assert p.freak_pattern_scale == 22.0 and p.freak_orientation_normalized == 1 and p.freak_scale_normalized == 1
+    assert p.brisk_fp_model == api.FP_X87 == 0  # the reference as it was built: Visual Studio 2010, Win32, x87
     assert p.freak_bit_mode == M.BITS_SSE
 
 

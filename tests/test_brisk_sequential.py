@@ -34,9 +34,16 @@ def quantised_noise(seed, h, w, levels=4, block=3):
     return np.kron(small, np.ones((block, block), np.int64))[:h, :w].astype(np.uint8)
 
 
-def sequential_keypoints(img, threshold, octaves):
-    ss = BS.ScaleSpace(img, octaves, _halfsample_simd, _twothird_simd)
-    kps = ss.get_keypoints(threshold)
+MODELS = {"x87": O.BRISK_FP_X87, "sse": O.BRISK_FP_SSE}
+
+
+def sequential_keypoints(img, threshold, octaves, model="x87"):
+    BS.set_fp_model(model)
+    try:
+        ss = BS.ScaleSpace(img, octaves, _halfsample_simd, _twothird_simd)
+        kps = ss.get_keypoints(threshold)
+    finally:
+        BS.set_fp_model("sse")
     out = np.zeros(len(kps), O.KEYPOINT_DTYPE)
     for i, k in enumerate(kps):
         out[i] = k
@@ -53,10 +60,16 @@ def cases():
     yield "ties_o1", quantised_noise(7, 120, 160, 3, 2), 25, 1
 
 
+@pytest.mark.parametrize("model", ["x87", "sse"])
 @pytest.mark.parametrize("name,img,thr,octaves", list(cases()), ids=[c[0] for c in cases()])
-def test_oracle_equals_the_sequential_restatement(name, img, thr, octaves):
-    got, ss = sequential_keypoints(img, thr, octaves)
-    want = O.brisk_detect(img, thr, octaves)
+def test_oracle_equals_the_sequential_restatement(name, img, thr, octaves, model):
+    """In both readings of a float expression: the reference's x87 build (default) and per-operation rounding."""
+    got, ss = sequential_keypoints(img, thr, octaves, model)
+    O.brisk_set_fp_model(MODELS[model])
+    try:
+        want = O.brisk_detect(img, thr, octaves)
+    finally:
+        O.brisk_set_fp_model(O.BRISK_FP_X87)
     assert len(got) == len(want) and len(got) > 10, (len(got), len(want))
     assert got.tobytes() == want.tobytes(), next(i for i in range(len(got)) if got[i].tobytes() != want[i].tobytes())
     if name.startswith("ties"):
@@ -71,6 +84,25 @@ def test_oracle_equals_the_sequential_restatement(name, img, thr, octaves):
 
 def test_golden_file_is_what_the_restatement_produces():
     z = np.load(GOLDEN)
-    for name, img, thr, octaves in cases():
-        got, _ = sequential_keypoints(img, thr, octaves)
-        assert z[name].tobytes() == got.tobytes(), name
+    for model in MODELS:
+        for name, img, thr, octaves in cases():
+            got, _ = sequential_keypoints(img, thr, octaves, model)
+            assert z[f"{model}/{name}"].tobytes() == got.tobytes(), (model, name)
+
+
+def test_the_two_float_models_differ_little_but_do_differ():
+    """The size of the open parity risk: which compiler flags built the reference's brisk.cpp is known from its README and
+    project file only (Visual Studio 2010, Win32, no /arch: x87).  Same number of keypoints either way; about a third differ in
+    the last bit of some float field; a handful differ by more."""
+    z = np.load(GOLDEN)
+    total = differ = far = 0
+    for name, *_ in cases():
+        a, b = z[f"x87/{name}"], z[f"sse/{name}"]
+        assert len(a) == len(b), name
+        total += len(a)
+        for i in range(len(a)):
+            if a[i].tobytes() != b[i].tobytes():
+                differ += 1
+                if abs(float(a[i]["x"]) - float(b[i]["x"])) + abs(float(a[i]["y"]) - float(b[i]["y"])) > 1e-3 or a[i]["size"] != b[i]["size"]:
+                    far += 1
+    assert total > 20000 and 0.2 < differ / total < 0.4 and 0 < far < 0.002 * total, (total, differ, far)

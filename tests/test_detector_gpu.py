@@ -116,13 +116,15 @@ def test_device_equals_the_independent_sequential_restatement(ctx):
     import test_brisk_sequential as T
     z = np.load(T.GOLDEN)
     n = 0
-    for name, img, thr, octaves in T.cases():
-        kps, offs, resp, layer = ctx.detect_pairs_host(img, None, thr, octaves)
-        w = z[name]
-        want = (np.stack([w["x"], w["y"], w["size"]], 1).astype(np.float32).reshape(-1, 3), w["response"].copy(), w["layer"].copy())
-        _assert_same_keypoints((kps, resp, layer), want, name)
-        n += len(w)
-    assert n > 20000
+    for model, code in (("x87", M.api.FP_X87), ("sse", M.api.FP_SSE)):  # both readings of a float expression
+        with M.Context(0, brisk_fp_model=code) as c:
+            for name, img, thr, octaves in T.cases():
+                kps, offs, resp, layer = c.detect_pairs_host(img, None, thr, octaves)
+                w = z[f"{model}/{name}"]
+                want = (np.stack([w["x"], w["y"], w["size"]], 1).astype(np.float32).reshape(-1, 3), w["response"].copy(), w["layer"].copy())
+                _assert_same_keypoints((kps, resp, layer), want, f"{model}/{name}")
+                n += len(w)
+    assert n > 40000
 
 
 @pytest.mark.parametrize("T,W,H", [(21, 320, 240), (25, 400, 300), (60, 320, 240), (72, 212, 160)])
