@@ -28,6 +28,8 @@
 //
 // Integer/byte work bound by LDS and VALU issue, no MFMA.  Floating point mirrors the reference's expressions
 // (float vs double literals) one operation at a time; compile with -ffp-contract=off.
+#include <type_traits>
+
 #include "device_helpers.h"
 
 namespace mofreak {
@@ -41,21 +43,20 @@ struct PairView {
     const uint8_t *score;
     uint8_t *touch;
     uint8_t *status;
-    bool x87;  // the float expressions' model (mofreak_params.brisk_fp_model, see Fp below)
 };
 
 // What a C `float` expression of brisk.cpp means.  The reference is a 32-bit Visual Studio 2010 project without an /arch
 // option: x87 code, the FPU at 53-bit precision, intermediates of an expression kept in FPU registers and rounded to float
-// only where they are assigned, cast, passed or returned (MOFREAK_FP_X87, the default); MOFREAK_FP_SSE rounds every float
-// operation to float.  Both are computed here in double with the rounding applied per operation or not: rounding a double
-// +, -, *, / of two floats to float equals the float operation (53 >= 2 * 24 + 2 bits), so the second reading is exact too.
+// only where they are assigned, cast, passed or returned (MOFREAK_FP_X87, the default: Fp<true>, intermediates in double);
+// MOFREAK_FP_SSE rounds every float operation to float (Fp<false>, intermediates in float).  The refinement kernel is
+// instantiated for both; operands are floats (or ints converted to float), results stay in R until they are stored.
+template <bool X87>
 struct Fp {
-    bool x87;
-    __device__ __forceinline__ double op(double v) const { return x87 ? v : (double)(float)v; }
-    __device__ __forceinline__ double mul(double a, double b) const { return op(a * b); }
-    __device__ __forceinline__ double add(double a, double b) const { return op(a + b); }
-    __device__ __forceinline__ double sub(double a, double b) const { return op(a - b); }
-    __device__ __forceinline__ double div(double a, double b) const { return op(a / b); }
+    typedef typename std::conditional<X87, double, float>::type R;
+    static __device__ __forceinline__ R mul(R a, R b) { return a * b; }
+    static __device__ __forceinline__ R add(R a, R b) { return a + b; }
+    static __device__ __forceinline__ R sub(R a, R b) { return a - b; }
+    static __device__ __forceinline__ R div(R a, R b) { return a / b; }
 };
 
 __device__ __forceinline__ PairView pair_view(const DetArgs &a, int p)
@@ -67,7 +68,6 @@ __device__ __forceinline__ PairView pair_view(const DetArgs &a, int p)
     v.score = a.score + o;
     v.touch = a.touch + o;
     v.status = a.status + o;
-    v.x87 = a.fp_x87 != 0;
     return v;
 }
 
@@ -566,7 +566,8 @@ __device__ __forceinline__ int score_5_8_block(const unsigned long long (&im)[5]
 }
 
 // BriskScaleSpace::subpixel2D (brisk.cpp:1535-1644); s = s_0_0, s_0_1, s_0_2, s_1_0, ... (first index x)
-__device__ __forceinline__ float subpixel2d(const Fp fp, const int (&s)[9], float &delta_x, float &delta_y)
+template <class FP>
+__device__ __forceinline__ float subpixel2d(const FP fp, const int (&s)[9], float &delta_x, float &delta_y)
 {
     const int s_0_0 = s[0], s_0_1 = s[1], s_0_2 = s[2], s_1_0 = s[3], s_1_1 = s[4], s_1_2 = s[5], s_2_0 = s[6], s_2_1 = s[7],
               s_2_2 = s[8];
@@ -622,12 +623,12 @@ __device__ __forceinline__ float subpixel2d(const Fp fp, const int (&s)[9], floa
     const float c1 = (float)coeff1, c2 = (float)coeff2, c3 = (float)coeff3, c4 = (float)coeff4, c5 = (float)coeff5, c6 = (float)coeff6;
     // c1*x*x + c2*y*y + c3*x + c4*y + c5*x*y + c6: products and sums of floats, left to right (then divided in double)
     auto quad = [&](float x, float y) -> double {
-        double v = fp.mul(fp.mul(c1, x), x);
+        typename FP::R v = fp.mul(fp.mul(c1, x), x);
         v = fp.add(v, fp.mul(fp.mul(c2, y), y));
         v = fp.add(v, fp.mul(c3, x));
         v = fp.add(v, fp.mul(c4, y));
         v = fp.add(v, fp.mul(fp.mul(c5, x), y));
-        return fp.add(v, c6);
+        return (double)fp.add(v, c6);
     };
     if (tx || tx_ || ty || ty_) {
         float dx1 = 0.0f, dx2 = 0.0f, dy1 = 0.0f, dy2 = 0.0f;
@@ -666,7 +667,8 @@ __device__ __forceinline__ float subpixel2d(const Fp fp, const int (&s)[9], floa
 }
 
 // refine1D (variant 0, :1418), refine1D_1 (1, :1459), refine1D_2 (2, :1499)
-__device__ __forceinline__ float refine1d(const Fp fp, int variant, float s_05, float s0, float s05, float &max)
+template <class FP>
+__device__ __forceinline__ float refine1d(const FP fp, int variant, float s_05, float s0, float s05, float &max)
 {
     const int i_05 = (int)(1024.0 * (double)s_05 + 0.5);
     const int i0 = (int)(1024.0 * (double)s0 + 0.5);
@@ -767,7 +769,7 @@ __device__ __forceinline__ void window_place(Window &win, int layer, int x_layer
 }
 
 // getScoreMaxAbove (ABOVE, brisk.cpp:1106-1249) / getScoreMaxBelow (:1251-1416); the window is in place and filled
-template <bool ABOVE>
+template <bool ABOVE, class FP>
 __device__ __forceinline__ float neighbour_layer_max(const PairView &v, Window &win, int layer, int x_layer, int y_layer, int threshold, bool &ismax, float &dx,
                                                      float &dy)
 {
@@ -776,7 +778,7 @@ __device__ __forceinline__ float neighbour_layer_max(const PairView &v, Window &
     float x_1, x1, y_1, y1;
     walk_square<ABOVE>(layer, x_layer, y_layer, x_1, x1, y_1, y1);
     const float thr = (float)threshold;
-    const Fp fp{v.x87};
+    const FP fp{};
     const int xa = (int)fp.add(x_1, 1.0f), xb = (int)x1, ya = (int)fp.add(y_1, 1.0f), yb = (int)y1;
     auto S = [&](int x, int y) { return window_at<ABOVE>(v, win, x, y); };  // getAgastScore(int, int, 1)
     auto Q = [&](int x, int y) { return window_at<false>(v, win, x, y); };  // same, for the layer below (no bookkeeping)
@@ -788,8 +790,8 @@ __device__ __forceinline__ float neighbour_layer_max(const PairView &v, Window &
         const float ry1 = yf - (float)y;
         const float ry = 1.0f - ry1;
         const float s00 = (float)S(x, y), s10 = (float)S(x + 1, y), s01 = (float)S(x, y + 1), s11 = (float)S(x + 1, y + 1);
-        const double r = fp.add(fp.add(fp.add(fp.mul(fp.mul(rx, ry), s00), fp.mul(fp.mul(rx1, ry), s10)), fp.mul(fp.mul(rx, ry1), s01)),
-                                fp.mul(fp.mul(rx1, ry1), s11));  // one expression, converted to uint8_t
+        const typename FP::R r = fp.add(fp.add(fp.add(fp.mul(fp.mul(rx, ry), s00), fp.mul(fp.mul(rx1, ry), s10)), fp.mul(fp.mul(rx, ry1), s01)),
+                                        fp.mul(fp.mul(rx1, ry1), s11));  // one expression, converted to uint8_t
         return (int)r & 0xff;
     };
 
@@ -917,12 +919,13 @@ struct Refined {
 };
 
 // What getKeypoints does with one 2-D maximum (brisk.cpp:609-702), refine3D included (:937-1103).
+template <class FP>
 __device__ __forceinline__ Refined refine_maximum(const PairView &v, uint8_t *lds_cells, int layer, int px, int py, int threshold)
 {
     // One walk above, one below, one own patch -- in the reference's order (above, below, patch), each at a single
     // call site so that everything inlines and no argument goes through the stack.
     const float basicSize = 12.0f;
-    const Fp fp{v.x87};
+    const FP fp{};
     const DetGeom &g = *v.g;
     const DetLayer &L = g.L[layer];
     Refined out;
@@ -965,7 +968,7 @@ __device__ __forceinline__ Refined refine_maximum(const PairView &v, uint8_t *ld
     float max_above = 0.f, max_below = 0.f;
     float delta_x_above = 0.f, delta_y_above = 0.f, delta_x_below = 0.f, delta_y_below = 0.f, delta_x_layer, delta_y_layer;
     if (!last) {  // refine3D: getScoreMaxAbove first (:945-950)
-        max_above = neighbour_layer_max<true>(v, wa, layer, px, py, center, ismax, delta_x_above, delta_y_above);
+        max_above = neighbour_layer_max<true, FP>(v, wa, layer, px, py, center, ismax, delta_x_above, delta_y_above);
         out.asked = wa.asked;
         out.ox = wa.ox;
         out.oy = wa.oy;
@@ -973,7 +976,7 @@ __device__ __forceinline__ Refined refine_maximum(const PairView &v, uint8_t *ld
         if (!ismax) return out;
     }
     if (layer > 0) {  // getScoreMaxBelow: the last layer (:651-657), octaves above 0 (:991-996), intra layers (:1049-1053)
-        max_below = neighbour_layer_max<false>(v, wb, layer, px, py, center, ismax, delta_x_below, delta_y_below);
+        max_below = neighbour_layer_max<false, FP>(v, wb, layer, px, py, center, ismax, delta_x_below, delta_y_below);
         out.escaped |= wb.escaped;
         if (!ismax) return out;
     } else if (!single) {  // layer 0: guess the missing layer below with the 5/8 mask (:959-989)
@@ -1023,8 +1026,8 @@ __device__ __forceinline__ Refined refine_maximum(const PairView &v, uint8_t *ld
     r1 = (float)(1.0 - (double)r0);
     const float ox = up ? delta_x_above : delta_x_below, oy = up ? delta_y_above : delta_y_below;
     // (r0 * delta_layer + r1 * delta_other + float(c)) [* scale + offset]: one expression each in the reference
-    double xe = fp.add(fp.add(fp.mul(r0, delta_x_layer), fp.mul(r1, ox)), (float)px);
-    double ye = fp.add(fp.add(fp.mul(r0, delta_y_layer), fp.mul(r1, oy)), (float)py);
+    typename FP::R xe = fp.add(fp.add(fp.mul(r0, delta_x_layer), fp.mul(r1, ox)), (float)px);
+    typename FP::R ye = fp.add(fp.add(fp.mul(r0, delta_y_layer), fp.mul(r1, oy)), (float)py);
     if (up || layer != 0) {  // layer 0 interpolating towards the guessed layer below stays in image coordinates (:1031-1032)
         xe = fp.add(fp.mul(xe, L.scale), L.offset);
         ye = fp.add(fp.mul(ye, L.scale), L.offset);
@@ -1051,10 +1054,10 @@ constexpr uint8_t kEmit = 1, kReached = 2;
 // Refinement of candidate i.  It reads nothing but the dense score maps, so it does not depend on whether the
 // candidate's tie (if it has one) is already decided: SPECULATIVE runs it ahead of the decision and parks what the
 // decision will publish -- result, "reached its patch", and the cells it asked for in the layer above.
-template <bool SPECULATIVE>
+template <bool SPECULATIVE, class FP>
 __device__ __forceinline__ void finish_candidate(const DetArgs &a, const PairView &v, uint8_t *lds_cells, int p, int i, int layer, int x, int y)
 {
-    const Refined r = refine_maximum(v, lds_cells, layer, x, y, a.threshold);
+    const Refined r = refine_maximum<FP>(v, lds_cells, layer, x, y, a.threshold);
     const int64_t ci = (int64_t)p * a.cand_cap + i;
     a.cand_res[ci] = r.r;
     if (r.escaped) atomicOr(a.status_word, 16);
@@ -1074,6 +1077,7 @@ __device__ __forceinline__ void finish_candidate(const DetArgs &a, const PairVie
 // maxima without ties: independent of everything else; ties: refined ahead of their decision
 constexpr int kRefineChunk = 512;  // candidates per workgroup
 
+template <bool X87>
 __global__ __launch_bounds__(kDetThreads) void det_refine_kernel(DetArgs a)
 {
     __shared__ __attribute__((aligned(4))) uint8_t windows[kDetThreads * kWinStride];
@@ -1106,9 +1110,9 @@ __global__ __launch_bounds__(kDetThreads) void det_refine_kernel(DetArgs a)
         const uint32_t xy = a.cand_xy[ci];
         const int layer = layer_of(ls, a.dg->n_layers, i), x = (int)(xy & 0xffff), y = (int)(xy >> 16);
         if (a.cand_flag[ci] == kDetMax)
-            finish_candidate<false>(a, v, windows + threadIdx.x * kWinStride, p, i, layer, x, y);
+            finish_candidate<false, Fp<X87>>(a, v, windows + threadIdx.x * kWinStride, p, i, layer, x, y);
         else
-            finish_candidate<true>(a, v, windows + threadIdx.x * kWinStride, p, i, layer, x, y);
+            finish_candidate<true, Fp<X87>>(a, v, windows + threadIdx.x * kWinStride, p, i, layer, x, y);
     }
 }
 
@@ -1464,7 +1468,10 @@ int launch_det_keypoints(const DetArgs &a, int64_t *running, void *stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(det_scan_kernel, dim3(a.n_pairs), dim3(kDetThreads), 0, s, a);
     hipLaunchKernelGGL(det_candidates_kernel, dim3((a.g.total_rows + 3) / 4, a.n_pairs), dim3(kDetThreads), 0, s, a);
-    hipLaunchKernelGGL(det_refine_kernel, dim3((a.cand_cap + kRefineChunk - 1) / kRefineChunk, a.n_pairs), dim3(kDetThreads), 0, s, a);
+    if (a.fp_x87)
+        hipLaunchKernelGGL(det_refine_kernel<true>, dim3((a.cand_cap + kRefineChunk - 1) / kRefineChunk, a.n_pairs), dim3(kDetThreads), 0, s, a);
+    else
+        hipLaunchKernelGGL(det_refine_kernel<false>, dim3((a.cand_cap + kRefineChunk - 1) / kRefineChunk, a.n_pairs), dim3(kDetThreads), 0, s, a);
     // ties: layer by layer (a layer's ties read what the maxima of the layer below asked for in it)
     for (int l = 0; l < a.g.n_layers; ++l) {
         int32_t *waiting = a.tie_waiting + (int64_t)l * a.n_pairs;
