@@ -289,7 +289,9 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
        over RCCL when on_device, then ONE device-to-host copy on the root;
     4. rank 0 writes <out_dir>/<name>.mofreak for every video, rows in (video, frame, keypoint) order -- the bytes a
        1-rank run writes (out_dir None: nothing is written, the gathered rows are still returned on rank 0).
-    Returns timings and, on rank 0, `rows_per_video`.
+    Returns timings and, on rank 0, `rows_per_video` -- views into a page-locked buffer that belongs to `mofreak` and is
+    reused by its next run_dataset call: copy what has to outlive that (keep_rows=False: no rows are brought to the host
+    at all, only the counts).
     """
     import time
 
