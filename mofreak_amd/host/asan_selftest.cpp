@@ -97,6 +97,30 @@ int main()
     mofreak_keypoint kp{4.0f, 4.0f, 7.0f};
     CHECK(mofreak_extract_pairs(ctx, frame, frame, 8, 8, 8, 64, 1, &kp, nullptr, 1, desc, valid, MOFREAK_MEM_HOST) == MOFREAK_ERR_NO_DEVICE);
     CHECK(std::strlen(mofreak_last_error(ctx)) > 0);
+    // the many-clips call: argument checks first, then the same refusal; the clip table is only read, the offsets zeroed
+    {
+        const uint8_t *clips[3] = {frame, nullptr, frame};
+        const int32_t lens[3] = {1, 0, 1};
+        int64_t offs[4] = {7, 7, 7, 7}, n_rows = 7;
+        mofreak_row row;
+        CHECK(mofreak_extract_clips(ctx, clips, lens, -1, 8, 8, 0, &kp, 1, &row, 1, offs, &n_rows, 0) == MOFREAK_ERR_BAD_ARG);
+        CHECK(mofreak_extract_clips(ctx, nullptr, lens, 3, 8, 8, 0, &kp, 1, &row, 1, offs, &n_rows, 0) == MOFREAK_ERR_BAD_ARG);
+        CHECK(mofreak_extract_clips(ctx, clips, lens, 3, 8, 8, 0, &kp, 1, nullptr, 1, offs, &n_rows, 0) == MOFREAK_ERR_BAD_ARG);
+        CHECK(mofreak_extract_clips(ctx, clips, lens, 0, 8, 8, 0, &kp, 1, &row, 1, offs, &n_rows, 0) == MOFREAK_OK && n_rows == 0);
+        CHECK(mofreak_extract_clips(ctx, clips, lens, 3, 8, 8, 0, &kp, 1, &row, 1, offs, &n_rows, 0) == MOFREAK_ERR_NO_DEVICE);
+        CHECK(mofreak_extract_stream_pipelined(ctx, frame, 1, 8, 8, 0, &kp, 1, &row, 1, &n_rows) == MOFREAK_OK && n_rows == 0);  // T <= gap: no rows, no device needed
+        CHECK(mofreak_set_loop_pipelining(ctx, 0) == MOFREAK_OK && mofreak_set_loop_pipelining(nullptr, 1) == MOFREAK_ERR_BAD_ARG);
+        uint16_t pos[320];
+        int32_t n_pos = 0;
+        for (int L = 1; L <= 16; ++L) CHECK(mofreak_table_mip_positions(ctx, L, pos, &n_pos) == MOFREAK_OK && n_pos == 300);
+        CHECK(mofreak_table_mip_positions(ctx, 17, pos, &n_pos) == MOFREAK_ERR_BAD_ARG);
+        p.brisk_fp_model = 2;
+        mofreak_ctx *bad = nullptr;
+        CHECK(mofreak_create(MOFREAK_TABLES_ONLY, &p, &bad) == MOFREAK_ERR_BAD_ARG && bad == nullptr);
+        p.brisk_fp_model = MOFREAK_FP_SSE;
+        CHECK(mofreak_create(MOFREAK_TABLES_ONLY, &p, &bad) == MOFREAK_OK && bad);
+        mofreak_destroy(bad);
+    }
     mofreak_destroy(ctx);
     // the facade's file format code (the reader reverses, like the reference's)
     {
