@@ -628,6 +628,14 @@ int mofreak_create(int device_id, const mofreak_params *params, mofreak_ctx **ou
     st.scale_normalized = p.freak_scale_normalized != 0;
     st.bit_mode = p.freak_bit_mode;
     st.mip_theta = p.mip_theta;
+    if (t.mip_need_cur.size() > 64 || t.mip_need_prev.size() > 256) {
+        mofreak_destroy(ctx);
+        return fail(nullptr, MOFREAK_ERR_UNSUPPORTED, "MIP position lists larger than the device tables");
+    }
+    st.mip_n_cur = (int32_t)t.mip_need_cur.size();
+    st.mip_n_prev = (int32_t)t.mip_need_prev.size();
+    for (size_t i = 0; i < 64; ++i) st.mip_cur[i] = t.mip_need_cur[std::min(i, t.mip_need_cur.size() - 1)];
+    for (size_t i = 0; i < 256; ++i) st.mip_prev[i] = t.mip_need_prev[std::min(i, t.mip_need_prev.size() - 1)];
     CREATE_TRY(hipMemcpy(ctx->d_lut, t.lut.data(), t.lut.size() * sizeof(PatternPoint), hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(ctx->d_resize, t.resize.data(), t.resize.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(ctx->d_small, &st, sizeof(st), hipMemcpyHostToDevice));

@@ -20,7 +20,11 @@ struct SmallTables {
     int32_t scale_normalized;
     int32_t bit_mode;
     int32_t mip_theta;
-    int32_t pad[3];
+    int32_t mip_n_cur, mip_n_prev;  // entries of the two lists below
+    int32_t pad[1];
+    // the 19x19 positions the MIP reads of the current / previous buffer (ascending): the gather path resamples only these
+    uint16_t mip_cur[64];
+    uint16_t mip_prev[256];
 };
 
 // Integral image of one chunk of pairs, as the kernels lay it out in HBM:

@@ -404,38 +404,45 @@ __global__ __launch_bounds__(256, 4) void describe_kernel(DescribeArgs a)
             // load that would run past the end of its frame row starts up to 3 bytes early instead and is shifted.
             if (lane < 2 * kPatch) ws.taps[lane / kPatch][lane % kPatch] = my_tap;
             wave_lds_sync();
-            constexpr int kMipPasses = (kPatch * kPatch + 63) / 64, kMipHalf = 3;  // output pixels per lane whose loads are in flight together
+            // Only the positions motionInterchangePattern reads are resampled (51 of the current buffer, 225 of the previous
+            // one: st.mip_cur / st.mip_prev): 10 loads per lane instead of 24.  A dump of the whole buffers (out_roi19,
+            // component tests) takes all 361 positions of both.
+            auto resample = [&](const uint8_t *frame, uint8_t *dst, const uint16_t *list, int n, int passes) {
+                constexpr int kInFlight = 2;  // output pixels per lane whose loads are in flight together
+                for (int h = 0; h < passes; h += kInFlight) {
+                    uint32_t q0[kInFlight], q1[kInFlight];
+                    int pos[kInFlight];
 #pragma unroll
-            for (int h = 0; h < kMipPasses; h += kMipHalf) {
-            uint32_t qc0[kMipHalf], qc1[kMipHalf], qp0[kMipHalf], qp1[kMipHalf];
+                    for (int u = 0; u < kInFlight; ++u) {
+                        const int j = lane + 64 * (h + u);
+                        const int o = list ? (int)list[min(j, n - 1)] : min(j, n - 1);
+                        pos[u] = j < n ? o : -1;
+                        const int dy = o / kPatch, dx = o - dy * kPatch;
+                        const ResizeTap tx = ws.taps[0][dx], ty = ws.taps[1][dy];
+                        const int col = tl_x + tx.ofs, xs = min(col, W - 4);
+                        const int64_t r0 = (int64_t)(tl_y + ty.ofs) * a.f.row_stride + xs, r1 = (int64_t)(tl_y + ty.ofs1) * a.f.row_stride + xs;
+                        __builtin_memcpy(&q0[u], frame + r0, 4);
+                        __builtin_memcpy(&q1[u], frame + r1, 4);
+                    }
 #pragma unroll
-            for (int u = 0; u < kMipHalf; ++u) {
-                const int o = min(lane + 64 * (h + u), kPatch * kPatch - 1);
-                const int dy = o / kPatch, dx = o - dy * kPatch;
-                const ResizeTap tx = ws.taps[0][dx], ty = ws.taps[1][dy];
-                const int col = tl_x + tx.ofs, xs = min(col, W - 4);
-                const int64_t r0 = (int64_t)(tl_y + ty.ofs) * a.f.row_stride + xs, r1 = (int64_t)(tl_y + ty.ofs1) * a.f.row_stride + xs;
-                __builtin_memcpy(&qc0[u], cur + r0, 4);
-                __builtin_memcpy(&qc1[u], cur + r1, 4);
-                __builtin_memcpy(&qp0[u], prev + r0, 4);
-                __builtin_memcpy(&qp1[u], prev + r1, 4);
-            }
-#pragma unroll
-            for (int u = 0; u < kMipHalf; ++u) {
-                const int o = lane + 64 * (h + u);
-                const int oc_ = min(o, kPatch * kPatch - 1);
-                const int dy = oc_ / kPatch, dx = oc_ - dy * kPatch;
-                const ResizeTap tx = ws.taps[0][dx], ty = ws.taps[1][dy];
-                const int col = tl_x + tx.ofs;
-                const int sh0 = 8 * (col - min(col, W - 4)), sh1 = sh0 + 8 * (tx.ofs1 - tx.ofs);
-                auto px = [&](uint32_t q0, uint32_t q1) {
-                    return resize_px((int)((q0 >> sh0) & 0xff), (int)((q0 >> sh1) & 0xff), (int)((q1 >> sh0) & 0xff), (int)((q1 >> sh1) & 0xff), tx, ty);
-                };
-                if (o < kPatch * kPatch) {
-                    ws.p19[0][o] = px(qc0[u], qc1[u]);
-                    ws.p19[1][o] = px(qp0[u], qp1[u]);
+                    for (int u = 0; u < kInFlight; ++u) {
+                        const int o = max(pos[u], 0);
+                        const int dy = o / kPatch, dx = o - dy * kPatch;
+                        const ResizeTap tx = ws.taps[0][dx], ty = ws.taps[1][dy];
+                        const int col = tl_x + tx.ofs;
+                        const int sh0 = 8 * (col - min(col, W - 4)), sh1 = sh0 + 8 * (tx.ofs1 - tx.ofs);
+                        const uint8_t px = resize_px((int)((q0[u] >> sh0) & 0xff), (int)((q0[u] >> sh1) & 0xff), (int)((q1[u] >> sh0) & 0xff),
+                                                     (int)((q1[u] >> sh1) & 0xff), tx, ty);
+                        if (pos[u] >= 0) dst[o] = px;
+                    }
                 }
-            }
+            };
+            if (a.out_roi19 == nullptr) {
+                resample(prev, ws.p19[1], st.mip_prev, st.mip_n_prev, (st.mip_n_prev + 63) / 64);
+                resample(cur, ws.p19[0], st.mip_cur, st.mip_n_cur, (st.mip_n_cur + 63) / 64);
+            } else {
+                resample(prev, ws.p19[1], nullptr, kPatch * kPatch, (kPatch * kPatch + 63) / 64);
+                resample(cur, ws.p19[0], nullptr, kPatch * kPatch, (kPatch * kPatch + 63) / 64);
             }
             wave_lds_sync();
             mot = mip_bits(ws.p19[0], ws.p19[1], st.mip_theta);

@@ -347,6 +347,12 @@ void build_tables(const FreakParams &p, Tables &t)
                 for (int k = 0; k < 9; ++k) need_prev[bp + k] = 1;
             }
         }
+        t.mip_need_cur.clear();
+        t.mip_need_prev.clear();
+        for (int i = 0; i < kPatch * kPatch; ++i) {
+            if (need_cur[i]) t.mip_need_cur.push_back(static_cast<uint16_t>(i));
+            if (need_prev[i]) t.mip_need_prev.push_back(static_cast<uint16_t>(i));
+        }
         // Sample order for the tile kernel: the needed bytes are covered by aligned dwords of the (cur19 | prev19)
         // buffer pair; the first 64 dwords go one per lane with byte u in pass u (so that a lane packs its four
         // results into one 32-bit store), the remaining dwords byte by byte in the last pass.  Bytes of a covering

@@ -114,6 +114,9 @@ struct Tables {
     // angle = (float)(a * (180.0/CV_PI)); thetaIdx = int(256*angle*(1/360.0)+0.5)
     std::vector<ThetaBound> theta_bounds;
     std::vector<uint16_t> mip_pos;
+    // The 19x19 positions (row * 19 + col) motionInterchangePattern reads of the current / the previous buffer at the 8
+    // patch centres, ascending: what the gather path resamples (51 and 225 of the 361 positions).
+    std::vector<uint16_t> mip_need_cur, mip_need_prev;
     int mip_n_cur = 0, mip_n = 0, mip_stride = 0;  // mip_stride: entries per L in mip_samples (mip_n rounded up to 64)
     std::vector<MipSample> mip_samples;
 };
