@@ -5,6 +5,7 @@ Layout:
   api.py     ctypes binding of that C ABI (numpy / torch buffers in, no compute of its own)
   host/      C++ MoFREAKUtilities facade with the reference's class interface, over the C ABI
   harness.py the Python mirror of MoFREAKUtilities / computeMoFREAKFiles + multi-GPU sharding
+  launch.py  one process per GPU from a parent that makes no GPU call (what `bench.py --gpus N` uses)
   synth.py   deterministic synthetic frame stacks and keypoint grids
   build.py   in-tree hipcc build
 
