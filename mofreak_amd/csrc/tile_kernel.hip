@@ -25,6 +25,8 @@
 // HBM traffic is the two frames (halo re-reads are served by L2 / Infinity Cache) + keypoints in + descriptors out.
 // Keypoints whose FREAK pattern does not fit the 48-px halo (patternSizes[scale] > 48, i.e. size >= ~14.9) or whose
 // ROI side exceeds 16 are left to the gather path (describe_kernel over a global integral) by the binning pass.
+#include <type_traits>
+
 #include "device_helpers.h"
 
 namespace mofreak {
@@ -59,8 +61,8 @@ constexpr int kScratchBytes = kTileWaves * kP19Wave;           // stage 1: 19x19
 constexpr int kOffTheta = kOffScratch + kScratchBytes;
 constexpr int kOffKf = kOffTheta + kThetaBounds * (int)sizeof(ThetaBound);   // the batch's keypoint records
 constexpr int kOffMot = kOffKf + kBatch * 16;                                // motion bytes kept for the fused store
-constexpr int kOffKint = kOffMot + kBatch * 8;                               // keypoints at integer coordinates: their corner in the integral
-constexpr int kOffDirs = kOffKint + kBatch * 4;                              // orientation sums, until a wave turns its keypoints' into thetas
+constexpr int kOffKint = kOffMot + kBatch * 8;                               // per keypoint: its corner in the integral (integer coordinates), its block of the pattern tables
+constexpr int kOffDirs = kOffKint + kBatch * 8;                              // orientation sums, until a wave turns its keypoints' into thetas
 constexpr int kOffStamps = kOffDirs + kBatch * 8;                            // diagnostic build only: 32 x u64
 constexpr int kTileLdsBytes = kOffStamps + 256;
 static_assert(kP19Wave % 16 == 0 && kOffScratch % 16 == 0 && kOffTheta % 16 == 0, "LDS carve alignment");
@@ -78,7 +80,7 @@ struct KpRec {   // per-keypoint record of a batch
     float kx, ky;
     int32_t g;
     uint16_t pk;    // FREAK scale index | ROI side << 6 | ROI half << 11 (MoFREAKUtilities.cpp:293-295)
-    int16_t theta;  // written by the orientation pass
+    int16_t unused;
 };
 static_assert(sizeof(KpRec) == 16, "record size used by the LDS carve");
 
@@ -567,13 +569,15 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     const SortedKp *tile_kps = a.sorted_kp + kp_begin;
     const SmallTables *st = a.small;
     const int bit_mode = st->bit_mode, mip_theta = st->mip_theta;
+    const int bit_ge = bit_mode == MOFREAK_BITS_SSE ? 1 : 0;
+    const int bit_flip = bit_mode == MOFREAK_BITS_SSE || bit_mode == MOFREAK_BITS_NATURAL ? 0 : 0x80;
     const bool orientation_normalized = st->orientation_normalized != 0;
 
     ThetaBound *s_theta = reinterpret_cast<ThetaBound *>(lds + kOffTheta);
 
     uint2 *s_mot = reinterpret_cast<uint2 *>(lds + kOffMot);
     KpRec *kf = reinterpret_cast<KpRec *>(lds + kOffKf);
-    uint32_t *kint = reinterpret_cast<uint32_t *>(lds + kOffKint);
+    uint2 *kint = reinterpret_cast<uint2 *>(lds + kOffKint);
     int2 *s_dirs = reinterpret_cast<int2 *>(lds + kOffDirs);
     uint32_t *s_roi = reinterpret_cast<uint32_t *>(lds + kOffDirs);  // stage 1 only: where a keypoint's ROI starts in the staged rows
     const bool one_batch = n_tile_kp <= kBatch;
@@ -589,12 +593,15 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             k.ky = kp.y;
             k.g = kp.g;
             k.pk = (uint16_t)((kp.packed >> 16) | (kp.packed & 0xff) << 6 | ((kp.packed >> 8) & 0xff) << 11);
-            k.theta = 0;
+            k.unused = 0;
             kf[tid] = k;
             // a keypoint at integer coordinates: LDS address of its own corner (ky, kx) in the integral; else the top bit
             const int xi = (int)kp.x, yi = (int)kp.y;
             const bool integral = (float)xi == kp.x && (float)yi == kp.y;
-            kint[tid] = integral ? lds0 + kOffIntegral + 2 * (kIColOff + (yi - oy) * kIPitch + (xi - ox)) : 0x80000000u;
+            // .y: byte offset of the keypoint's 43 un-rotated points in the pattern tables (16-byte entries); the orientation
+            // pass replaces it by the offset of the rotated ones
+            kint[tid] = make_uint2(integral ? lds0 + kOffIntegral + 2 * (kIColOff + (yi - oy) * kIPitch + (xi - ox)) : 0x80000000u,
+                                   (kp.packed >> 16) * (uint32_t)(kNbOrientation * kNbPoints * 16));
             // the ROI's first byte in the staged rows (:293-295, :460 float -> int parameters)
             const int half = (int)((kp.packed >> 8) & 0xff);
             s_roi[tid] = (uint32_t)((yi - half - oy + 1) * kTileStagePitch + (xi - half - ox));
@@ -940,13 +947,13 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
 #pragma unroll
         for (int u = 0; u < kBoxIters; ++u) {
             rec_full[u] = lds0 + kOffKf + task_kq[u] * 16;
-            kint_full[u] = lds0 + kOffKint + task_kq[u] * 4;
+            kint_full[u] = lds0 + kOffKint + task_kq[u] * 8;
             vdst_full[u] = vv + task_kq[u] * kVStride + task_p[u];
         }
         struct Task {       // one box-mean task of a group
             uint32_t c0, c1;    // (kx, ky) as bits -- or, when every keypoint of the batch has integer coordinates, the LDS
                                 // addresses of its corner in the integral and of its record
-            uint32_t pk_theta;  // scale index | ROI bits << 6 | theta << 16
+            uint32_t tab;       // byte offset of the keypoint's 43 points (un-rotated in pass A, rotated in pass B) in the tables
             uint32_t vdst;      // where the box mean goes
         };
         const float box_margin = a.box_margin;
@@ -966,169 +973,172 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                 const int k1 = min(lane, nb - 1), k2 = min(lane + 64, nb - 1);
                 const uint32_t s0 = kf[0].pk & 63;
                 one_scale = __all((kf[k1].pk & 63) == s0 && (kf[k2].pk & 63) == s0);
-                all_int = __all((int)(kint[k1] | kint[k2]) >= 0) && box_margin < 1.0f;
+                all_int = __all((int)(kint[k1].x | kint[k2].x) >= 0) && box_margin < 1.0f;
             }
-            // a group's last keypoints may be missing: their tasks redo the group's last real keypoint
-            auto group_tasks = [&](int kbase, Task (&t)[kBoxIters]) {
-                const int last = min(kGroup, nb - kbase) - 1;
+            // The rest of the batch is compiled twice, for keypoints at integer coordinates and for the general case: the
+            // choice is made once per batch here instead of once per box inside the loops.
+            auto run_batch = [&](auto int_tag) {
+                constexpr bool kAllInt = decltype(int_tag)::value;
+                // a group's last keypoints may be missing: their tasks redo the group's last real keypoint
+                auto group_tasks = [&](int kbase, Task (&t)[kBoxIters]) {
+                    const int last = min(kGroup, nb - kbase) - 1;
 #pragma unroll
-                for (int u = 0; u < kBoxIters; ++u) {
-                    uint32_t ra = rec_full[u] + kbase * 16, ka = kint_full[u] + kbase * 4;
-                    t[u].vdst = vdst_full[u];
-                    if (last != kGroup - 1) {  // (wave-uniform)
-                        const int kq = min(task_kq[u], last);
-                        ra = lds0 + kOffKf + (kbase + kq) * 16;
-                        ka = lds0 + kOffKint + (kbase + kq) * 4;
-                        t[u].vdst = vv + kq * kVStride + task_p[u];
+                    for (int u = 0; u < kBoxIters; ++u) {
+                        uint32_t ra = rec_full[u] + kbase * 16, ka = kint_full[u] + kbase * 8;
+                        t[u].vdst = vdst_full[u];
+                        if (last != kGroup - 1) {  // (wave-uniform)
+                            const int kq = min(task_kq[u], last);
+                            ra = lds0 + kOffKf + (kbase + kq) * 16;
+                            ka = lds0 + kOffKint + (kbase + kq) * 8;
+                            t[u].vdst = vv + kq * kVStride + task_p[u];
+                        }
+                        if (kAllInt) {
+                            const LdsU2 ct = lds_ld<LdsU2>(ka);
+                            t[u].c0 = ct.x;
+                            t[u].c1 = ra;
+                            t[u].tab = ct.y;
+                        } else {
+                            const LdsU2 xy = lds_ld<LdsU2>(ra);
+                            t[u].c0 = xy.x;
+                            t[u].c1 = xy.y;
+                            t[u].tab = lds_ld<uint32_t>(ka + 4);
+                        }
                     }
-                    t[u].pk_theta = lds_ld<uint32_t>(ra + 12);
-                    if (all_int) {
-                        t[u].c0 = lds_ld<uint32_t>(ka);
-                        t[u].c1 = ra;
-                    } else {
-                        const LdsU2 xy = lds_ld<LdsU2>(ra);
-                        t[u].c0 = xy.x;
-                        t[u].c1 = xy.y;
+                };
+                // entry: the task's BoxInt (kAllInt) or PatternPoint, as loaded; e: its byte offset in the tables
+                auto box = [&](const Task t, const LdsU4 entry, uint32_t e) -> int {
+                    if (kAllInt) {
+                        const BoxInt B = __builtin_bit_cast(BoxInt, entry);
+                        if (B.margin > box_margin) return mean_intensity_int(t.c0, B);
+                        // a corner too close to a rounding boundary (rare): the float expressions
+                        return mean_intensity_tile(ibase, lds_ld<float>(t.c1), lds_ld<float>(t.c1 + 4), *reinterpret_cast<const PatternPoint *>(reinterpret_cast<const uint8_t *>(a.lut) + e));
                     }
-                }
-            };
-            // entry: the task's BoxInt (all_int) or PatternPoint, as loaded; e: its index in the tables
-            auto box = [&](const Task t, const LdsU4 entry, uint32_t e) -> int {
-                if (all_int) {
-                    const BoxInt B = __builtin_bit_cast(BoxInt, entry);
-                    if (B.margin > box_margin) return mean_intensity_int(t.c0, B);
-                    // a corner too close to a rounding boundary (rare): the float expressions
-                    return mean_intensity_tile(ibase, lds_ld<float>(t.c1), lds_ld<float>(t.c1 + 4), a.lut[e]);
-                }
-                return mean_intensity_tile(ibase, __builtin_bit_cast(float, t.c0), __builtin_bit_cast(float, t.c1), __builtin_bit_cast(PatternPoint, entry));
-            };
-            // both tables have 16-byte entries with the same indexing: one (wave-uniform) base, 32-bit byte offsets
-            const uint8_t *table = all_int ? reinterpret_cast<const uint8_t *>(a.lut_int) : reinterpret_cast<const uint8_t *>(a.lut);
-            auto load_entry = [&](uint32_t e) -> LdsU4 { return *reinterpret_cast<const LdsU4 *>(table + (e << 4)); };
+                    return mean_intensity_tile(ibase, __builtin_bit_cast(float, t.c0), __builtin_bit_cast(float, t.c1), __builtin_bit_cast(PatternPoint, entry));
+                };
+                // both tables have 16-byte entries with the same indexing: one (wave-uniform) base, 32-bit byte offsets
+                const uint8_t *table = kAllInt ? reinterpret_cast<const uint8_t *>(a.lut_int) : reinterpret_cast<const uint8_t *>(a.lut);
+                auto load_entry = [&](uint32_t e) -> LdsU4 { return *reinterpret_cast<const LdsU4 *>(table + e); };
+                auto entry_of = [&](const Task t, int u) -> uint32_t { return t.tab + task_p[u] * 16; };
 
-            // ---- pass A over the wave's groups: un-rotated box means, orientation sums, theta -> the records
-            if (orientation_normalized) {
-                LdsU4 E0[kBoxIters];   // the lane's un-rotated entries, kept across groups of one scale
-                int have_idx = -1;
-                if (one_scale) {
-                    have_idx = kf[0].pk & 63;
+                // ---- pass A over the wave's groups: un-rotated box means, orientation sums, theta -> the records
+                if (orientation_normalized) {
+                    LdsU4 E0[kBoxIters];   // the lane's un-rotated entries, kept across groups of one scale
+                    uint32_t have_tab = ~0u;
+                    if (one_scale) {
+                        have_tab = (kf[0].pk & 63) * (uint32_t)(kNbOrientation * kNbPoints * 16);
 #pragma unroll
-                    for (int u = 0; u < kBoxIters; ++u) E0[u] = load_entry((uint32_t)have_idx * (kNbOrientation * kNbPoints) + task_p[u]);
+                        for (int u = 0; u < kBoxIters; ++u) E0[u] = load_entry(have_tab + task_p[u] * 16);
+                    }
+                    for (int kbase = wave * kGroup; kbase < nb; kbase += kGroup * kTileWaves) {
+                        const int last = min(kGroup, nb - kbase) - 1;
+                        Task t[kBoxIters];
+                        group_tasks(kbase, t);
+                        if (!one_scale) {
+#pragma unroll
+                            for (int u = 0; u < kBoxIters; ++u)
+                                if (t[u].tab != have_tab) E0[u] = load_entry(entry_of(t[u], u));
+                            have_tab = t[1].tab == t[0].tab && t[kBoxIters - 1].tab == t[0].tab ? t[0].tab : ~0u;
+                        }
+#pragma unroll
+                        for (int u = 0; u < kBoxIters; ++u)
+                            lds_st<uint8_t>(t[u].vdst, (uint8_t)box(t[u], E0[u], entry_of(t[u], u)));
+                        wave_lds_sync();
+                        int direction0 = 0, direction1 = 0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const float delta = (float)((int)lds_ld<uint8_t>(opi[k]) - (int)lds_ld<uint8_t>(opj[k]));
+                            direction0 += (int)(delta * owx[k]);  // C division by 2048: truncates toward zero, per term
+                            direction1 += (int)(delta * owy[k]);
+                        }
+                        direction0 = row16_sum(direction0);
+                        direction1 = row16_sum(direction1);
+                        if (osub == 0 && oq <= last) s_dirs[kbase + oq] = make_int2(direction0, direction1);
+                        wave_lds_sync();  // the next group overwrites the box means
+                    }
+                    TILE_STAMP(5);
+                    // thetas of all the wave's keypoints in one go: lane = keypoint (group lane / 4, slot lane % 4)
+                    {
+                        const int kp = (wave + kTileWaves * (lane >> 2)) * kGroup + (lane & 3);
+                        if (kp < nb) {
+                            const int2 d = s_dirs[kp];
+                            const int theta = theta_index(s_theta, d.x, d.y);
+                            kint[kp].y = (((kf[kp].pk & 63) * kNbOrientation + theta) * kNbPoints) * 16u;
+                            if (a.out_info)
+                                *reinterpret_cast<int4 *>(a.out_info + (out_base + kf[kp].g) * 4) = make_int4(kf[kp].pk & 63, theta, d.x, d.y);
+                        }
+                        wave_lds_sync();  // pass B reads the thetas
+                    }
+                    TILE_STAMP(6);
+                } else if (a.out_info) {
+                    for (int kbase = wave * kGroup; kbase < nb; kbase += kGroup * kTileWaves)
+                        if (lane < min(kGroup, nb - kbase))
+                            *reinterpret_cast<int4 *>(a.out_info + (out_base + kf[kbase + lane].g) * 4) = make_int4(kf[kbase + lane].pk & 63, 0, 0, 0);
+                }
+                // ---- pass B: box means of the rotated pattern, bits, store.  The pattern points (or boxes) of the next
+                //      group are fetched (L2) while the current group's boxes are summed.
+                LdsU4 ec[kBoxIters];
+                Task tc[kBoxIters];
+                if (wave * kGroup < nb) {
+                    group_tasks(wave * kGroup, tc);
+#pragma unroll
+                    for (int u = 0; u < kBoxIters; ++u) ec[u] = load_entry(entry_of(tc[u], u));
                 }
                 for (int kbase = wave * kGroup; kbase < nb; kbase += kGroup * kTileWaves) {
                     const int last = min(kGroup, nb - kbase) - 1;
-                    Task t[kBoxIters];
-                    group_tasks(kbase, t);
-                    if (!one_scale) {
+                    const int knext = kbase + kGroup * kTileWaves;
+                    LdsU4 en[kBoxIters];
+                    Task tn[kBoxIters];
+                    group_tasks(knext < nb ? knext : kbase, tn);
 #pragma unroll
-                        for (int u = 0; u < kBoxIters; ++u)
-                            if ((int)(t[u].pk_theta & 63) != have_idx) E0[u] = load_entry((t[u].pk_theta & 63) * (kNbOrientation * kNbPoints) + task_p[u]);
-                        const int s0 = t[0].pk_theta & 63;
-                        have_idx = (int)(t[1].pk_theta & 63) == s0 && (int)(t[kBoxIters - 1].pk_theta & 63) == s0 ? s0 : -1;
-                    }
+                    for (int u = 0; u < kBoxIters; ++u) en[u] = load_entry(entry_of(tn[u], u));
 #pragma unroll
-                    for (int u = 0; u < kBoxIters; ++u)
-                        lds_st<uint8_t>(t[u].vdst, (uint8_t)box(t[u], E0[u], (t[u].pk_theta & 63) * (kNbOrientation * kNbPoints) + task_p[u]));
+                    for (int u = 0; u < kBoxIters; ++u) lds_st<uint8_t>(tc[u].vdst, (uint8_t)box(tc[u], ec[u], entry_of(tc[u], u)));
                     wave_lds_sync();
-                    int direction0 = 0, direction1 = 0;
+                    // lane = descriptor bit; lane q stores keypoint q's descriptor
+                    {
+                        int va[kGroup], vb[kGroup];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const float delta = (float)((int)lds_ld<uint8_t>(opi[k]) - (int)lds_ld<uint8_t>(opj[k]));
-                        direction0 += (int)(delta * owx[k]);  // C division by 2048: truncates toward zero, per term
-                        direction1 += (int)(delta * owy[k]);
-                    }
-                    direction0 = row16_sum(direction0);
-                    direction1 = row16_sum(direction1);
-                    if (osub == 0 && oq <= last) s_dirs[kbase + oq] = make_int2(direction0, direction1);
-                    wave_lds_sync();  // the next group overwrites the box means
-                }
-                TILE_STAMP(5);
-                // thetas of all the wave's keypoints in one go: lane = keypoint (group lane / 4, slot lane % 4)
-                {
-                    const int kp = (wave + kTileWaves * (lane >> 2)) * kGroup + (lane & 3);
-                    if (kp < nb) {
-                        const int2 d = s_dirs[kp];
-                        const int theta = theta_index(s_theta, d.x, d.y);
-                        kf[kp].theta = (int16_t)theta;
-                        if (a.out_info)
-                            *reinterpret_cast<int4 *>(a.out_info + (out_base + kf[kp].g) * 4) = make_int4(kf[kp].pk & 63, theta, d.x, d.y);
-                    }
-                    wave_lds_sync();  // pass B reads the thetas
-                }
-                TILE_STAMP(6);
-            } else if (a.out_info) {
-                for (int kbase = wave * kGroup; kbase < nb; kbase += kGroup * kTileWaves)
-                    if (lane < min(kGroup, nb - kbase))
-                        *reinterpret_cast<int4 *>(a.out_info + (out_base + kf[kbase + lane].g) * 4) = make_int4(kf[kbase + lane].pk & 63, 0, 0, 0);
-            }
-            // ---- pass B: box means of the rotated pattern, bits, store.  The pattern points (or boxes) of the next
-            //      group are fetched (L2) while the current group's boxes are summed.
-            auto rotated_index = [&](const Task t, int u) -> uint32_t {
-                return ((t.pk_theta & 63) * kNbOrientation + (t.pk_theta >> 16)) * kNbPoints + task_p[u];
-            };
-            LdsU4 ec[kBoxIters];
-            Task tc[kBoxIters];
-            if (wave * kGroup < nb) {
-                group_tasks(wave * kGroup, tc);
+                        for (int qq = 0; qq < kGroup; ++qq) {
+                            va[qq] = lds_ld<uint8_t>(pi + qq * kVStride);
+                            vb[qq] = lds_ld<uint8_t>(pj + qq * kVStride);
+                        }
+                        // one comparison for the three bit modes: signed chars compare like their values with the top bit
+                        // flipped (bit_flip = 0x80), and a >= b is a + 1 > b (bit_ge = 1)
+                        uint2 app = make_uint2(0, 0);
 #pragma unroll
-                for (int u = 0; u < kBoxIters; ++u) ec[u] = load_entry(rotated_index(tc[u], u));
-            }
-            for (int kbase = wave * kGroup; kbase < nb; kbase += kGroup * kTileWaves) {
-                const int last = min(kGroup, nb - kbase) - 1;
-                const int knext = kbase + kGroup * kTileWaves;
-                LdsU4 en[kBoxIters];
-                Task tn[kBoxIters];
-                group_tasks(knext < nb ? knext : kbase, tn);
-#pragma unroll
-                for (int u = 0; u < kBoxIters; ++u) en[u] = load_entry(rotated_index(tn[u], u));
-#pragma unroll
-                for (int u = 0; u < kBoxIters; ++u) lds_st<uint8_t>(tc[u].vdst, (uint8_t)box(tc[u], ec[u], rotated_index(tc[u], u)));
-                wave_lds_sync();
-                // lane = descriptor bit; lane q stores keypoint q's descriptor
-                {
-                    int va[kGroup], vb[kGroup];
-#pragma unroll
-                    for (int qq = 0; qq < kGroup; ++qq) {
-                        va[qq] = lds_ld<uint8_t>(pi + qq * kVStride);
-                        vb[qq] = lds_ld<uint8_t>(pj + qq * kVStride);
-                    }
-                    uint2 app = make_uint2(0, 0);
-#pragma unroll
-                    for (int qq = 0; qq < kGroup; ++qq) {
-                        bool bit;
-                        if (bit_mode == MOFREAK_BITS_SSE)
-                            bit = va[qq] >= vb[qq];
-                        else if (bit_mode == MOFREAK_BITS_NATURAL)
-                            bit = va[qq] > vb[qq];
-                        else
-                            bit = (int)(int8_t)va[qq] > (int)(int8_t)vb[qq];
-                        const uint64_t bits = __ballot(bit);
-                        if (lane == qq) app = make_uint2((uint32_t)bits, (uint32_t)(bits >> 32));
-                    }
-                    if (lane <= last) {  // descriptor and validity flag out, side by side
-                        int64_t out_idx = out_base + kf[kbase + lane].g;
+                        for (int qq = 0; qq < kGroup; ++qq) {
+                            const uint64_t bits = __ballot((va[qq] ^ bit_flip) + bit_ge > (vb[qq] ^ bit_flip));
+                            if (lane == qq) app = make_uint2((uint32_t)bits, (uint32_t)(bits >> 32));
+                        }
+                        if (lane <= last) {  // descriptor and validity flag out, side by side
+                            int64_t out_idx = out_base + kf[kbase + lane].g;
 #ifdef MOFREAK_DEBUG_BOUNDS
-                        if (out_idx < 0 || out_idx >= a.out_items) {
-                            atomicOr(&g_tile_oob, 2u);
-                            out_idx = 0;
-                        }
+                            if (out_idx < 0 || out_idx >= a.out_items) {
+                                atomicOr(&g_tile_oob, 2u);
+                                out_idx = 0;
+                            }
 #endif
-                        if (one_batch) {
-                            const uint2 mot = s_mot[kbase + lane];
-                            *reinterpret_cast<uint4 *>(a.out_desc + out_idx * 16) = make_uint4(app.x, app.y, mot.x, mot.y);
-                        } else {
-                            *reinterpret_cast<uint2 *>(a.out_desc + out_idx * 16) = app;
+                            if (one_batch) {
+                                const uint2 mot = s_mot[kbase + lane];
+                                *reinterpret_cast<uint4 *>(a.out_desc + out_idx * 16) = make_uint4(app.x, app.y, mot.x, mot.y);
+                            } else {
+                                *reinterpret_cast<uint2 *>(a.out_desc + out_idx * 16) = app;
+                            }
+                            a.out_valid[out_idx] = 1;
                         }
-                        a.out_valid[out_idx] = 1;
+                    }
+                    wave_lds_sync();  // the next group overwrites the box means
+#pragma unroll
+                    for (int u = 0; u < kBoxIters; ++u) {
+                        ec[u] = en[u];
+                        tc[u] = tn[u];
                     }
                 }
-                wave_lds_sync();  // the next group overwrites the box means
-#pragma unroll
-                for (int u = 0; u < kBoxIters; ++u) {
-                    ec[u] = en[u];
-                    tc[u] = tn[u];
-                }
-            }
+            };
+            if (all_int)
+                run_batch(std::true_type{});
+            else
+                run_batch(std::false_type{});
         }
     }
     TILE_STAMP(7);
