@@ -856,9 +856,11 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             for (int w4 = 0; w4 < 4; ++w4) {
                 const uint32_t x = w4 == 0 ? c[u].x : w4 == 1 ? c[u].y : w4 == 2 ? c[u].z : c[u].w;
                 const uint32_t y = w4 == 0 ? p[u].x : w4 == 1 ? p[u].y : w4 == 2 ? p[u].z : p[u].w;
-                const uint32_t s0 = __builtin_amdgcn_sad_u8(x & 0xffu, y & 0xffu, acc);
-                const uint32_t s1 = __builtin_amdgcn_sad_u8(x & 0xffffu, y & 0xffffu, acc);
-                const uint32_t s2 = __builtin_amdgcn_sad_u8(x & 0xffffffu, y & 0xffffffu, acc);
+                // the first one, two, three bytes: the other bytes of y replaced by x's, where they add nothing (one v_bfi
+                // per prefix instead of two masks)
+                const uint32_t s0 = __builtin_amdgcn_sad_u8(x, (y & 0xffu) | (x & ~0xffu), acc);
+                const uint32_t s1 = __builtin_amdgcn_sad_u8(x, (y & 0xffffu) | (x & ~0xffffu), acc);
+                const uint32_t s2 = __builtin_amdgcn_sad_u8(x, (y & 0xffffffu) | (x & ~0xffffffu), acc);
                 acc = __builtin_amdgcn_sad_u8(x, y, acc);
                 pk[2 * w4] = __builtin_amdgcn_perm(s1, s0, 0x05040100u);      // low halves: s0 | s1 << 16
                 pk[2 * w4 + 1] = __builtin_amdgcn_perm(acc, s2, 0x05040100u);
@@ -871,7 +873,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             const uint32_t excl = (uint32_t)incl - acc;
             const uint32_t carry2 = __builtin_amdgcn_perm(excl, excl, 0x05040504u);  // low half in both halves
             if (r < RH && q < runs) {
-                uint8_t *row = lds + kOffIntegral + (r + 1) * kTileStagePitch;
+                uint8_t *row = lds + kOffIntegral + __umul24(r + 1, kTileStagePitch);
                 uint4 *dst = reinterpret_cast<uint4 *>(row + (8 + 16 * q) * 2);
                 dst[0] = make_uint4(pk_add_u16(pk[0], carry2), pk_add_u16(pk[1], carry2), pk_add_u16(pk[2], carry2), pk_add_u16(pk[3], carry2));
                 dst[1] = make_uint4(pk_add_u16(pk[4], carry2), pk_add_u16(pk[5], carry2), pk_add_u16(pk[6], carry2), pk_add_u16(pk[7], carry2));
