@@ -172,6 +172,9 @@ int validate_frames(const mofreak_ctx *ctx, const void *cur, const void *prev, i
         return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "frame wider than the banded integral kernel supports (W <= 10232)");
     if ((int64_t)(H + 1) * integral_pitch(W) >= ((int64_t)1 << 31))
         return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "frame too large for 32-bit integral indexing");
+    // the gather path addresses a frame's bytes by 32-bit offsets built from 24-bit factors (row index x row_stride)
+    if (row_stride >= ((int64_t)1 << 23) || (int64_t)H * row_stride >= ((int64_t)1 << 31))
+        return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "row_stride >= 2^23 or a frame of 2 GiB and more");
     return MOFREAK_OK;
 }
 
@@ -269,7 +272,7 @@ int run_gather(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, const 
         a.slow_count = gate;
         a.n_pairs_total = n_pairs;
         const int64_t want = (n_items + 3) / 4;
-        const int n_blocks = (int)std::min<int64_t>(want, (int64_t)ctx->n_cus * 8);  // 8 workgroups of 4 waves: all a CU can hold at describe_kernel's register count
+        const int n_blocks = (int)std::min<int64_t>(want, (int64_t)ctx->n_cus * 5);  // 5 workgroups of 4 waves: what a CU holds at describe_kernel's register count
         const int e = launch_describe(a, n_blocks, ctx->stream);
         if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("describe launch: ") + hipGetErrorString((hipError_t)e));
     }

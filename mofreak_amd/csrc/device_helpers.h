@@ -15,6 +15,8 @@ namespace {
 
 constexpr double kCvPi = 3.1415926535897932384626433832795;
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // LDS written by some lanes of a wave and read by others of the SAME wave: DS operations of one wave execute
@@ -50,6 +52,30 @@ __device__ __forceinline__ int absdiff_u8(uint32_t a, uint32_t b, int k)
     return x > y ? x - y : y - x;
 }
 
+// (int)((double)a + 0.5) for a float 0.5 <= a < 2^22 with one float add: a + 0.5f is exact while it stays in a's
+// binade; when it crosses into the next one the sum lies in [2^k, 2^k + 0.5), so rounding it to the coarser grid cannot
+// reach another integer.  (Tile-path taps are > 1: the keypoint passed FREAK's border filter.)
+__device__ __forceinline__ int round_half_up_pos(float a) { return (int)(a + 0.5f); }
+
+// floor(v / a) for 0 <= v <= 255 * a, 0 < a <= 8192: (v + 0.5) / a lies at least 0.5 / a away from an integer, and the
+// relative error of v_rcp_f32 (1 ulp) plus one rounding of the fma is below 2^-22, i.e. below 256 * 2^-22 = 6e-5 absolute.
+__device__ __forceinline__ int div_box_small(int v, int a)
+{
+    const float r = __builtin_amdgcn_rcpf((float)a);
+    return (int)__builtin_fmaf((float)v, r, 0.5f * r);
+}
+
+// The vertical step of the 8-bit bilinear resize, ((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2, with the
+// weights pre-shifted by 12: t < 2^20 and b << 12 <= 2^23 are 24-bit operands, and the high half of their 48-bit
+// product, (t & ~15) * (b << 12) >> 32, is (b * (t >> 4)) >> 16 exactly (all factors non-negative).
+__device__ __forceinline__ int resize_y(uint32_t t0, uint32_t t1, uint32_t b0s, uint32_t b1s)
+{
+    uint32_t p0, p1;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(p0) : "v"(t0 & ~15u), "v"(b0s));
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(p1) : "v"(t1 & ~15u), "v"(b1s));
+    return (int)((p0 + p1 + 2u) >> 2);
+}
+
 // ------------------------------------------------------------------------------------------------
 // FREAK pieces
 // ------------------------------------------------------------------------------------------------
@@ -67,24 +93,28 @@ __device__ __forceinline__ int div_box(int v, int a)
     return q;
 }
 
-// FREAK::meanIntensity, box branch (radius >= 0.5; the context refuses tables with a smaller sigma).
+// FREAK::meanIntensity, box branch (radius >= 0.5; the context refuses tables with a smaller sigma), on the int32 integral
+// of one pair in HBM (`integ` is the same in every lane: the corners are 32-bit element offsets from it).
+// int(xf - radius + 0.5), int(xf + radius + 1.5): the reference adds 0.5 / 1.5 in double, i.e. exactly; the arguments are > 1
+// (the keypoint passed FREAK's border filter), so round_half_up_pos gives the same integers.
 __device__ __forceinline__ int mean_intensity(const int32_t *__restrict__ integ, int pitch, float kx, float ky,
                                               const PatternPoint P)
 {
     const float xf = P.x + kx;
     const float yf = P.y + ky;
     const float radius = P.sigma;
-    const int x_left = (int)((double)(xf - radius) + 0.5);
-    const int y_top = (int)((double)(yf - radius) + 0.5);
-    const int x_right = (int)((double)(xf + radius) + 1.5);
-    const int y_bottom = (int)((double)(yf + radius) + 1.5);
-    const int32_t *top = integ + (int64_t)y_top * pitch + kIntegralColOffset;
-    const int32_t *bot = integ + (int64_t)y_bottom * pitch + kIntegralColOffset;
-    int ret_val = bot[x_right];
-    ret_val -= bot[x_left];
-    ret_val += top[x_left];
-    ret_val -= top[x_right];
-    return div_box(ret_val, (x_right - x_left) * (y_bottom - y_top)) & 0xff;
+    const int x_left = round_half_up_pos(xf - radius);
+    const int y_top = round_half_up_pos(yf - radius);
+    const int x_right = round_half_up_pos(xf + radius) + 1;
+    const int y_bottom = round_half_up_pos(yf + radius) + 1;
+    const uint32_t top = __umul24(y_top, pitch) + kIntegralColOffset, bot = __umul24(y_bottom, pitch) + kIntegralColOffset;  // rows, pitch < 2^24
+    int ret_val = integ[bot + x_right];
+    ret_val -= integ[bot + x_left];
+    ret_val += integ[top + x_left];
+    ret_val -= integ[top + x_right];
+    const int area = (int)__umul24(x_right - x_left, y_bottom - y_top);
+    // (wave-uniform choice: the fix-up form only where some lane's box is beyond div_box_small's range)
+    return (__all(area <= 8192) ? div_box_small(ret_val, area) : div_box(ret_val, area)) & 0xff;
 }
 
 // thetaIdx from the integer direction sums (freak.cpp computeImpl):
@@ -157,6 +187,40 @@ __device__ __forceinline__ uint64_t mip_bits(const uint8_t *cur19, const uint8_t
         ssd += d * d;
     }
     return __ballot(ssd > mip_theta);
+}
+
+// The same bits from 19x19 buffers that start on a dword (the gather path's LDS scratch), per-lane constants hoisted by the
+// caller: lane = 8*centre + offset; the two 9-byte strips sit at arbitrary byte offsets, so the covering aligned dwords are
+// fetched and the strips shifted out; SSD = sum c^2 + sum p^2 - 2 sum c*p over the first eight bytes (packed u8 dot
+// products) + the ninth byte's squared difference.
+struct MipStripLane {
+    int cw, pw;  // dword index of the first covering dword in the current / previous buffer
+    int cs, ps;  // byte shifts
+};
+__device__ __forceinline__ MipStripLane mip_strip_lane()
+{
+    const int lane = lane_id();
+    const int mc = lane >> 3, mi = lane & 7;
+    const int mcx = (0xDDD99555u >> (4 * mc)) & 15, mcy = (0xD95D5D95u >> (4 * mc)) & 15;
+    const int mdx = (int)((0x14787410u >> (4 * mi)) & 15) - 4, mdy = (int)((0x10147874u >> (4 * mi)) & 15) - 4;
+    const int base_c = (mcy - 1) * kPatch + (mcx - 1), base_p = (mcy + mdy - 1) * kPatch + (mcx + mdx - 1);
+    return MipStripLane{base_c >> 2, base_p >> 2, base_c & 3, base_p & 3};
+}
+__device__ __forceinline__ uint64_t mip_bits_strips(const uint32_t *cur19, const uint32_t *prev19, const MipStripLane m, int mip_theta)
+{
+    uint32_t cd[3], pd[3];
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+        cd[w] = cur19[m.cw + w];
+        pd[w] = prev19[m.pw + w];
+    }
+    const uint32_t c0 = __builtin_amdgcn_alignbyte(cd[1], cd[0], m.cs), c1 = __builtin_amdgcn_alignbyte(cd[2], cd[1], m.cs);
+    const uint32_t p0 = __builtin_amdgcn_alignbyte(pd[1], pd[0], m.ps), p1 = __builtin_amdgcn_alignbyte(pd[2], pd[1], m.ps);
+    const int d8 = (int)((cd[2] >> (8 * m.cs)) & 0xffu) - (int)((pd[2] >> (8 * m.ps)) & 0xffu);
+    const uint32_t sq = __builtin_amdgcn_udot4(c0, c0, __builtin_amdgcn_udot4(c1, c1, (uint32_t)__mul24(d8, d8), false), false) +
+                        __builtin_amdgcn_udot4(p0, p0, __builtin_amdgcn_udot4(p1, p1, 0u, false), false);
+    const uint32_t cross = __builtin_amdgcn_udot4(c0, p0, __builtin_amdgcn_udot4(c1, p1, 0u, false), false);
+    return __ballot((int)(sq - 2u * cross) > mip_theta);
 }
 
 // One output pixel of cv::resize(8UC1 -> 19x19, INTER_LINEAR) from its four source pixels.

@@ -216,8 +216,9 @@ __global__ __launch_bounds__(256) void bgr2gray_kernel(const uint8_t *bgr, int W
 }
 
 struct WaveScratch {
-    ResizeTap taps[2][20];
-    uint8_t p19[2][kP19Pad];
+    uint2 tx[20];  // per output column: .x = ofs | ofs1 << 16, .y = c0 | c1 << 16 (the weights as v_dot2_u32_u16 takes them)
+    uint4 ty[20];  // per output row: .x = ofs | ofs1 << 16, .y = c0 << 12, .z = c1 << 12 (resize_y's pre-shifted weights)
+    uint32_t p19[2][kP19Pad / 4];
 };
 
 // The pair a keypoint belongs to: the last p in [0, n_pairs) with offsets[p] <= g (offsets ascend, offsets[0] <= g).  The
@@ -236,14 +237,18 @@ __device__ __forceinline__ int pair_of(const int64_t *offsets, int n_pairs, int6
 
 // ------------------------------------------------------------------------------------------------
 // describe_kernel: one wavefront per keypoint instance (grid-stride over the chunk's instances).
+// DUMP: also the two whole 19x19 buffers -> a.out_roi19 (component tests); the product instantiation has none of it.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4) void describe_kernel(DescribeArgs a)
+template <bool DUMP>
+__global__ __launch_bounds__(256, 5) void describe_kernel(DescribeArgs a)
 {
     __shared__ __attribute__((aligned(16))) SmallTables st;
     __shared__ __attribute__((aligned(16))) WaveScratch scratch[4];
+    __shared__ __attribute__((aligned(16))) ThetaBound s_theta[kThetaBounds];  // one memory round trip less per keypoint
 
     for (int i = threadIdx.x; i < (int)(sizeof(SmallTables) / 4); i += 256)
         reinterpret_cast<int32_t *>(&st)[i] = reinterpret_cast<const int32_t *>(a.small)[i];
+    for (int i = threadIdx.x; i < kThetaBounds; i += 256) s_theta[i] = a.theta[i];
     __syncthreads();
 
     const int lane = lane_id();
@@ -252,6 +257,20 @@ __global__ __launch_bounds__(256, 4) void describe_kernel(DescribeArgs a)
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveScratch &ws = scratch[wave_in_block];
     const int W = a.f.W, H = a.f.H;
+    // Per-lane constants of the MIP part.  Only the positions motionInterchangePattern reads are resampled (225 of the
+    // previous buffer, 51 of the current one: st.mip_prev / st.mip_cur, ascending): four passes over the first list, one
+    // over the second; a lane's position in each: column | row << 8, or -1.
+    constexpr int kPrevPasses = 4, kMipPasses = kPrevPasses + 1;  // st.mip_n_prev <= 256, st.mip_n_cur <= 64 (SmallTables)
+    int mip_at[kMipPasses];
+#pragma unroll
+    for (int u = 0; u < kMipPasses; ++u) {
+        const int j = lane + 64 * u, n = u < kPrevPasses ? st.mip_n_prev : st.mip_n_cur;
+        const int o = u < kPrevPasses ? (int)st.mip_prev[min(j, 255)] : (int)st.mip_cur[lane];
+        const int dy = (o * 27) >> 9;  // o / 19 for o < 361
+        mip_at[u] = (u < kPrevPasses ? j : lane) < n ? (o - dy * kPatch) | dy << 8 : -1;
+    }
+    const MipStripLane strips = mip_strip_lane();
+    const int stride = (int)a.f.row_stride;  // (the context takes frames of < 2^31 bytes and rows of < 2^23: 32-bit offsets, 24-bit factors)
 
     // gather path behind the tile kernel: the instances are the binning pass's slow list (device-resident count)
     const int64_t n_slow = a.slow_list ? (int64_t)*a.slow_count : 0;
@@ -361,7 +380,7 @@ __global__ __launch_bounds__(256, 4) void describe_kernel(DescribeArgs a)
         if (ok) {
             // the 19 + 19 resize taps of this ROI side: asked for now, parked in LDS when the MIP part gets to them
             ResizeTap my_tap{0, 0, 0, 0};
-            if (lane < 2 * kPatch) my_tap = a.resize[(int64_t)L * 2 * kPatch + lane];
+            if (lane < 2 * kPatch) my_tap = a.resize[L * 2 * kPatch + lane];
             // ================= FREAK on the difference image (through its integral)
             const int32_t *integ = a.integral + (int64_t)pair_local * (H + 1) * a.pitch;
             const PatternPoint *lut_scale = a.lut + (int64_t)idx * kNbOrientation * kNbPoints;
@@ -380,7 +399,7 @@ __global__ __launch_bounds__(256, 4) void describe_kernel(DescribeArgs a)
                 }
                 direction0 = wave_sum(t0);
                 direction1 = wave_sum(t1);
-                theta = theta_index(a.theta, direction0, direction1);
+                theta = theta_index(s_theta, direction0, direction1);
             }
             int v = 0;
             if (lane < kNbPoints) v = mean_intensity(integ, a.pitch, kx, ky, lut_scale[theta * kNbPoints + lane]);
@@ -400,59 +419,63 @@ __global__ __launch_bounds__(256, 4) void describe_kernel(DescribeArgs a)
             // ================= MIP on (current, previous) gray frames
             // cv::resize(ROI -> 19x19, INTER_LINEAR) of both frames straight from memory: an output pixel's two taps of a
             // row are neighbouring bytes (or the same byte at the right edge), so one unaligned 4-byte load per row and
-            // frame brings them; a lane's (up to) six output pixels ask for their loads three pixels (12 loads) at a time.  A
-            // load that would run past the end of its frame row starts up to 3 bytes early instead and is shifted.
-            if (lane < 2 * kPatch) ws.taps[lane / kPatch][lane % kPatch] = my_tap;
-            wave_lds_sync();
-            // Only the positions motionInterchangePattern reads are resampled (51 of the current buffer, 225 of the previous
-            // one: st.mip_cur / st.mip_prev): 10 loads per lane instead of 24.  A dump of the whole buffers (out_roi19,
-            // component tests) takes all 361 positions of both.
-            auto resample = [&](const uint8_t *frame, uint8_t *dst, const uint16_t *list, int n, int passes) {
-                constexpr int kInFlight = 2;  // output pixels per lane whose loads are in flight together
-                for (int h = 0; h < passes; h += kInFlight) {
-                    uint32_t q0[kInFlight], q1[kInFlight];
-                    int pos[kInFlight];
-#pragma unroll
-                    for (int u = 0; u < kInFlight; ++u) {
-                        const int j = lane + 64 * (h + u);
-                        const int o = list ? (int)list[min(j, n - 1)] : min(j, n - 1);
-                        pos[u] = j < n ? o : -1;
-                        const int dy = o / kPatch, dx = o - dy * kPatch;
-                        const ResizeTap tx = ws.taps[0][dx], ty = ws.taps[1][dy];
-                        const int col = tl_x + tx.ofs, xs = min(col, W - 4);
-                        const int64_t r0 = (int64_t)(tl_y + ty.ofs) * a.f.row_stride + xs, r1 = (int64_t)(tl_y + ty.ofs1) * a.f.row_stride + xs;
-                        __builtin_memcpy(&q0[u], frame + r0, 4);
-                        __builtin_memcpy(&q1[u], frame + r1, 4);
-                    }
-#pragma unroll
-                    for (int u = 0; u < kInFlight; ++u) {
-                        const int o = max(pos[u], 0);
-                        const int dy = o / kPatch, dx = o - dy * kPatch;
-                        const ResizeTap tx = ws.taps[0][dx], ty = ws.taps[1][dy];
-                        const int col = tl_x + tx.ofs;
-                        const int sh0 = 8 * (col - min(col, W - 4)), sh1 = sh0 + 8 * (tx.ofs1 - tx.ofs);
-                        const uint8_t px = resize_px((int)((q0[u] >> sh0) & 0xff), (int)((q0[u] >> sh1) & 0xff), (int)((q1[u] >> sh0) & 0xff),
-                                                     (int)((q1[u] >> sh1) & 0xff), tx, ty);
-                        if (pos[u] >= 0) dst[o] = px;
-                    }
-                }
-            };
-            if (a.out_roi19 == nullptr) {
-                resample(prev, ws.p19[1], st.mip_prev, st.mip_n_prev, (st.mip_n_prev + 63) / 64);
-                resample(cur, ws.p19[0], st.mip_cur, st.mip_n_cur, (st.mip_n_cur + 63) / 64);
-            } else {
-                resample(prev, ws.p19[1], nullptr, kPatch * kPatch, (kPatch * kPatch + 63) / 64);
-                resample(cur, ws.p19[0], nullptr, kPatch * kPatch, (kPatch * kPatch + 63) / 64);
+            // frame brings them (a load that would run past the end of its frame row starts up to 3 bytes early instead);
+            // v_perm picks the two bytes, the horizontal step is a packed dot product, the vertical one resize_y -- the
+            // tile kernel's arithmetic.  All of a lane's loads (two per position, five positions) are in flight together.
+            {
+                const uint32_t ofsw = (uint32_t)(uint16_t)my_tap.ofs | (uint32_t)(uint16_t)my_tap.ofs1 << 16;
+                if (lane < kPatch)
+                    ws.tx[lane] = make_uint2(ofsw, (uint32_t)(uint16_t)my_tap.c0 | (uint32_t)(uint16_t)my_tap.c1 << 16);
+                else if (lane < 2 * kPatch)
+                    ws.ty[lane - kPatch] = make_uint4(ofsw, (uint32_t)my_tap.c0 << 12, (uint32_t)my_tap.c1 << 12, 0u);
             }
             wave_lds_sync();
-            mot = mip_bits(ws.p19[0], ws.p19[1], st.mip_theta);
-            if (a.out_roi19 != nullptr) {
+            struct Sample {
+                uint32_t q0, q1, sel;  // the two rows' dwords; v_perm selector: byte of the left tap | byte of the right tap << 16
+            };
+            auto ask = [&](const uint8_t *frame, int at) -> Sample {
+                const int dxy = max(at, 0);
+                const uint2 tx = ws.tx[dxy & 0xff];
+                const uint32_t ty = ws.ty[dxy >> 8].x;
+                const int ofs = (int)(tx.x & 0xffff), col = tl_x + ofs, xs = min(col, W - 4);
+                const uint32_t left = (uint32_t)(col - xs), right = left + (tx.x >> 16) - (uint32_t)ofs;
+                Sample r;
+                r.sel = left | right << 16 | 0x0c000c00u;
+                __builtin_memcpy(&r.q0, frame + (uint32_t)(__mul24(tl_y + (int)(ty & 0xffff), stride) + xs), 4);
+                __builtin_memcpy(&r.q1, frame + (uint32_t)(__mul24(tl_y + (int)(ty >> 16), stride) + xs), 4);
+                return r;
+            };
+            auto put = [&](const Sample &r, int at, uint32_t *dst) {  // the weights again from LDS: cheaper than keeping them while the loads fly
+                const int dxy = max(at, 0);
+                const u16x2 wx = __builtin_bit_cast(u16x2, ws.tx[dxy & 0xff].y);
+                const uint4 ty = ws.ty[dxy >> 8];
+                const uint32_t t0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, r.q0, r.sel)), wx, 0u, false);
+                const uint32_t t1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, r.q1, r.sel)), wx, 0u, false);
+                if (at >= 0) reinterpret_cast<uint8_t *>(dst)[(dxy >> 8) * kPatch + (dxy & 0xff)] = (uint8_t)resize_y(t0, t1, ty.y, ty.z);
+            };
+            if (!DUMP) {
+                Sample sm[kMipPasses];
+#pragma unroll
+                for (int u = 0; u < kMipPasses; ++u) sm[u] = ask(u < kPrevPasses ? prev : cur, mip_at[u]);
+#pragma unroll
+                for (int u = 0; u < kMipPasses; ++u) put(sm[u], mip_at[u], ws.p19[u < kPrevPasses ? 1 : 0]);
+            } else {  // all 361 positions of both buffers
+                for (int j = lane; j < kPatch * kPatch; j += 64) {
+                    const int dy = (j * 27) >> 9, at = (j - dy * kPatch) | dy << 8;
+                    const Sample s1 = ask(prev, at), s0 = ask(cur, at);
+                    put(s1, at, ws.p19[1]);
+                    put(s0, at, ws.p19[0]);
+                }
+            }
+            wave_lds_sync();
+            mot = mip_bits_strips(ws.p19[0], ws.p19[1], strips, st.mip_theta);
+            if (DUMP) {
                 uint8_t *dst = a.out_roi19 + out_idx * (2 * kPatch * kPatch);
                 for (int o = lane; o < 2 * kPatch * kPatch; o += 64)
-                    dst[o] = o < kPatch * kPatch ? ws.p19[0][o] : ws.p19[1][o - kPatch * kPatch];
+                    dst[o] = o < kPatch * kPatch ? reinterpret_cast<const uint8_t *>(ws.p19[0])[o] : reinterpret_cast<const uint8_t *>(ws.p19[1])[o - kPatch * kPatch];
             }
             wave_lds_sync();  // the next keypoint of this wave overwrites the scratch
-        } else if (a.out_roi19 != nullptr) {
+        } else if (DUMP) {
             uint8_t *dst = a.out_roi19 + out_idx * (2 * kPatch * kPatch);
             for (int o = lane; o < 2 * kPatch * kPatch; o += 64) dst[o] = 0;
         }
@@ -664,7 +687,10 @@ int launch_integral(const IntegralArgs &a, void *stream)
 
 int launch_describe(const DescribeArgs &a, int n_blocks, void *stream)
 {
-    hipLaunchKernelGGL(describe_kernel, dim3((n_blocks + 7) & ~7), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    if (a.out_roi19 != nullptr)
+        hipLaunchKernelGGL(describe_kernel<true>, dim3((n_blocks + 7) & ~7), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(describe_kernel<false>, dim3((n_blocks + 7) & ~7), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 

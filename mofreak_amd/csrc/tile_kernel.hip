@@ -84,8 +84,6 @@ struct KpRec {   // per-keypoint record of a batch
 };
 static_assert(sizeof(KpRec) == 16, "record size used by the LDS carve");
 
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-
 // LDS accesses by integer byte address (the address of the dynamic LDS block is folded into the scalar bases once):
 // the per-lane address arithmetic stays 32-bit and the instruction's immediate offset takes the constant part.
 //
@@ -121,19 +119,6 @@ typedef uint32_t LdsU2 __attribute__((ext_vector_type(2)));
 struct __attribute__((aligned(8))) Px16 {
     uint32_t w[4];
 };
-
-// (int)((double)a + 0.5) for a float 0.5 <= a < 2^22 with one float add: a + 0.5f is exact while it stays in a's
-// binade; when it crosses into the next one the sum lies in [2^k, 2^k + 0.5), so rounding it to the coarser grid cannot
-// reach another integer.  (Tile-path taps are > 1: the keypoint passed FREAK's border filter.)
-__device__ __forceinline__ int round_half_up_pos(float a) { return (int)(a + 0.5f); }
-
-// floor(v / a) for 0 <= v <= 255 * a, 0 < a <= 8192: (v + 0.5) / a lies at least 0.5 / a away from an integer, and the
-// relative error of v_rcp_f32 (1 ulp) plus one rounding of the fma is below 2^-22, i.e. below 256 * 2^-22 = 6e-5 absolute.
-__device__ __forceinline__ int div_box_small(int v, int a)
-{
-    const float r = __builtin_amdgcn_rcpf((float)a);
-    return (int)__builtin_fmaf((float)v, r, 0.5f * r);
-}
 
 __device__ __forceinline__ int dpp_row_shr(int v, int n)
 {
@@ -517,17 +502,6 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs a)
             last_stamp = now_;                                                      \
         }                                                                           \
     } while (0)
-
-// The vertical step of the 8-bit bilinear resize, ((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2, with the
-// weights pre-shifted by 12: t < 2^20 and b << 12 <= 2^23 are 24-bit operands, and the high half of their 48-bit
-// product, (t & ~15) * (b << 12) >> 32, is (b * (t >> 4)) >> 16 exactly (all factors non-negative).
-__device__ __forceinline__ int resize_y(uint32_t t0, uint32_t t1, uint32_t b0s, uint32_t b1s)
-{
-    uint32_t p0, p1;
-    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(p0) : "v"(t0 & ~15u), "v"(b0s));
-    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(p1) : "v"(t1 & ~15u), "v"(b1s));
-    return (int)((p0 + p1 + 2u) >> 2);
-}
 
 template <bool STAMPS>
 __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)

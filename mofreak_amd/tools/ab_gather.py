@@ -38,6 +38,12 @@ def one(lib, pairs, steps):
         desc = torch.zeros((cap, 16), dtype=torch.uint8, device="cuda")
         valid = torch.zeros(cap, dtype=torch.uint8, device="cuda")
         n = ctx.detect_pairs(cur, prev, W, H, pairs, kps, offs, capacity=cap)
+        band = int(os.environ.get("AB_SORT_BAND", "0"))
+        if band:  # locality experiment: every pair's keypoints in bands of `band` rows (rows change order: compare times only)
+            o = offs.cpu().numpy()
+            pair = torch.from_numpy(np.repeat(np.arange(pairs), np.diff(o))).cuda()
+            key = pair * 100000 + (kps[:n, 1] / band).floor().long() * 100 + (kps[:n, 0] / 64).floor().long()
+            kps[:n] = kps[:n][torch.argsort(key, stable=True)]
         if os.environ.get("AB_PATH") == "gather":
             ctx.set_path(api.PATH_GATHER)
         for _ in range(2):
