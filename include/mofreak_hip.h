@@ -160,6 +160,7 @@ int mofreak_get_tile_stamps(mofreak_ctx *ctx, uint64_t *out, int n, int reset);
  *
  *   cur, prev    gray u8 frames; pair p at cur + p*pair_stride, prev + p*pair_stride; rows row_stride apart
  *                (a T-frame stack is the n_pairs = T-gap case with cur = frames + gap*H*W, prev = frames)
+ *                limits (MOFREAK_ERR_UNSUPPORTED beyond them): W <= 10232, row_stride < 2^23, H*row_stride < 2^31
  *   kps          keypoints, in the order the detector produced them
  *   kp_offsets   NULL: the same n_kp keypoints are described in every pair (dense grid);
  *                else n_pairs+1 int64 CSR offsets into kps (same memory space as kps), n_kp = total

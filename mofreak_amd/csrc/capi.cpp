@@ -306,7 +306,8 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
     } else {
         const int tiles_x = (g.W + kTileW - 1) / kTileW, tiles_y = (g.H + kTileH - 1) / kTileH;
         const int64_t n_keys = (int64_t)tiles_x * tiles_y * (d_offsets ? n_pairs : 1);
-        if (n_keys >= ((int64_t)1 << 31)) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "too many (pair, tile) bins in one call");
+        const int64_t n_bkeys = (int64_t)tiles_y * (d_offsets ? n_pairs : 1);  // the gather path's keypoints are binned too: by band of rows
+        if (n_keys + n_bkeys >= ((int64_t)1 << 31)) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "too many (pair, tile) bins in one call");
         const size_t bin_blocks = ((size_t)n_kp + 255) / 256;
         // keys, then a byte of scale index per keypoint, then (4-byte aligned) pass 1's two figures per workgroup
         const size_t wg_at = ((size_t)n_kp * 5 + 3) & ~(size_t)3;
@@ -316,7 +317,7 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
         // every counter of the binning pass in one buffer (one fill clears them): the gather path's count and the largest
         // pattern size on a 64-byte line each, then per key the population / start, the scatter cursor and the smallest
         // (stored complemented, so that it too starts from zero) and largest ROI side
-        const size_t key_pad = ((size_t)n_keys + 1 + 15) & ~(size_t)15;
+        const size_t key_pad = ((size_t)(n_keys + n_bkeys) + 1 + 15) & ~(size_t)15;
         if ((rc = ensure(ctx, ctx->slow_count, (kBinHeaderInts + 4 * key_pad) * sizeof(int32_t)))) return rc;
         int32_t *bin_base = static_cast<int32_t *>(ctx->slow_count.ptr);
         BinArgs b;
@@ -347,6 +348,7 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
         b.out_valid = out_valid;
         b.out_info = out_info;
         b.n_keys = n_keys;
+        b.n_bkeys = n_bkeys;
         int e = launch_bin(b, ctx->stream);
         if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("binning launch: ") + hipGetErrorString((hipError_t)e));
         if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(span.ev[1], ctx->stream));

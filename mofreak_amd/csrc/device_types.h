@@ -100,22 +100,23 @@ struct BinArgs {
     int32_t tiles_x, tiles_y;
     int32_t force_slow;         // every valid keypoint goes to the gather path (tests, roi19 dumps)
     const SmallTables *small;
-    int32_t *kp_key;            // [n_kp] key >= 0, -1 erased, -2 slow
+    int32_t *kp_key;            // [n_kp] key >= 0: tile key; -1: erased; <= -3: gather path, band key b (pair * tiles_y + tile row) as -3 - b
     uint8_t *kp_scale;          // [n_kp] FREAK scale index (0 for keypoints that fail the size / finiteness tests)
-    int32_t *tile_start;        // [n_keys + 1] counts, then exclusive starts
-    int32_t *tile_cursor;       // [n_keys]
+    int32_t *tile_start;        // [n_keys + n_bkeys + 1] counts, then exclusive starts: the tiles' keys, behind them the gather path's band keys
+    int32_t *tile_cursor;       // [n_keys + n_bkeys]
     uint32_t *tile_lmin_c;      // [n_keys] smallest (as its complement ~L) / largest ROI side among the tile's keypoints: equal in
     uint32_t *tile_lmax;        // the usual case, and then the tile kernel can fetch its sample table before it has seen a keypoint
     size_t counter_bytes;       // slow_count .. the end of tile_lmax are one buffer (kBinHeaderInts in front of tile_start): one fill
     SortedKp *sorted_kp;        // [n_kp] keypoints grouped by key
-    int32_t *slow_list;         // [n_kp]
+    int32_t *slow_list;         // [n_kp] the gather path's keypoints, band after band (tile_start[n_keys + b] - tile_start[n_keys] is where band b starts)
     int32_t *slow_count;        // [1]
     int32_t *max_ps;            // [1] largest patternSizes[] among the tile-path keypoints: sizes the tile kernel's halo
     int32_t *wg_slow, *wg_maxps;  // [ceil(n_kp / 256)] pass 1's per-workgroup gather-path count / largest tile-path pattern
     uint8_t *out_desc;          // erased keypoints are finalised by the binning pass (zeros, valid = 0)
     uint8_t *out_valid;
     int32_t *out_info;
-    int64_t n_keys;
+    int64_t n_keys;             // tile keys: tiles_x * tiles_y (shared list) or that per pair (CSR)
+    int64_t n_bkeys;            // band keys of the gather path: tiles_y, or that per pair
 };
 
 // Per-lane constants of the tile kernel (64 entries, host-built): one lane's share of the tables of stage 3.

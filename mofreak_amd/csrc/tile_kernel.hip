@@ -293,15 +293,13 @@ __global__ __launch_bounds__(256) void bin_count_kernel(BinArgs a)
             const bool roi_in = (x_i - half >= 0) && (y_i - half >= 0) && (x_i - half + L <= a.W) && (y_i - half + L <= a.H);
             const bool fast = !a.force_slow && ps <= kTileHalo && L <= kTileMaxRoi && half <= kTileMipHalo &&
                               (L - half) <= kTileMipHalo + 1 && roi_in;
+            const int pr = a.kp_offsets ? pair_of(offsets_in_lds ? s_off : a.kp_offsets, a.n_pairs, g) : 0;
             if (fast) {
-                const int tile = (y_i / kTileH) * a.tiles_x + (x_i / kTileW);
-                int64_t k64 = tile;
-                if (a.kp_offsets) k64 += (int64_t)pair_of(offsets_in_lds ? s_off : a.kp_offsets, a.n_pairs, g) * (a.tiles_x * a.tiles_y);
-                key = (int)k64;
+                key = pr * (a.tiles_x * a.tiles_y) + (y_i / kTileH) * a.tiles_x + (x_i / kTileW);
                 tile_ps = ps;
                 tile_L = L;
-            } else {
-                key = -2;
+            } else {  // gather path: binned too, by the band of kTileH rows of its pair (band key b as -3 - b)
+                key = -3 - (pr * a.tiles_y + y_i / kTileH);
             }
         }
         a.kp_key[g] = key;
@@ -322,12 +320,19 @@ __global__ __launch_bounds__(256) void bin_count_kernel(BinArgs a)
         }
         todo &= ~same;
     }
+    for (unsigned long long todo = __ballot(key <= -3); todo;) {  // the gather path's bands: keys behind the tiles'
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(key, leader);
+        const unsigned long long same = __ballot(key == k);
+        if (lane_id() == leader) atomicAdd(&a.tile_start[a.n_keys + (-3 - k)], __popcll(same));
+        todo &= ~same;
+    }
     // How many keypoints already need the gather path (pass 2 decides from it whether thin tiles follow them there) and
     // the largest pattern on the tile path (it sizes the tile kernel's integral halo): one pair of numbers per
     // workgroup, reduced by pass 2 -- thousands of atomics on one address are served one after the other, and a wave
     // does not retire before its own has been.
     __shared__ int s_wave_slow[4], s_wave_ps[4];
-    const unsigned long long slow = __ballot(key == -2);
+    const unsigned long long slow = __ballot(key <= -3);
     int m = tile_ps;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
@@ -348,13 +353,16 @@ __global__ __launch_bounds__(256) void bin_count_kernel(BinArgs a)
 constexpr int kSparseTile = 8;   // keypoints below which a tile is handed to the gather path (flat between 8 and 16 on detector output)
 constexpr int kSparseMarker = -(1 << 30);
 
-// Pass 2: exclusive scan of the tile populations (single workgroup; n_keys is a few hundred to ~1e5): every thread
-// sums a run of consecutive keys, the run totals are scanned across the workgroup, every thread writes its run's starts
-// -- two sweeps of independent loads instead of a barrier-separated step per 256 keys.
+// Pass 2: exclusive scan of the populations -- the tiles', then, continuing behind them, those of the gather path's bands
+// (single workgroup; n_keys is a few hundred to ~1e5): every thread sums a run of consecutive keys, the run totals are
+// scanned across the workgroup, every thread writes its run's starts -- two sweeps of independent loads instead of a
+// barrier-separated step per 256 keys.  The keypoints of a tile that is handed to the gather path are added to their
+// band's population first (a tile row IS a band).
 constexpr int kScanThreads = 1024, kScanWaves = kScanThreads / 64;
 
 __global__ __launch_bounds__(kScanThreads) void bin_scan_kernel(int32_t *tile_start, int32_t *tile_cursor, int32_t *slow_count, int32_t *max_ps,
-                                                       const int32_t *wg_slow, const int32_t *wg_maxps, int n_blocks, int64_t n_kp, int64_t n_keys)
+                                                       const int32_t *wg_slow, const int32_t *wg_maxps, int n_blocks, int64_t n_kp, int64_t n_keys,
+                                                       int64_t n_bkeys, int tiles_x, int tiles_y)
 {
     __shared__ int wave_tot[kScanWaves], wave_slow[kScanWaves], wave_ps[kScanWaves];
     const int lane = lane_id(), w = threadIdx.x >> 6;
@@ -378,80 +386,93 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_kernel(int32_t *tile_st
         max_pattern = max(max_pattern, wave_ps[i]);
     }
     const bool drop_sparse = n_slow > 0 && (int64_t)n_slow * 8 >= n_kp;
-    if (threadIdx.x == 0) {
-        *max_ps = max_pattern;
-        *slow_count = 0;  // pass 3 counts while it fills the list
-    }
-    const int64_t run = (n_keys + kScanThreads - 1) / kScanThreads, b0 = min((int64_t)threadIdx.x * run, n_keys), b1 = min(b0 + run, n_keys);
+    if (threadIdx.x == 0) *max_ps = max_pattern;
+    const int tiles = tiles_x * tiles_y;
     constexpr int kPre = 8;  // keys whose populations are requested together
-    int sum = 0;
-    for (int64_t bb = b0; bb < b1; bb += kPre) {
-        int v[kPre];
+    // one scan of `n` populations at `pop`, the starts continuing from `first`; returns the total behind them
+    auto scan = [&](int32_t *pop, int64_t n, int first, bool tile_keys) -> int {
+        const int64_t run = (n + kScanThreads - 1) / kScanThreads, b0 = min((int64_t)threadIdx.x * run, n), b1 = min(b0 + run, n);
+        int sum = 0;
+        for (int64_t bb = b0; bb < b1; bb += kPre) {
+            int v[kPre];
 #pragma unroll
-        for (int u = 0; u < kPre; ++u) v[u] = bb + u < b1 ? tile_start[bb + u] : 0;
+            for (int u = 0; u < kPre; ++u) v[u] = bb + u < b1 ? __hip_atomic_load(&pop[bb + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
 #pragma unroll
-        for (int u = 0; u < kPre; ++u) {
-            if (drop_sparse && v[u] > 0 && v[u] < kSparseTile) {
-                v[u] = 0;
-                tile_start[bb + u] = 0;
-                tile_cursor[bb + u] = kSparseMarker;  // pass 3 sends this tile's keypoints to the slow list
+            for (int u = 0; u < kPre; ++u) {
+                if (tile_keys && drop_sparse && v[u] > 0 && v[u] < kSparseTile) {
+                    const int key = (int)(bb + u);
+                    atomicAdd(&tile_start[n_keys + (key / tiles) * tiles_y + (key % tiles) / tiles_x], v[u]);  // its band's population
+                    v[u] = 0;
+                    pop[bb + u] = 0;
+                    tile_cursor[bb + u] = kSparseMarker;  // pass 3 sends this tile's keypoints to the gather path's list
+                }
+                sum += v[u];
             }
-            sum += v[u];
         }
-    }
-    const int incl = wave_inclusive_scan(sum);
-    if (lane == 63) wave_tot[w] = incl;
+        const int incl = wave_inclusive_scan(sum);
+        __syncthreads();  // (wave_tot is used twice)
+        if (lane == 63) wave_tot[w] = incl;
+        __syncthreads();
+        int base = first + incl - sum, total = first;
+        for (int i = 0; i < kScanWaves; ++i) {
+            if (i < w) base += wave_tot[i];
+            total += wave_tot[i];
+        }
+        for (int64_t bb = b0; bb < b1; bb += kPre) {
+            int v[kPre];
+#pragma unroll
+            for (int u = 0; u < kPre; ++u) v[u] = bb + u < b1 ? __hip_atomic_load(&pop[bb + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+#pragma unroll
+            for (int u = 0; u < kPre; ++u) {
+                if (bb + u < b1) pop[bb + u] = base;
+                base += v[u];
+            }
+        }
+        return total;
+    };
+    const int n_tile_kp = scan(tile_start, n_keys, 0, true);
+    __threadfence();  // the bands' populations now hold the thin tiles' keypoints
     __syncthreads();
-    int base = incl - sum;
-    for (int i = 0; i < w; ++i) base += wave_tot[i];
-    for (int64_t bb = b0; bb < b1; bb += kPre) {
-        int v[kPre];
-#pragma unroll
-        for (int u = 0; u < kPre; ++u) v[u] = bb + u < b1 ? tile_start[bb + u] : 0;
-#pragma unroll
-        for (int u = 0; u < kPre; ++u) {
-            if (bb + u < b1) tile_start[bb + u] = base;
-            base += v[u];
-        }
+    const int n_all = scan(tile_start + n_keys, n_bkeys, n_tile_kp, false);
+    if (threadIdx.x == 0) {
+        tile_start[n_keys + n_bkeys] = n_all;  // (with no band at all this is tile_start[n_keys]: where the last tile ends)
+        *slow_count = n_all - n_tile_kp;
     }
-    if (threadIdx.x == kScanThreads - 1) tile_start[n_keys] = base;  // the last run ends at n_keys (empty runs pass the total along)
 }
 
 // Pass 3: scatter keypoints into their tile's segment / the slow list; finalise erased keypoints.
 __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs a)
 {
-    __shared__ int s_wave_slow[4], s_base;
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = g < a.n_kp;
     const int key = live ? a.kp_key[g] : -1;
-    const bool to_slow = key == -2 || (key >= 0 && a.tile_cursor[key] < 0);
-    // the gather path's list: one counter bump per workgroup (bumps of one address are served one after the other), the
-    // workgroup's keypoints in order behind it -- the list stays close to keypoint order (the order the detector emits:
-    // layer, then raster), which is what gives describe_kernel's neighbouring wavefronts neighbouring rows of the integral
-    const unsigned long long slow_lanes = __ballot(to_slow);
-    if (lane_id() == 0) s_wave_slow[threadIdx.x >> 6] = __popcll(slow_lanes);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int total = s_wave_slow[0] + s_wave_slow[1] + s_wave_slow[2] + s_wave_slow[3];
-        s_base = total ? atomicAdd(a.slow_count, total) : 0;
-    }
-    __syncthreads();
-    if (to_slow) {
-        int base = s_base;
-        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += s_wave_slow[w];
-        a.slow_list[base + __popcll(slow_lanes & ((1ull << lane_id()) - 1))] = (int)g;
+    // one key space: a tile's keypoints go to its segment of sorted_kp, the gather path's to their band's segment of its
+    // list (bands of kTileH rows, pair after pair: describe_kernel's wavefronts in flight then work on one strip of one
+    // pair's integral instead of on a whole layer's keypoints all over it -- half the HBM fetches)
+    int ukey = -1;
+    bool to_slow = false;
+    if (key >= 0) {
+        if (a.tile_cursor[key] < 0) {  // a thin tile, handed over by pass 2
+            const int tiles = a.tiles_x * a.tiles_y;
+            to_slow = true;
+            ukey = (int)a.n_keys + (key / tiles) * a.tiles_y + (key % tiles) / a.tiles_x;
+        } else {
+            ukey = key;
+        }
+    } else if (key <= -3) {
+        to_slow = true;
+        ukey = (int)a.n_keys + (-3 - key);
     }
     if (!live) return;
-    // a tile's keypoints: one cursor bump per distinct tile in the wave, the wave's keypoints of that tile in order behind
-    // it.  Who leads which tile is worked out first, without touching memory, so that all the bumps (which return a value:
-    // a memory round trip each) are in flight together.
-    const bool to_tile = !to_slow && key >= 0;
+    // one cursor bump per distinct key in the wave, the wave's keypoints of that key in order behind it.  Who leads which
+    // key is worked out first, without touching memory, so that all the bumps (which return a value: a memory round trip
+    // each) are in flight together.
     int leader = 0, rank = 0, count = 0;
-    for (unsigned long long todo = __ballot(to_tile); todo;) {
+    for (unsigned long long todo = __ballot(ukey >= 0); todo;) {
         const int first = __ffsll((long long)todo) - 1;
-        const int k = __shfl(key, first);
-        const unsigned long long same = __ballot(to_tile && key == k);
-        if (to_tile && key == k) {
+        const int k = __shfl(ukey, first);
+        const unsigned long long same = __ballot(ukey == k);
+        if (ukey == k) {
             leader = first;
             rank = __popcll(same & ((1ull << lane_id()) - 1));
             count = __popcll(same);
@@ -459,9 +480,10 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs a)
         todo &= ~same;
     }
     int pos = 0;
-    if (to_tile && lane_id() == leader) pos = a.tile_start[key] + atomicAdd(&a.tile_cursor[key], count);
+    if (ukey >= 0 && lane_id() == leader) pos = a.tile_start[ukey] + atomicAdd(&a.tile_cursor[ukey], count);
     pos = __shfl(pos, leader) + rank;
     if (to_slow) {
+        a.slow_list[pos - a.tile_start[a.n_keys]] = (int)g;
     } else if (key >= 0) {
         const mofreak_keypoint kp = a.kps[g];
         SortedKp s;
@@ -1136,7 +1158,7 @@ int launch_bin(const BinArgs &a, void *stream)
     const int blocks = (int)((a.n_kp + 255) / 256);
     if (blocks > 0) hipLaunchKernelGGL(bin_count_kernel, dim3(blocks), dim3(256), 0, s, a);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, a.tile_start, a.tile_cursor, a.slow_count, a.max_ps, a.wg_slow, a.wg_maxps, blocks,
-                       a.n_kp, a.n_keys);
+                       a.n_kp, a.n_keys, a.n_bkeys, a.tiles_x, a.tiles_y);
     if (blocks > 0) hipLaunchKernelGGL(bin_scatter_kernel, dim3(blocks), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }

@@ -277,6 +277,9 @@ def test_bad_arguments_are_reported(gpu_ctx):
         gpu_ctx.extract_pairs_host(z, z, kp, kp_offsets=np.array([0, 5], np.int64))  # offsets[n_pairs] != n_kp
     with pytest.raises(M.MoFREAKError):
         gpu_ctx.extract_pairs(z, z, 0, 64, 1, kp, out_d, out_v)
+    with pytest.raises(M.MoFREAKError) as e:  # the gather path's 32-bit byte offsets: rows of 2^23 bytes and more are refused
+        gpu_ctx.extract_pairs(z, z, 64, 64, 1, kp, out_d, out_v, row_stride=1 << 23)
+    assert e.value.code == -4 and "row_stride" in str(e.value)
 
 
 def test_strides_and_unaligned_frames(ctx_path, oracle):
