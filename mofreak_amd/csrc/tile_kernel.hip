@@ -349,8 +349,11 @@ __global__ __launch_bounds__(256) void bin_count_kernel(BinArgs a)
 
 // A tile costs the same whether it holds 5 keypoints or 90 (gray tiles, the integral), the gather path costs per
 // keypoint.  When the gather path runs anyway for a good share of the call (large keypoints: a detector's output),
-// thinly populated tiles are cheaper there; on dense grids nothing changes.
-constexpr int kSparseTile = 8;   // keypoints below which a tile is handed to the gather path (flat between 8 and 16 on detector output)
+// thinly populated tiles are cheaper there; on dense grids (86 keypoints per tile on the benchmark) nothing changes.
+// With the gather path's keypoints in bands (pass 3) a keypoint more in a band it works on anyway costs it ~1.1 ns, a
+// tile ~18 ns before its first keypoint: measured on detector output (32 full-HD pairs, bin + tile + gather per call)
+// 0.618 ms at 8, 0.594 at 12, 0.586 at 16, 0.578 at 24, 0.576 at 32, 0.560 at 48 (profiles/r03_gather_experiments.txt).
+constexpr int kSparseTile = 48;  // keypoints below which a tile is handed to the gather path
 constexpr int kSparseMarker = -(1 << 30);
 
 // Pass 2: exclusive scan of the populations -- the tiles', then, continuing behind them, those of the gather path's bands

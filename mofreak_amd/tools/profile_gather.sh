@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $root
 out=gpurun_out/prof_gather
 rm -rf $out && mkdir -p $out
 export AB_STEPS=2
-for band in 0 64; do
+for band in 0; do
   export AB_SORT_BAND=$band
   for set in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD"; do
     tag=$(echo $set | tr ' ' '_' | cut -c1-20)
@@ -14,7 +14,7 @@ done
 python3 - $out <<'PY'
 import csv, glob, collections, sys
 out = sys.argv[1]
-for band in (0, 64):
+for band in (0,):
     tot = collections.defaultdict(list)
     for f in sorted(glob.glob(f'{out}/b{band}_*/*/*counter_collection.csv')):
         per = collections.defaultdict(lambda: collections.defaultdict(float))
