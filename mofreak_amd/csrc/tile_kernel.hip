@@ -584,9 +584,11 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     const int tile_L = (int)~a.tile_lmin_c[key];
     const bool uniform = tile_L == (int)a.tile_lmax[key];
 
+    // (a last group of fewer than kGroup keypoints is filled up with copies of the batch's last one: stage 3 then has whole
+    // groups only, and what it computes for the copies is not stored)
     auto make_records = [&](int b0, int nb) {
-        if (tid < nb) {
-            const SortedKp kp = tile_kps[b0 + tid];
+        if (tid < ((nb + kGroup - 1) & ~(kGroup - 1))) {
+            const SortedKp kp = tile_kps[b0 + min(tid, nb - 1)];
             KpRec k;
             k.kx = kp.x;
             k.ky = kp.y;
@@ -955,7 +957,6 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             uint32_t c0, c1;    // (kx, ky) as bits -- or, when every keypoint of the batch has integer coordinates, the LDS
                                 // addresses of its corner in the integral and of its record
             uint32_t tab;       // byte offset of the keypoint's 43 points (un-rotated in pass A, rotated in pass B) in the tables
-            uint32_t vdst;      // where the box mean goes
         };
         const float box_margin = a.box_margin;
 
@@ -980,19 +981,11 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             // choice is made once per batch here instead of once per box inside the loops.
             auto run_batch = [&](auto int_tag) {
                 constexpr bool kAllInt = decltype(int_tag)::value;
-                // a group's last keypoints may be missing: their tasks redo the group's last real keypoint
+                // (groups are whole: make_records fills the last one up)
                 auto group_tasks = [&](int kbase, Task (&t)[kBoxIters]) {
-                    const int last = min(kGroup, nb - kbase) - 1;
 #pragma unroll
                     for (int u = 0; u < kBoxIters; ++u) {
-                        uint32_t ra = rec_full[u] + kbase * 16, ka = kint_full[u] + kbase * 8;
-                        t[u].vdst = vdst_full[u];
-                        if (last != kGroup - 1) {  // (wave-uniform)
-                            const int kq = min(task_kq[u], last);
-                            ra = lds0 + kOffKf + (kbase + kq) * 16;
-                            ka = lds0 + kOffKint + (kbase + kq) * 8;
-                            t[u].vdst = vv + kq * kVStride + task_p[u];
-                        }
+                        const uint32_t ra = rec_full[u] + kbase * 16, ka = kint_full[u] + kbase * 8;
                         if (kAllInt) {
                             const LdsU2 ct = lds_ld<LdsU2>(ka);
                             t[u].c0 = ct.x;
@@ -1042,7 +1035,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                         }
 #pragma unroll
                         for (int u = 0; u < kBoxIters; ++u)
-                            lds_st<uint8_t>(t[u].vdst, (uint8_t)box(t[u], E0[u], entry_of(t[u], u)));
+                            lds_st<uint8_t>(vdst_full[u], (uint8_t)box(t[u], E0[u], entry_of(t[u], u)));
                         wave_lds_sync();
                         int direction0 = 0, direction1 = 0;
 #pragma unroll
@@ -1093,7 +1086,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
 #pragma unroll
                     for (int u = 0; u < kBoxIters; ++u) en[u] = load_entry(entry_of(tn[u], u));
 #pragma unroll
-                    for (int u = 0; u < kBoxIters; ++u) lds_st<uint8_t>(tc[u].vdst, (uint8_t)box(tc[u], ec[u], entry_of(tc[u], u)));
+                    for (int u = 0; u < kBoxIters; ++u) lds_st<uint8_t>(vdst_full[u], (uint8_t)box(tc[u], ec[u], entry_of(tc[u], u)));
                     wave_lds_sync();
                     // lane = descriptor bit; lane q stores keypoint q's descriptor
                     {
