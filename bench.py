@@ -189,24 +189,26 @@ def detector_figures(ctx, torch, synth, W, H, pairs=32, steps=3, with_cpu=True):
                         "detect_and_describe_frac": (det_bytes + desc_bytes) / both_s / 1e9 / HBM_PEAK_GBS,
                         "note": "host-timed calls (launch gaps included), wall clock around synchronising calls"}}
     # the reference's whole frame loop as ONE call (mofreak_compute_stream: detector -> descriptors -> rows) on a stack of
-    # pairs + 5 frames: two lanes side by side by default, one batch after the other for comparison
+    # pairs + 5 frames: as the library chooses by default, and forced onto two lanes / one lane for comparison
     try:
         T = pairs + 5
         stack = torch.from_numpy(np.stack([fr[t % len(fr)] for t in range(T)])).cuda()
         rows = torch.empty(pairs * 12000 * 32, dtype=torch.uint8, device="cuda")
         loop = {}
-        for mode in (True, False):
+        from mofreak_amd import api
+        for name, mode in (("default", api.LOOP_AUTO), ("two_lanes", api.LOOP_TWO_LANES), ("one_lane", api.LOOP_ONE_LANE)):
             ctx.set_loop_pipelining(mode)
             ctx.compute_stream(stack, T, W, H, rows, capacity=rows.numel() // 32)
             ctx.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
                 n_rows, n_loop_kp = ctx.compute_stream(stack, T, W, H, rows, capacity=rows.numel() // 32)
-            loop["two_lanes" if mode else "one_lane"] = pairs * steps / (time.perf_counter() - t0)
-        out["frame_loop"] = {"pairs_per_s": loop["two_lanes"], "one_lane_pairs_per_s": loop["one_lane"], "rows_per_pair": n_rows / pairs,
+            loop[name] = pairs * steps / (time.perf_counter() - t0)
+        out["frame_loop"] = {"pairs_per_s": loop["default"], "two_lanes_pairs_per_s": loop["two_lanes"], "one_lane_pairs_per_s": loop["one_lane"],
+                             "rows_per_pair": n_rows / pairs,
                              "note": "mofreak_compute_stream on a device-resident stack, rows compacted on the device"}
     finally:
-        ctx.set_loop_pipelining(True)
+        ctx.set_loop_pipelining(1)  # MOFREAK_LOOP_AUTO
     if with_cpu:  # part of the cpu_baseline leg: the oracle as a reported baseline, never as the product
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib

@@ -128,9 +128,18 @@ int mofreak_check_status(mofreak_ctx *ctx);
 #define MOFREAK_PATH_AUTO 0
 #define MOFREAK_PATH_GATHER 1
 int mofreak_set_path(mofreak_ctx *ctx, int path);
-/* mofreak_compute_stream's software pipelining (on by default).  0: one batch after the other on the context's stream
- * (A/B measurements; the rows do not depend on it). */
-int mofreak_set_loop_pipelining(mofreak_ctx *ctx, int enable);
+/* mofreak_compute_stream's two-lane loop (the batches of a stack alternate between two streams, the detector of one beside
+ * the descriptors of the other).  The rows do not depend on it.
+ *   MOFREAK_LOOP_AUTO (default)  two lanes when the stack needs more than one batch of 128 pairs anyway -- where they were
+ *                                measured to pay (1920x1080: +20 % at 256 pairs; 640x480: +6 % at 512) -- one lane below
+ *                                (two half-size batches cost the detector more than the overlap returns: -14 % at 32 pairs
+ *                                of 640x480)
+ *   MOFREAK_LOOP_ONE_LANE        one batch after the other on the context's stream
+ *   MOFREAK_LOOP_TWO_LANES       two lanes from 16 pairs up (tests, A/B measurements) */
+#define MOFREAK_LOOP_ONE_LANE 0
+#define MOFREAK_LOOP_AUTO 1
+#define MOFREAK_LOOP_TWO_LANES 2
+int mofreak_set_loop_pipelining(mofreak_ctx *ctx, int mode);
 
 /* Per-call device timing, measured with HIP events on the context's stream around the binning kernels, the tile
  * kernel and the gather path of every extract call.  Off by default. */

@@ -23,6 +23,7 @@ BITS_SSE, BITS_NATURAL, BITS_SSE_SIGNED = 0, 1, 2
 FP_X87, FP_SSE = 0, 1  # mofreak_params.brisk_fp_model
 TABLES_ONLY = -1
 PATH_AUTO, PATH_GATHER = 0, 1
+LOOP_ONE_LANE, LOOP_AUTO, LOOP_TWO_LANES = 0, 1, 2
 
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4")])
 ROW_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("frame_number", "<i4"), ("scale", "<f4"),
@@ -247,9 +248,11 @@ class Context:
         """PATH_AUTO (tile kernel + gather path for large keypoints) or PATH_GATHER (gather path for everything)."""
         self._check(self._lib.mofreak_set_path(self._h, path))
 
-    def set_loop_pipelining(self, enable: bool):
-        """compute_stream's software pipelining (detector of batch k + 1 beside the descriptors of batch k): on by default."""
-        self._check(self._lib.mofreak_set_loop_pipelining(self._h, 1 if enable else 0))
+    def set_loop_pipelining(self, mode):
+        """compute_stream's two-lane loop: LOOP_AUTO (default: stacks of more than 128 pairs), LOOP_ONE_LANE, LOOP_TWO_LANES
+        (from 16 pairs up).  True / False are taken as LOOP_TWO_LANES / LOOP_ONE_LANE."""
+        mode = LOOP_TWO_LANES if mode is True else LOOP_ONE_LANE if mode is False else int(mode)
+        self._check(self._lib.mofreak_set_loop_pipelining(self._h, mode))
 
     def get_tile_stamps(self, reset: bool = True) -> np.ndarray:
         out = np.zeros(32, np.uint64)

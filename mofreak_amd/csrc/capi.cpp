@@ -72,7 +72,7 @@ struct mofreak_ctx {
         bool ready = false;
     } loop;
     mofreak_ctx *helper = nullptr;         // lane 1: a context of its own (stream, workspaces), created on first use
-    bool loop_pipelined = true;  // mofreak_set_loop_pipelining(ctx, 0): one batch after the other (A/B tests)
+    int loop_mode = MOFREAK_LOOP_AUTO;  // mofreak_set_loop_pipelining
     int path_mode = MOFREAK_PATH_AUTO;
     int chunk_pairs_hint = 0;
     // optional per-launch timing (mofreak_set_profiling): events around the integral group and the describe launch
@@ -770,7 +770,8 @@ int mofreak_reserve(mofreak_ctx *ctx, int W, int H, int chunk_pairs)
 int mofreak_set_loop_pipelining(mofreak_ctx *ctx, int enable)
 {
     if (!ctx) return MOFREAK_ERR_BAD_ARG;
-    ctx->loop_pipelined = enable != 0;
+    if (enable < MOFREAK_LOOP_ONE_LANE || enable > MOFREAK_LOOP_TWO_LANES) return fail(ctx, MOFREAK_ERR_BAD_ARG, "loop mode must be 0, 1 or 2");
+    ctx->loop_mode = enable;
     return MOFREAK_OK;
 }
 
@@ -2076,10 +2077,12 @@ int mofreak_compute_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W
         if ((rc = ensure(ctx, ctx->stage[5], (size_t)std::max<int64_t>(rows_capacity, 1) * sizeof(mofreak_row)))) return rc;
         d_rows = static_cast<mofreak_row *>(ctx->stage[5].ptr);
     }
-    // Enough pairs for two batches: the two-lane loop.  Batches as large as two lanes allow (the detector's tie rounds are
-    // chains of short launches: the more pairs share them the better), up to 128 pairs.
+    // The two-lane loop: batches as large as two lanes allow (the detector's tie rounds are chains of short launches: the
+    // more pairs share them the better), up to 128 pairs.  By default only for stacks that need more than one such batch
+    // anyway (include/mofreak_hip.h has the measurements); forced: from 16 pairs up.
     const int batch = n_pairs >= 16 ? std::min((n_pairs + 1) / 2, 128) : 0;
-    if (batch > 0 && ctx->loop_pipelined) {
+    const bool two_lanes = ctx->loop_mode == MOFREAK_LOOP_TWO_LANES || (ctx->loop_mode == MOFREAK_LOOP_AUTO && n_pairs > 128);
+    if (batch > 0 && two_lanes) {
         int64_t total = 0, n_kp = 0;
         for (int attempt = 0;; ++attempt) {
             int64_t need = 0;

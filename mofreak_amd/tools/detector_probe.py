@@ -1,6 +1,6 @@
 """Times the keypoint detector (and, with `describe`, the descriptors behind it) on 1920x1080 moving-object frame pairs.
 
-usage: python mofreak_amd/tools/detector_probe.py [pairs_per_call=32] [calls=6] [describe]
+usage: python mofreak_amd/tools/detector_probe.py [pairs_per_call=32] [calls=6] [describe]   (PROBE_NOISE=n: noisy frames)
 The command the detector profiles under profiles/ are taken on (mofreak_amd/tools/profile_detector.sh).
 """
 import sys, os, time, numpy as np
@@ -14,6 +14,10 @@ W, H = 1920, 1080
 ctx = api.Context()
 distinct = 4
 fr = synth.moving_objects_stack(5 + distinct, W, H)
+noise = int(os.environ.get("PROBE_NOISE", "0"))  # +-noise grey levels on every pixel of every frame: no exactly-still background
+if noise:
+    rng = np.random.default_rng(1)
+    fr = np.clip(fr.astype(np.int16) + rng.integers(-noise, noise + 1, fr.shape, dtype=np.int16), 0, 255).astype(np.uint8)
 cur = torch.from_numpy(np.stack([fr[5 + (p % distinct)] for p in range(pairs)])).cuda()
 prev = torch.from_numpy(np.stack([fr[p % distinct] for p in range(pairs)])).cuda()
 cap = 32768 * pairs

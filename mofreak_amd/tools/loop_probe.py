@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The whole frame loop (mofreak_compute_stream: BRISK keypoints on |frame - frame[-5]|, their descriptors, rows) on a
 device-resident 1920x1080 moving-object stack, with and without the software pipelining of detector and descriptors.
-usage: loop_probe.py [PAIRS ...]   (default 32 64 128)"""
+usage: loop_probe.py [PAIRS ...]   (default 32 64 128; LOOP_W / LOOP_H: another frame size)"""
 import json
 import os
 import sys
@@ -14,7 +14,7 @@ import torch
 import mofreak_amd as M
 from mofreak_amd import synth
 
-W, H = 1920, 1080
+W, H = int(os.environ.get("LOOP_W", "1920")), int(os.environ.get("LOOP_H", "1080"))
 sizes = [int(a) for a in sys.argv[1:]] or [32, 64, 128]
 distinct = 9
 base = synth.moving_objects_stack(distinct, W, H)

@@ -140,7 +140,7 @@ def test_pipelined_frame_loop_rows_equal_the_sequential_loop_and_the_oracle(ctx,
     try:
         plain = ctx.compute_stream_host(fr)
     finally:
-        ctx.set_loop_pipelining(True)
+        ctx.set_loop_pipelining(M.api.LOOP_AUTO)
     assert got.tobytes() == plain.tobytes() and len(got) > 200
     lists = [O.brisk_detect(O.absdiff(fr[t], fr[t - 5])) for t in range(5, T)]
     kps = np.concatenate([np.stack([k["x"], k["y"], k["size"]], 1) for k in lists]).astype(np.float32)
@@ -149,7 +149,11 @@ def test_pipelined_frame_loop_rows_equal_the_sequential_loop_and_the_oracle(ctx,
     assert got.tobytes() == want.tobytes()
     assert got["frame_number"].min() == 4 and got["frame_number"].max() == T - 2
     # again on the same context: the buffers and events of the first call are reused
-    assert ctx.compute_stream_host(fr).tobytes() == want.tobytes()
+    ctx.set_loop_pipelining(True)
+    try:
+        assert ctx.compute_stream_host(fr).tobytes() == want.tobytes()
+    finally:
+        ctx.set_loop_pipelining(M.api.LOOP_AUTO)
 
 
 def test_pipelined_frame_loop_grows_its_keypoint_buffers(ctx):
@@ -160,11 +164,12 @@ def test_pipelined_frame_loop_grows_its_keypoint_buffers(ctx):
     fr = np.kron(fr, np.ones((1, 4, 4), np.uint8))  # blocky binary noise: corners everywhere
     ctx.set_detect_capacity(1 << 20)
     try:
+        ctx.set_loop_pipelining(True)  # (two lanes from 16 pairs up; the default takes them for stacks of more than 128 pairs)
         got = ctx.compute_stream_host(fr, capacity=T * 40000)
         ctx.set_loop_pipelining(False)
         plain = ctx.compute_stream_host(fr, capacity=T * 40000)
     finally:
-        ctx.set_loop_pipelining(True)
+        ctx.set_loop_pipelining(M.api.LOOP_AUTO)
         ctx.set_detect_capacity(131072)
     assert len(got) > 17 * 8192 and got.tobytes() == plain.tobytes()
 
