@@ -38,6 +38,8 @@ struct mofreak_ctx {
     // workspace (grown on demand, never shrunk)
     DeviceBuffer integral, band_totals, scratch_desc, scratch_valid, compact_offsets, stage[6], offsets_dev;
     DeviceBuffer kp_key, sorted_idx, slow_list, slow_count;  // keypoint binning (slow_count: all its counters, BinArgs)
+    const int32_t *slow_band_start = nullptr;  // the last binning pass's band starts (inside slow_count) for the gather path behind it
+    int slow_bands_per_pair = 0;
     DeviceBuffer bow_counts, bow_expanded, pair_label;
     // keypoint detector workspace
     DeviceBuffer det_img, det_score, det_touch, det_status, det_rows, det_cand_xy, det_cand_flag, det_cand_emit, det_cand_spec, det_cand_asked, det_cand_win, det_cand_res, det_layer_start,
@@ -149,10 +151,11 @@ int choose_chunk(const mofreak_ctx *ctx, int W, int H, int n_pairs)
 // Pairs per chunk of the gather path when it runs BEHIND the tile kernel (usually with nothing to do): few big chunks keep
 // the number of (device-gated, empty) launches small.  mofreak_reserve sizes the workspace for the same figure, so that
 // calls after it do not allocate.
-int slow_chunk(int W, int H)
+int slow_chunk(const mofreak_ctx *ctx, int W, int H)
 {
     const size_t per_pair = (size_t)(H + 1) * integral_pitch(W) * sizeof(int32_t);
-    return (int)std::max<size_t>(1, ((size_t)1 << 30) / per_pair);
+    const int chunk = (int)std::max<size_t>(1, ((size_t)1 << 30) / per_pair);
+    return ctx->chunk_pairs_hint > 0 ? std::min(chunk, ctx->chunk_pairs_hint) : chunk;  // (mofreak_reserve's chunk_pairs: also here)
 }
 
 struct Geometry {
@@ -227,7 +230,7 @@ int run_gather(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, const 
                const mofreak_keypoint *kps, const int64_t *d_offsets, const int64_t *h_offsets, int64_t n_kp,
                uint8_t *out_desc, uint8_t *out_valid, int32_t *out_info, uint8_t *out_roi19, bool slow_mode)
 {
-    int chunk = slow_mode ? slow_chunk(g.W, g.H) : choose_chunk(ctx, g.W, g.H, n_pairs);
+    int chunk = slow_mode ? slow_chunk(ctx, g.W, g.H) : choose_chunk(ctx, g.W, g.H, n_pairs);
     chunk = std::max(1, std::min(chunk, n_pairs));
     const int32_t *gate = slow_mode ? static_cast<const int32_t *>(ctx->slow_count.ptr) : nullptr;
     for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
@@ -270,6 +273,8 @@ int run_gather(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, const 
         a.status = ctx->d_status;
         a.slow_list = slow_mode ? static_cast<const int32_t *>(ctx->slow_list.ptr) : nullptr;
         a.slow_count = gate;
+        a.band_start = slow_mode ? ctx->slow_band_start : nullptr;
+        a.bands_per_pair = ctx->slow_bands_per_pair;
         a.n_pairs_total = n_pairs;
         const int64_t want = (n_items + 3) / 4;
         const int n_blocks = (int)std::min<int64_t>(want, (int64_t)ctx->n_cus * 5);  // 5 workgroups of 4 waves: what a CU holds at describe_kernel's register count
@@ -349,6 +354,8 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
         b.out_info = out_info;
         b.n_keys = n_keys;
         b.n_bkeys = n_bkeys;
+        ctx->slow_band_start = b.tile_start + n_keys;
+        ctx->slow_bands_per_pair = tiles_y;
         int e = launch_bin(b, ctx->stream);
         if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("binning launch: ") + hipGetErrorString((hipError_t)e));
         if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(span.ev[1], ctx->stream));
@@ -759,7 +766,7 @@ int mofreak_reserve(mofreak_ctx *ctx, int W, int H, int chunk_pairs)
     NEED_DEVICE(ctx);
     ctx->chunk_pairs_hint = chunk_pairs > 0 ? chunk_pairs : 0;
     // the larger of the two users: the gather path alone (chunk_pairs at a time) and the gather path behind the tile kernel
-    const int chunk = std::max(choose_chunk(ctx, W, H, 1 << 30), ctx->path_mode == MOFREAK_PATH_GATHER ? 1 : slow_chunk(W, H));
+    const int chunk = std::max(choose_chunk(ctx, W, H, 1 << 30), ctx->path_mode == MOFREAK_PATH_GATHER ? 1 : slow_chunk(ctx, W, H));
     const int pitch = integral_pitch(W);
     const int n_bands = (H + kBandRows * kBandGroup - 1) / (kBandRows * kBandGroup);
     int rc = ensure(ctx, ctx->integral, (size_t)chunk * (H + 1) * pitch * sizeof(int32_t));

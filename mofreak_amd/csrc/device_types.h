@@ -79,6 +79,8 @@ struct DescribeArgs {
     // tile (slow_list, *slow_count of them), in every pair of the chunk (shared list) or in their own pair (CSR)
     const int32_t *slow_list;
     const int32_t *slow_count;
+    const int32_t *band_start;  // CSR: where each (pair, band of rows) starts in the list (BinArgs::tile_start + n_keys): a chunk of pairs owns one piece of it
+    int32_t bands_per_pair;
     int64_t n_pairs_total;     // pairs of the whole call (CSR pair search in slow-list mode)
 };
 

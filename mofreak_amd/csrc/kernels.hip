@@ -273,7 +273,12 @@ __global__ __launch_bounds__(256, 5) void describe_kernel(DescribeArgs a)
     const int stride = (int)a.f.row_stride;  // (the context takes frames of < 2^31 bytes and rows of < 2^23: 32-bit offsets, 24-bit factors)
 
     // gather path behind the tile kernel: the instances are the binning pass's slow list (device-resident count)
-    const int64_t n_slow = a.slow_list ? (int64_t)*a.slow_count : 0;
+    int64_t n_slow = a.slow_list ? (int64_t)*a.slow_count : 0, slow_lo = 0;
+    if (a.slow_list && a.kp_offsets) {  // the list is in (pair, band) order: this chunk's pairs own one piece of it
+        const int32_t *b = a.band_start;
+        slow_lo = b[a.first_pair * a.bands_per_pair] - b[0];
+        n_slow = b[(a.first_pair + a.n_pairs) * a.bands_per_pair] - b[0] - slow_lo;
+    }
     const int64_t n_items = a.slow_list ? (a.kp_offsets ? n_slow : n_slow * a.n_pairs) : a.n_items;
 
     // Workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own: every XCD takes one contiguous eighth
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(256, 5) void describe_kernel(DescribeArgs a)
                 r.g = a.slow_list[item - (int64_t)r.pair_local * n_slow];
                 r.out_idx = (a.first_pair + r.pair_local) * a.n_kp + r.g;
             } else {
-                r.g = a.slow_list[item];
+                r.g = a.slow_list[slow_lo + item];
                 r.out_idx = r.g;
             }
         } else if (a.kp_offsets == nullptr) {

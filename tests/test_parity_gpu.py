@@ -219,6 +219,25 @@ def test_mixed_sizes_random_positions_bit_exact(ctx_path, oracle):
     ctx_path.check_status()  # no ROI ever leaves the image for keypoints that survive FREAK's border filter
 
 
+def test_gather_path_in_chunks_of_pairs_behind_the_tile_kernel(native_lib, oracle):
+    """Ragged keypoint lists of mixed sizes over 7 pairs with the gather path's integral workspace limited to 3 pairs: every chunk
+    takes its own piece of the band-sorted list (pairs 0-2, 3-5, 6), the tile kernel the dense small keypoints."""
+    W, H = 320, 240
+    fr = synth.synth_stack(12, W, H)
+    rng = np.random.default_rng(17)
+    counts = [900, 0, 1500, 40, 700, 1, 1200]
+    kps = np.concatenate([synth.random_keypoints(rng, n, W, H, sizes=(7.0, 9.5, 12.0, 16.0, 27.0, 40.0)) for n in counts] + [np.zeros((0, 3), np.float32)])
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    cur, prev = fr[5:12], fr[0:7]
+    want_d, want_v = oracle_pairs(oracle, cur, prev, kps, offsets=offs)
+    with M.Context(0) as ctx:
+        ctx.reserve(W, H, 3)
+        desc, valid = ctx.extract_pairs_host(cur, prev, kps, kp_offsets=offs)
+        ctx.check_status()
+    assert np.array_equal(valid, want_v) and np.array_equal(desc, want_d)
+    assert 0.2 < valid.mean() < 0.95
+
+
 @pytest.mark.parametrize("mode", [M.BITS_NATURAL, M.BITS_SSE_SIGNED])
 def test_other_bit_modes(native_lib, oracle, mode):
     W, H = 320, 240
