@@ -196,7 +196,7 @@ def detector_figures(ctx, torch, synth, W, H, pairs=32, steps=3, with_cpu=True):
         rows = torch.empty(pairs * 12000 * 32, dtype=torch.uint8, device="cuda")
         loop = {}
         from mofreak_amd import api
-        for name, mode in (("default", api.LOOP_AUTO), ("two_lanes", api.LOOP_TWO_LANES), ("one_lane", api.LOOP_ONE_LANE)):
+        for name, mode in (("two_lanes", api.LOOP_TWO_LANES), ("one_lane", api.LOOP_ONE_LANE), ("default", api.LOOP_AUTO)):  # (the first mode also pays for the buffers)
             ctx.set_loop_pipelining(mode)
             ctx.compute_stream(stack, T, W, H, rows, capacity=rows.numel() // 32)
             ctx.synchronize()
