@@ -58,10 +58,13 @@ struct ResizeTap {
 };
 
 // ---- geometry of the fused tile kernel (tile_kernel.hip); the MIP sample table below bakes in kTileStagePitch
-constexpr int kTileW = 96, kTileH = 64;  // pixels a workgroup owns
-constexpr int kTileHalo = 48;            // FREAK: keypoints whose patternSizes[scale] <= kTileHalo take the tile path
+constexpr int kTileW = 128, kTileH = 64;  // pixels a workgroup owns: 128 keypoints of an 8-pixel grid, whole groups and whole pairs of
+                                          // keypoints for every wave of the tile kernel (96 x 64: 86 of them, 2.7 groups per wave)
+constexpr int kTileHalo = 40;            // FREAK: keypoints whose patternSizes[scale] <= kTileHalo take the tile path (size < ~12.7;
+                                          // 48 with 96-pixel tiles: what two workgroups' LDS per CU allows for the wider region)
+constexpr int kTileHaloX = (kTileHalo + 15) & ~15;  // 16-byte pieces of a region row start on 16 bytes of the frame row
 constexpr int kTileMipHalo = 8;          // MIP: ROI reach beyond the tile (the smallest halo, 24, covers it)
-constexpr int kTileRW = kTileW + 2 * kTileHalo, kTileRH = kTileH + 2 * kTileHalo;           // largest integral region 192 x 160
+constexpr int kTileRW = kTileW + 2 * kTileHaloX, kTileRH = kTileH + 2 * kTileHalo;          // largest integral region 224 x 144
 // One LDS row of the tile kernel: first the staged gray bytes of a region row (current at byte 0, previous at byte
 // kTileRW), later, in place, the row of the u16 integral (kTileRW + 8 entries).
 constexpr int kTileStagePitch = 2 * (kTileRW + 8);

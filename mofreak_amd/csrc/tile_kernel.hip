@@ -37,7 +37,7 @@ constexpr int kTileThreads = 512;                    // 8 waves; two workgroups 
 constexpr int kStageRows = kTileThreads / 16;        // region rows a staging step takes (16 lanes per row)
 constexpr int kTileLdsLimit = 80 * 1024;             // a workgroup's LDS budget (two per CU); debug builds check accesses against it
 constexpr int kTileWaves = kTileThreads / 64;
-constexpr int kBatch = 96;                           // keypoints described per pass over a tile's list
+constexpr int kBatch = 128;                          // keypoints described per pass over a tile's list
 constexpr int kGroup = 4;                            // keypoints one wave describes together in stage 3
 constexpr int kMinHalo = 24;                         // smallest integral halo (patternSizes[0] = 23)
 constexpr int kIPitch = kTileStagePitch / 2;         // LDS integral pitch (u16); logical column c at physical c+7
@@ -61,10 +61,14 @@ constexpr int kScratchBytes = kTileWaves * kP19Wave;           // stage 1: 19x19
 constexpr int kOffTheta = kOffScratch + kScratchBytes;
 constexpr int kOffKf = kOffTheta + kThetaBounds * (int)sizeof(ThetaBound);   // the batch's keypoint records
 constexpr int kOffMot = kOffKf + kBatch * 16;                                // motion bytes kept for the fused store
-constexpr int kOffKint = kOffMot + kBatch * 8;                               // per keypoint: its corner in the integral (integer coordinates), its block of the pattern tables
-constexpr int kOffDirs = kOffKint + kBatch * 8;                              // orientation sums, until a wave turns its keypoints' into thetas
-constexpr int kOffStamps = kOffDirs + kBatch * 8;                            // diagnostic build only: 32 x u64
-constexpr int kTileLdsBytes = kOffStamps + 256;
+constexpr int kOffKint = kOffMot + kBatch * 8;                               // per keypoint: its corner in the integral (integer coordinates); where its ROI starts in
+                                                                             // the staged rows (stage 1), then its block of the pattern tables (stage 3)
+constexpr int kStampLds = 8;                                                 // diagnostic build only: the phases' u64 tick sums
+constexpr int kOffStamps = kOffKint + kBatch * 8;
+constexpr int kTileLdsBytes = kOffStamps + kStampLds * 8;
+constexpr int kDirsInScratch = kTileWaves * kGroup * kVStride;               // stage 3: behind the waves' box means, every wave's keypoints' orientation sums
+constexpr int kDirsPerWave = (kBatch / kTileWaves) * 8;
+static_assert(kDirsInScratch % 8 == 0 && kDirsInScratch + kTileWaves * kDirsPerWave <= kScratchBytes, "the orientation sums fit the scratch area");
 static_assert(kP19Wave % 16 == 0 && kOffScratch % 16 == 0 && kOffTheta % 16 == 0, "LDS carve alignment");
 static_assert(2 * kTileLdsBytes <= 160 * 1024 && kTileLdsBytes <= kTileLdsLimit, "two workgroups per CU");
 static_assert(kTileRW % 16 == 0 && kTileRH % kColBlockRows == 0 && kTileRW / 16 <= 16 && kTileThreads % 64 == 0, "region blocking");
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds;  // LDS address of the block
     unsigned long long *s_stamps = reinterpret_cast<unsigned long long *>(lds + kOffStamps);
     if (STAMPS && threadIdx.x == 0)
-        for (int i = 0; i < kTileStampSlots; ++i) s_stamps[i] = 0;
+        for (int i = 0; i < kStampLds; ++i) s_stamps[i] = 0;
     unsigned long long last_stamp = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
     const int n_tiles = a.tiles_x * a.tiles_y;
     // 1-D grid, remapped so that each XCD (workgroups are dealt round-robin over the 8 XCDs) walks a contiguous range
@@ -577,8 +581,6 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     uint2 *s_mot = reinterpret_cast<uint2 *>(lds + kOffMot);
     KpRec *kf = reinterpret_cast<KpRec *>(lds + kOffKf);
     uint2 *kint = reinterpret_cast<uint2 *>(lds + kOffKint);
-    int2 *s_dirs = reinterpret_cast<int2 *>(lds + kOffDirs);
-    uint32_t *s_roi = reinterpret_cast<uint32_t *>(lds + kOffDirs);  // stage 1 only: where a keypoint's ROI starts in the staged rows
     const bool one_batch = n_tile_kp <= kBatch;
     // The binning pass recorded the smallest and largest ROI side of the tile: equal in the usual case.
     const int tile_L = (int)~a.tile_lmin_c[key];
@@ -586,7 +588,8 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
 
     // (a last group of fewer than kGroup keypoints is filled up with copies of the batch's last one: stage 3 then has whole
     // groups only, and what it computes for the copies is not stored)
-    auto make_records = [&](int b0, int nb) {
+    auto table_block = [](uint32_t scale) { return scale * (uint32_t)(kNbOrientation * kNbPoints * 16); };
+    auto make_records = [&](int b0, int nb, bool for_mip) {
         if (tid < ((nb + kGroup - 1) & ~(kGroup - 1))) {
             const SortedKp kp = tile_kps[b0 + min(tid, nb - 1)];
             KpRec k;
@@ -599,13 +602,12 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             // a keypoint at integer coordinates: LDS address of its own corner (ky, kx) in the integral; else the top bit
             const int xi = (int)kp.x, yi = (int)kp.y;
             const bool integral = (float)xi == kp.x && (float)yi == kp.y;
-            // .y: byte offset of the keypoint's 43 un-rotated points in the pattern tables (16-byte entries); the orientation
-            // pass replaces it by the offset of the rotated ones
-            kint[tid] = make_uint2(integral ? lds0 + kOffIntegral + 2 * (kIColOff + (yi - oy) * kIPitch + (xi - ox)) : 0x80000000u,
-                                   (kp.packed >> 16) * (uint32_t)(kNbOrientation * kNbPoints * 16));
-            // the ROI's first byte in the staged rows (:293-295, :460 float -> int parameters)
+            // .y, stage 1: the ROI's first byte in the staged rows (:293-295, :460 float -> int parameters); stage 3: byte offset
+            // of the keypoint's 43 un-rotated points in the pattern tables (16-byte entries), which the orientation pass
+            // replaces by the offset of the rotated ones
             const int half = (int)((kp.packed >> 8) & 0xff);
-            s_roi[tid] = (uint32_t)((yi - half - oy + 1) * kTileStagePitch + (xi - half - ox));
+            kint[tid] = make_uint2(integral ? lds0 + kOffIntegral + 2 * (kIColOff + (yi - oy) * kIPitch + (xi - ox)) : 0x80000000u,
+                                   for_mip ? (uint32_t)((yi - half - oy + 1) * kTileStagePitch + (xi - half - ox)) : table_block(kp.packed >> 16));
         }
     };
 
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     if (uniform) load_samples(tile_L);  // one ROI side in the whole tile (the usual case): its samples stay in registers
     const bool tail_ok = lane + 64 * (kMipIters - 1) < a.mip_n;  // the last pass is a partial one (launch_tile checks mip_n)
 
-    make_records(0, min(kBatch, n_tile_kp));
+    make_records(0, min(kBatch, n_tile_kp), true);
     if (tid < kThetaBounds) s_theta[tid] = a.theta[tid];
     if (wide) {
         if (sq < runs) {
@@ -775,7 +777,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             const int nb = min(kBatch, n_tile_kp - b0);
             if (b0 > 0) {  // further batches of a crowded tile: their records
                 __syncthreads();
-                make_records(b0, nb);
+                make_records(b0, nb, true);
                 __syncthreads();
             }
             if (uniform) {
@@ -787,7 +789,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                 for (int kk = wave; kk < nb; kk += 2 * kTileWaves) {
                     const int kk2 = kk + kTileWaves;
                     const bool two = kk2 < nb;
-                    const uint32_t roi = s_roi[kk], roi2 = s_roi[two ? kk2 : kk];
+                    const uint32_t roi = kint[kk].y, roi2 = kint[two ? kk2 : kk].y;
                     uint32_t px[2][kMipIters];
 #pragma unroll
                     for (int u = 0; u < kMipIters; ++u) {
@@ -818,7 +820,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                         have_L = L;
                         load_samples(L);
                     }
-                    const uint32_t roi = s_roi[kk];
+                    const uint32_t roi = kint[kk].y;
                     uint32_t px[kMipIters];
 #pragma unroll
                     for (int u = 0; u < kMipIters; ++u) px[u] = sample(ml, u, roi);
@@ -832,6 +834,9 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
         }
     }
     __syncthreads();  TILE_STAMP(1);
+    // a single batch keeps its records for stage 3: the slot that held the ROI offsets now takes the table blocks (stage 2's
+    // barriers come before anyone reads them)
+    if (one_batch && tid < ((n_tile_kp + kGroup - 1) & ~(kGroup - 1))) kint[tid].y = table_block(kf[tid].pk & 63);
 
     // ================= stage 2: integral of |cur - prev| over tile + halo, modulo 2^16, in LDS
     {  // <stage 2>
@@ -964,7 +969,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             const int nb = min(kBatch, n_tile_kp - b0);
             if (!one_batch) {  // crowded tile: the records of this batch (a single batch still has them from stage 0)
                 __syncthreads();
-                make_records(b0, nb);
+                make_records(b0, nb, false);
                 __syncthreads();
             }
             // What the batch's keypoints have in common (every wave works it out for itself from the records): one
@@ -1023,7 +1028,9 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
 #pragma unroll
                         for (int u = 0; u < kBoxIters; ++u) E0[u] = load_entry(have_tab + task_p[u] * 16);
                     }
-                    for (int kbase = wave * kGroup; kbase < nb; kbase += kGroup * kTileWaves) {
+                    const uint32_t dirs = lds0 + kOffScratch + kDirsInScratch + wave * kDirsPerWave;  // the wave's keypoints' orientation sums: group j's at [4 j .. 4 j + 3]
+                    int j = 0;
+                    for (int kbase = wave * kGroup; kbase < nb; kbase += kGroup * kTileWaves, ++j) {
                         const int last = min(kGroup, nb - kbase) - 1;
                         Task t[kBoxIters];
                         group_tasks(kbase, t);
@@ -1046,7 +1053,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                         }
                         direction0 = row16_sum(direction0);
                         direction1 = row16_sum(direction1);
-                        if (osub == 0 && oq <= last) s_dirs[kbase + oq] = make_int2(direction0, direction1);
+                        if (osub == 0 && oq <= last) lds_st<LdsU2>(dirs + (j * kGroup + oq) * 8, LdsU2{(uint32_t)direction0, (uint32_t)direction1});
                         wave_lds_sync();  // the next group overwrites the box means
                     }
                     TILE_STAMP(5);
@@ -1054,7 +1061,8 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                     {
                         const int kp = (wave + kTileWaves * (lane >> 2)) * kGroup + (lane & 3);
                         if (kp < nb) {
-                            const int2 d = s_dirs[kp];
+                            const LdsU2 dd = lds_ld<LdsU2>(dirs + lane * 8);  // (lane = 4 * group + slot, as stored)
+                            const int2 d = make_int2((int)dd.x, (int)dd.y);
                             const int theta = theta_index(s_theta, d.x, d.y);
                             kint[kp].y = (((kf[kp].pk & 63) * kNbOrientation + theta) * kNbPoints) * 16u;
                             if (a.out_info)
@@ -1140,7 +1148,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     if (tid == 0 && g_tile_oob) atomicOr(a.status, 64);  // mofreak_check_status reports it
 #endif
     if (STAMPS && tid == 0)
-        for (int i = 0; i < kTileStampSlots; ++i)
+        for (int i = 0; i < kStampLds; ++i)
             if (s_stamps[i]) atomicAdd(&a.stamps[i], s_stamps[i]);
 }
 
