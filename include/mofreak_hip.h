@@ -123,7 +123,7 @@ int mofreak_reserve(mofreak_ctx *ctx, int W, int H, int chunk_pairs);
 int mofreak_check_status(mofreak_ctx *ctx);
 
 /* Which kernels describe the keypoints.  AUTO: the fused tile kernel for every keypoint whose FREAK pattern fits a
- * tile's 48-px halo (size < ~14.9), the gather path (global integral + one wavefront per keypoint) for the rest.
+ * tile's 40-px halo (size < ~12.56), the gather path (global integral + one wavefront per keypoint) for the rest.
  * GATHER: the gather path for everything (the round-1 v1 kernels; kept for large keypoints and for A/B tests). */
 #define MOFREAK_PATH_AUTO 0
 #define MOFREAK_PATH_GATHER 1

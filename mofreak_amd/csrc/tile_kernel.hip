@@ -1,6 +1,6 @@
-// Fused tile kernel of the MoFREAK path for gfx950 (CDNA4): one 512-thread workgroup owns a 96x64-pixel tile of one
+// Fused tile kernel of the MoFREAK path for gfx950 (CDNA4): one 512-thread workgroup owns a 128x64-pixel tile of one
 // frame pair and describes every keypoint whose pixel falls in it, entirely out of LDS.  Two workgroups share a CU
-// (75 KB of LDS each), so one workgroup's barriers and global-memory latencies are covered by the other's work.
+// (79.5 KB of LDS each), so one workgroup's barriers and global-memory latencies are covered by the other's work.
 //
 //   stage 0  the gray bytes of the tile + halo of `current` and `previous` -> LDS, each region row into the LDS row
 //            that will hold its integral: the frames are fetched once, in one round trip to memory per tile
@@ -16,14 +16,14 @@
 //            are translation-invariant, so the tile-local integral gives the same box means as cv::integral of the
 //            whole frame -- which never exists in HBM.
 //            The halo is sized per call from the largest FREAK pattern among the call's tile-path keypoints
-//            (binning pass, device-resident word): 24, 32, 40 or 48 pixels.
+//            (binning pass, device-resident word): 24, 32 or 40 pixels.
 //   stage 3  FREAK (cv::FREAK::compute on the difference image, :427-428), one wave per group of four keypoints, no
 //            workgroup barrier: 43 box means per keypoint (172 tasks over three 64-lane passes), orientation with
 //            16 lanes per keypoint (DPP row reduction), rotated means, lane = descriptor bit, __ballot = the 8
 //            appearance bytes, one 16-byte store per descriptor
 //
 // HBM traffic is the two frames (halo re-reads are served by L2 / Infinity Cache) + keypoints in + descriptors out.
-// Keypoints whose FREAK pattern does not fit the 48-px halo (patternSizes[scale] > 48, i.e. size >= ~14.9) or whose
+// Keypoints whose FREAK pattern does not fit the 40-px halo (patternSizes[scale] > 40, i.e. size >= ~12.56) or whose
 // ROI side exceeds 16 are left to the gather path (describe_kernel over a global integral) by the binning pass.
 #include <type_traits>
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B timing of gather-path builds on detector keypoints (1920x1080 moving-object pairs: 40 % of the keypoints are too large
+"""A/B timing of gather-path builds on detector keypoints (1920x1080 moving-object pairs: most of the keypoints are too large
 for the tile kernel).  Kernel experiments only.
 
   ab_gather.py LIB [LIB ...]   each library (a build of the same ABI) in a process of its own: the keypoints are detected once,
@@ -56,7 +56,7 @@ def one(lib, pairs, steps):
         prof = ctx.get_profile(reset=True)
         ctx.check_status()
         digest = hashlib.sha256(desc[:n].cpu().numpy().tobytes() + valid[:n].cpu().numpy().tobytes()).hexdigest()[:16]
-        large = float((kps[:n, 2] > 14.9).float().mean())
+        large = float((kps[:n, 2] >= 12.56).float().mean())
     c = prof["calls"]
     print(json.dumps({"lib": os.path.basename(lib), "pairs": pairs, "keypoints": int(n), "large": round(large, 3), "bin_ms": prof["bin_ms"] / c,
                       "tile_ms": prof["tile_ms"] / c, "gather_ms": prof["gather_ms"] / c, "sha": digest}), flush=True)

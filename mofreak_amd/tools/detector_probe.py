@@ -38,4 +38,4 @@ ctx.synchronize()
 t1 = time.perf_counter()
 print(f"pairs={pairs} kp/pair={n/pairs:.0f} {'detect+describe' if describe else 'detect'} {pairs*steps/(t1-t0):.0f} pairs/s  {1e3*(t1-t0)/steps:.3f} ms/call")
 sz = kps[:n, 2].cpu().numpy()
-print("size quantiles", np.quantile(sz, [0, .1, .25, .5, .75, .9, 1]).round(1), "frac>14.9", (sz > 14.9).mean())
+print("size quantiles", np.quantile(sz, [0, .1, .25, .5, .75, .9, 1]).round(1), "frac>=12.56", (sz >= 12.56).mean())

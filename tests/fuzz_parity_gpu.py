@@ -43,7 +43,7 @@ def main():
               H = int(rng.choice([80, 121, 240, 301, 480, 577]))
               n_pairs = int(rng.integers(1, 4))
               n_kp = int(rng.choice([1, 7, 60, 400, 2500, 9000]))
-              sizes = [(7.0, 9.0, 12.0), (8.4, 12.0, 18.0, 27.0, 40.5), (12.0,), (13.3, 14.9, 15.2, 22.7, 31.0, 55.5, 71.9), (6.9, 100.0)][int(rng.integers(0, 5))]
+              sizes = [(7.0, 9.0, 12.0), (8.4, 12.0, 18.0, 27.0, 40.5), (12.0,), (12.5, 12.6, 13.3, 14.9, 15.2, 22.7, 31.0, 55.5, 71.9), (6.9, 100.0)][int(rng.integers(0, 5))]
               integer_xy = bool(rng.integers(0, 2))
               if rng.integers(0, 2):
                   frames = rng.integers(0, 256, (n_pairs + 5, H, W), dtype=np.uint8)

@@ -424,7 +424,7 @@ def test_identical_frames_give_zero_motion_and_ff_appearance(ctx_path):
 
 # ------------------------------------------------------------------ tile-path specifics
 def test_crowded_tiles_and_tile_borders(gpu_ctx, oracle):
-    """More keypoints in one 96x64 tile than one batch (96): a 3-px grid puts ~680 in a tile, several batches; mixed
+    """More keypoints in one 128x64 tile than one batch (128): a 3-px grid puts ~900 in a tile, several batches; mixed
     ROI sides inside a batch; sizes right below and above the tile path's limit; frame not a multiple of the tile."""
     W, H = 331, 275
     fr = synth.synth_stack(7, W, H)
@@ -432,7 +432,7 @@ def test_crowded_tiles_and_tile_borders(gpu_ctx, oracle):
     xs, ys = np.meshgrid(np.arange(30, W - 30, 3), np.arange(30, H - 30, 3))
     n = xs.size
     kps = np.stack([xs.ravel() + rng.choice([0, 0.25, 0.5, 0.999], n), ys.ravel() + rng.choice([0, 0.5], n),
-                    rng.choice(np.float32([7.0, 7.5, 9.0, 11.3, 12.0, 13.99, 14.8, 14.9, 15.0, 16.0, 17.5]), n)], 1).astype(np.float32)
+                    rng.choice(np.float32([7.0, 7.5, 9.0, 11.3, 12.0, 12.5, 12.56, 12.6, 13.99, 14.8, 14.9, 15.0, 16.0, 17.5]), n)], 1).astype(np.float32)
     rng.shuffle(kps)
     cur, prev = fr[5:], fr[:2]
     desc, valid = gpu_ctx.extract_pairs_host(cur, prev, kps)
@@ -440,11 +440,11 @@ def test_crowded_tiles_and_tile_borders(gpu_ctx, oracle):
     assert np.array_equal(valid, want_v) and np.array_equal(desc, want_d)
     assert valid.sum() > 5000
     gpu_ctx.check_status()
-    # keypoints sitting exactly on tile borders (x = 96k, y = 64k) and one pixel either side
+    # keypoints sitting exactly on tile borders (x = 128k and, the earlier tile width, 96k; y = 64k) and one pixel either side
     W, H = 640, 480
     fr = synth.synth_stack(6, W, H)
-    pts = [(x + dx, y + dy) for x in (96, 192, 288, 384) for y in (64, 128, 192, 256, 320) for dx in (-1, -0.001, 0, 0.5, 1) for dy in (-1, 0, 0.75)]
-    kps = np.float32([[x, y, s] for (x, y) in pts for s in (7.0, 12.0, 14.5)])
+    pts = [(x + dx, y + dy) for x in (96, 128, 192, 256, 288, 384) for y in (64, 128, 192, 256, 320) for dx in (-1, -0.001, 0, 0.5, 1) for dy in (-1, 0, 0.75)]
+    kps = np.float32([[x, y, s] for (x, y) in pts for s in (7.0, 12.0, 12.5, 14.5)])
     desc, valid = gpu_ctx.extract_pairs_host(fr[5:6], fr[0:1], kps)
     want_d, want_v = oracle_pairs(oracle, fr[5:6], fr[0:1], kps)
     assert valid.all() and np.array_equal(valid, want_v) and np.array_equal(desc, want_d)
@@ -453,7 +453,7 @@ def test_crowded_tiles_and_tile_borders(gpu_ctx, oracle):
 @pytest.mark.parametrize("sizes", [(7.0,), (7.0, 7.7), (9.0, 9.9), (12.0,), (7.0, 9.0, 12.0, 14.5)])
 def test_integer_keypoints_every_halo_and_scale(gpu_ctx, oracle, sizes):
     """Keypoints at integer coordinates take the tile kernel's fixed-offset boxes (BoxInt) -- one scale per tile or
-    several, every halo size the pattern sizes select (24, 32, 40, 48), tiles cut by the image border, groups of
+    several, every halo size the pattern sizes select (24, 32, 40; size 14.5 is the gather path's), tiles cut by the image border, groups of
     four that do not fill up, a frame width that is not a multiple of 8 (byte-wise staging) -- and must give the
     float expressions' bits, including the pattern points that sit too close to a rounding boundary."""
     for W, H in ((417, 301), (640, 200)):
