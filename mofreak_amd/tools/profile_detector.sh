@@ -14,7 +14,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/s
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_detector_kernel_stats.csv
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_dd -- python3 $probe 32 6 describe > $out/stats_dd.log 2>&1
 cp $(find $out/stats_dd -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_detector_describe_kernel_stats.csv
-grep -h "pairs=" $out/stats.log $out/stats_dd.log > gpurun_out/${tag}_detector_probe_lines.txt || true
+# the probe's own figures come from plain runs (under the profiler the host side of every launch is slower)
+{ timeout -k 10 120 python3 $probe 32 12; timeout -k 10 120 python3 $probe 32 12 describe; } 2>&1 | grep -h "pairs=" > gpurun_out/${tag}_detector_probe_lines.txt || true
+grep -h "pairs=" $out/stats.log $out/stats_dd.log | sed "s/^/under rocprofv3: /" >> gpurun_out/${tag}_detector_probe_lines.txt || true
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVES" \
