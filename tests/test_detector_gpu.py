@@ -156,6 +156,22 @@ def test_pipelined_frame_loop_rows_equal_the_sequential_loop_and_the_oracle(ctx,
         ctx.set_loop_pipelining(M.api.LOOP_AUTO)
 
 
+def test_default_loop_mode_takes_two_lanes_for_long_stacks(ctx):
+    """MOFREAK_LOOP_AUTO: a stack of more than 128 pairs (two batches) goes over two lanes without being asked to; same rows as
+    the one-lane loop."""
+    T, W, H = 140, 160, 120
+    fr = synth.moving_objects_stack(T, W, H, seed=5)
+    ctx.set_loop_pipelining(M.api.LOOP_AUTO)
+    got = ctx.compute_stream_host(fr)
+    ctx.set_loop_pipelining(M.api.LOOP_ONE_LANE)
+    try:
+        plain = ctx.compute_stream_host(fr)
+    finally:
+        ctx.set_loop_pipelining(M.api.LOOP_AUTO)
+    assert got.tobytes() == plain.tobytes() and len(got) > 500
+    assert got["frame_number"].min() == 4 and got["frame_number"].max() == T - 2
+
+
 def test_pipelined_frame_loop_grows_its_keypoint_buffers(ctx):
     """More keypoints per frame than the batch buffers were made for (8192): reported inside the call, buffers grown, same rows."""
     rng = np.random.default_rng(3)
