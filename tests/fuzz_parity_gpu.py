@@ -37,6 +37,7 @@ def main():
         f = O.Freak(orientation_normalized=bool(par.get("freak_orientation_normalized", 1)),
                     scale_normalized=bool(par.get("freak_scale_normalized", 1)), bit_mode=par.get("freak_bit_mode", O.BITS_SSE))
         t_ctx = min(t_end, time.time() + 20)
+        print(f"... {rounds} rounds, {int(t_end - time.time())} s to go", flush=True)  # (a run that says nothing for minutes looks hung)
         with M.Context(0, **par) as ctx:
           while time.time() < t_ctx:
               W = int(rng.choice([97, 160, 203, 320, 417, 640, 731, 1024, 1283]))
