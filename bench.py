@@ -189,26 +189,18 @@ def detector_figures(ctx, torch, synth, W, H, pairs=32, steps=3, with_cpu=True):
                         "detect_and_describe_frac": (det_bytes + desc_bytes) / both_s / 1e9 / HBM_PEAK_GBS,
                         "note": "host-timed calls (launch gaps included), wall clock around synchronising calls"}}
     # the reference's whole frame loop as ONE call (mofreak_compute_stream: detector -> descriptors -> rows) on a stack of
-    # pairs + 5 frames: as the library chooses by default, and forced onto two lanes / one lane for comparison
-    try:
-        T = pairs + 5
-        stack = torch.from_numpy(np.stack([fr[t % len(fr)] for t in range(T)])).cuda()
-        rows = torch.empty(pairs * 12000 * 32, dtype=torch.uint8, device="cuda")
-        loop = {}
-        from mofreak_amd import api
-        for name, mode in (("two_lanes", api.LOOP_TWO_LANES), ("one_lane", api.LOOP_ONE_LANE), ("default", api.LOOP_AUTO)):  # (the first mode also pays for the buffers)
-            ctx.set_loop_pipelining(mode)
-            ctx.compute_stream(stack, T, W, H, rows, capacity=rows.numel() // 32)
-            ctx.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                n_rows, n_loop_kp = ctx.compute_stream(stack, T, W, H, rows, capacity=rows.numel() // 32)
-            loop[name] = pairs * steps / (time.perf_counter() - t0)
-        out["frame_loop"] = {"pairs_per_s": loop["default"], "two_lanes_pairs_per_s": loop["two_lanes"], "one_lane_pairs_per_s": loop["one_lane"],
-                             "rows_per_pair": n_rows / pairs,
-                             "note": "mofreak_compute_stream on a device-resident stack, rows compacted on the device"}
-    finally:
-        ctx.set_loop_pipelining(1)  # MOFREAK_LOOP_AUTO
+    # pairs + 5 frames
+    T = pairs + 5
+    stack = torch.from_numpy(np.stack([fr[t % len(fr)] for t in range(T)])).cuda()
+    rows = torch.empty(pairs * 12000 * 32, dtype=torch.uint8, device="cuda")
+    ctx.compute_stream(stack, T, W, H, rows, capacity=rows.numel() // 32)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        n_rows, n_loop_kp = ctx.compute_stream(stack, T, W, H, rows, capacity=rows.numel() // 32)
+    out["frame_loop"] = {"pairs_per_s": pairs * steps / (time.perf_counter() - t0), "rows_per_pair": n_rows / pairs,
+                         "note": "mofreak_compute_stream on a device-resident stack, rows compacted on the device"}
+    del stack, rows
     if with_cpu:  # part of the cpu_baseline leg: the oracle as a reported baseline, never as the product
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
@@ -235,11 +227,17 @@ def dist_setup(args):
                          "(one process per GPU; --share-device rehearses N > 1 on one)")
     torch.cuda.set_device(local_rank)
     on_device = args.backend == "nccl"  # gloo moves its (small) control tensors and the gathered rows through the host
-    if world > 1:
+    if world > 1 or args.force_dist:
+        # --force-dist: a one-rank process group, so that every collective and the device branch of the row gather run
+        # exactly as they do at N > 1 (the same code path, RCCL included, on a one-GPU box)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if on_device:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
         assert dist.get_world_size() == world
     return torch, dist, rank, local_rank, world, on_device
 
@@ -256,20 +254,31 @@ def library_id(M):
                 "build_flags": M.load().mofreak_build_flags()}
 
 
+def grouped(dist):
+    """A process group exists (N > 1, or N = 1 with --force-dist)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def ranks_seen(dist, world):
     """What the process group itself says (not the flag): goes into every line."""
-    return dist.get_world_size() if world > 1 else 1
+    return dist.get_world_size() if grouped(dist) else 1
+
+
+def dist_info(dist, args):
+    if not grouped(dist):
+        return {"process_group": None}
+    return {"process_group": {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "forced_at_n1": bool(args.force_dist)}}
 
 
 def fence(torch, dist, world):
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped(dist):
         dist.barrier()
     torch.cuda.synchronize()
 
 
 def max_over_ranks(torch, dist, world, on_device, seconds):
-    if world > 1:
+    if grouped(dist):
         t = torch.tensor([seconds], dtype=torch.float64, device="cuda" if on_device else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
@@ -339,7 +348,7 @@ def bench_resident(args):
     if not full_leg:
         verify_sample(ver, frames, kps, sorted({0, n_pairs // 3, (2 * n_pairs) // 3, n_pairs - 1})[: max(1, args.verify_pairs)])
     ver_all = [ver.pairs, ver.descriptors, ver.mismatches]
-    if world > 1:  # the line carries the sum over ranks
+    if grouped(dist):  # the line carries the sum over ranks
         t = torch.tensor(ver_all, dtype=torch.int64, device="cuda" if on_device else "cpu")
         dist.all_reduce(t)
         ver_all = [int(x) for x in t.tolist()]
@@ -348,7 +357,7 @@ def bench_resident(args):
     rows = torch.empty(n_desc * 32, dtype=torch.uint8, device="cuda")
     n_rows = ctx.compact_rows(d_kps, n_pairs, gap - 1, desc, valid, rows)
     gather_ms = None
-    if world > 1:
+    if grouped(dist):
         fence(torch, dist, world)
         tg = time.perf_counter()
         allrows, counts = harness.gather_rows(rows if on_device else rows.cpu(), n_rows, dst=0)
@@ -369,9 +378,16 @@ def bench_resident(args):
         pipeline_gbs = b_alg_pair * prof["pairs"] / (all_ms * 1e-3) / 1e9
         traffic = None
         valu = None
+        counters_note = None
+        lib = library_id(M)
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and args.config == "C3":
             tj = json.load(open(tpath))
+            if tj.get("library_sha256_16") != lib["sha256_16"]:
+                # counters of another build say nothing about this one: the line carries none rather than stale ones
+                counters_note = (f"profiles/traffic.json was collected on build {tj.get('library_sha256_16')}, this is {lib['sha256_16']}: "
+                                 "traffic and valu_issue withheld (rerun mofreak_amd/tools/profile_tile.sh)")
+                tj = {}
             traffic = tj.get("tile_kernel_hbm_bytes_per_launch")
             if tj.get("valu_wave_instr_per_descriptor"):
                 # What bounds the kernel is vector instruction issue and LDS cycles, not bytes: instructions per descriptor
@@ -400,16 +416,19 @@ def bench_resident(args):
                                    f"{n_kp} keypoints/pair of size {cfg['size']}, 16-byte descriptors",
                        "descriptors_per_step_per_gpu": n_desc, "bit_mode": "SSE", "parallelism": f"one stack per GPU x{world}"},
             "timed_region_s": elapsed,
-            "roofline": {"bound": "hbm", "kernel": "tile_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "bound_observed": "valu+lds (vector issue and LDS cycles: valu_issue below; the HBM fraction is the metric's figure, "
+                                                           "not what limits this kernel)",
+                         "kernel": "tile_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "copy_ceiling_GBs": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs if copy_gbs else None,
                          "algorithmic_bytes_per_pair": b_alg_pair, "pairs_per_launch": pairs_per_launch,
                          "avg_launch_ms": tile_ms_avg, "launches_timed": prof["calls"],
                          "binning_avg_ms": prof["bin_ms"] / launches, "gather_path_avg_ms": prof["gather_ms"] / launches,
                          "pipeline_achieved_GBs": pipeline_gbs, "pipeline_frac": pipeline_gbs / HBM_PEAK_GBS,
-                         "valu_issue": valu},
-            "gather_ms": gather_ms, "ranks_seen": ranks_seen(dist, world), "library": library_id(M),
+                         "valu_issue": valu, "counters_note": counters_note},
+            "gather_ms": gather_ms, "ranks_seen": ranks_seen(dist, world), "library": lib,
         }
+        out.update(dist_info(dist, args))
         if full_leg:
             cp = min(args.cpu_pairs, n_pairs)
             out.update(cpu_baselines(frames, kps, cp, cores=min(ncpu, 16), shape=f"{W}x{H}", ver=ver))
@@ -421,14 +440,15 @@ def bench_resident(args):
             try:
                 out["detector"] = detector_figures(ctx, torch, synth, W, H, with_cpu=not args.no_cpu_baseline)
                 # the detector's tie rounds are chains of short launches per call: more pairs per call share them
-                big = detector_figures(ctx, torch, synth, W, H, pairs=128, steps=2, with_cpu=False)
-                out["detector"]["at_128_pairs_per_call"] = {k: big[k] for k in ("pairs_per_s", "detect_and_describe_pairs_per_s", "frame_loop")}
+                for big_pairs in (128, 256):
+                    big = detector_figures(ctx, torch, synth, W, H, pairs=big_pairs, steps=2, with_cpu=False)
+                    out["detector"][f"at_{big_pairs}_pairs_per_call"] = {k: big[k] for k in ("pairs_per_s", "detect_and_describe_pairs_per_s", "frame_loop")}
             except Exception as e:  # never let the side figure take the metric line down
                 out["detector"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     ctx.set_stream(None)
     ctx.close()
-    if world > 1:
+    if grouped(dist):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and failed:
@@ -481,11 +501,11 @@ def bench_dataset(args):
                            "every rank's clips in ONE pipelined mofreak_extract_clips call, rows gathered device to device" if res["batched"]
                            else f"{args.workers} host thread(s) with a context each per rank, one synchronous C-ABI call per clip")},
             "frames_in_GBs": float(lengths.sum() * W * H * steps / elapsed / 1e9),
-            "gather_ms": gather_s * 1e3, "ranks_seen": ranks_seen(dist, world), "frames_in_MB_per_step": float(lengths.sum() * W * H / 1e6),
+            "gather_ms": gather_s * 1e3, "ranks_seen": ranks_seen(dist, world), **dist_info(dist, args), "rounds": res["rounds"], "frames_in_MB_per_step": float(lengths.sum() * W * H / 1e6),
             "note": f"host frames in ({'pageable' if args.pageable else 'page-locked'} memory) -> rows on rank 0's host; "
                     "compute, gather and the root's device-to-host copy are all inside the timed region"}), flush=True)
     mo.close()
-    if world > 1:
+    if grouped(dist):
         dist.barrier()
         dist.destroy_process_group()
 
@@ -548,13 +568,13 @@ def bench_stream(args):
             "config": {"workload": f"C5: one {W}x{H} stream of {T} frames per GPU from page-locked host memory, dense {cfg['step']}-px grid, "
                                    f"{len(kps)} keypoints/frame, chunks of {args.chunk} frames", "descriptors_per_step_per_gpu": n_desc,
                        "parallelism": f"one stream per GPU x{world}"},
-            "ranks_seen": ranks_seen(dist, world), "frames_per_s": world * (T - 5) * steps / elapsed, "resident_descriptors_per_s": resident,
+            "ranks_seen": ranks_seen(dist, world), **dist_info(dist, args), "frames_per_s": world * (T - 5) * steps / elapsed, "resident_descriptors_per_s": resident,
             "pcie_bound_descriptors_per_s": pcie_bound, "frac_of_min_bound": value / world / min(pcie_bound, resident),
             "h2d_GBs": (T * W * H * steps / elapsed) / 1e9, "d2h_GBs": (n_desc * 32 * steps / elapsed) / 1e9}), flush=True)
     ctx.host_free(frames)
     ctx.host_free(rows)
     ctx.close()
-    if world > 1:
+    if grouped(dist):
         dist.barrier()
         dist.destroy_process_group()
 
@@ -579,6 +599,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL); 'gloo' + "
                     "--share-device rehearses the N > 1 control flow on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
+    ap.add_argument("--force-dist", action="store_true", help="--gpus 1: create a one-rank process group of --backend anyway, so that the collectives and "
+                    "the device branch of the row gather (RCCL with the default backend) run as they do at N > 1")
     ap.add_argument("--no-detector", action="store_true", help="skip the (untimed-region) keypoint detector figures")
     ap.add_argument("--verify-pairs", type=int, default=4, help="pairs per rank checked against the oracle when there is no "
                     "cpu_baseline leg (N > 1, --no-cpu-baseline); with the leg, all of its pairs are checked")

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MOFREAK_ABI_VERSION 2
+#define MOFREAK_ABI_VERSION 3
 
 /* status codes */
 #define MOFREAK_OK 0
@@ -128,19 +128,6 @@ int mofreak_check_status(mofreak_ctx *ctx);
 #define MOFREAK_PATH_AUTO 0
 #define MOFREAK_PATH_GATHER 1
 int mofreak_set_path(mofreak_ctx *ctx, int path);
-/* mofreak_compute_stream's two-lane loop (the batches of a stack alternate between two streams, the detector of one beside
- * the descriptors of the other).  The rows do not depend on it.
- *   MOFREAK_LOOP_AUTO (default)  two lanes when the stack needs more than one batch of 128 pairs anyway -- where they were
- *                                measured to pay (1920x1080: +20 % at 256 pairs; 640x480: +6 % at 512) -- one lane below
- *                                (two half-size batches cost the detector more than the overlap returns: -14 % at 32 pairs
- *                                of 640x480)
- *   MOFREAK_LOOP_ONE_LANE        one batch after the other on the context's stream
- *   MOFREAK_LOOP_TWO_LANES       two lanes from 16 pairs up (tests, A/B measurements) */
-#define MOFREAK_LOOP_ONE_LANE 0
-#define MOFREAK_LOOP_AUTO 1
-#define MOFREAK_LOOP_TWO_LANES 2
-int mofreak_set_loop_pipelining(mofreak_ctx *ctx, int mode);
-
 /* Per-call device timing, measured with HIP events on the context's stream around the binning kernels, the tile
  * kernel and the gather path of every extract call.  Off by default. */
 typedef struct mofreak_profile {
@@ -280,9 +267,7 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
  * stack already in memory: for every frame from index gap on, BRISK keypoints on |frame - frame[-gap]|
  * (mofreak_detect_pairs), their MoFREAK descriptors (mofreak_extract_pairs) and the rows FREAK did not erase, in the
  * order the reference appends them (mofreak_compact_rows).  Equivalent to those three calls; frames cross the host
- * boundary once.  Synchronises the stream.  From 16 processed frames up the loop is software pipelined: the frames are
- * taken in batches and the detector of batch k + 1 runs on one HIP stream beside the descriptors of batch k on another
- * (the detector is bound by vector issue, the descriptors of large keypoints by memory latency); the rows are the same.
+ * boundary once.  Synchronises the stream.
  */
 int mofreak_compute_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W, int H, int threshold, int octaves,
                            mofreak_row *rows_out, int64_t rows_capacity, int64_t *n_rows_out, int64_t *n_keypoints_out,

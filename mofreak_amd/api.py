@@ -23,7 +23,6 @@ BITS_SSE, BITS_NATURAL, BITS_SSE_SIGNED = 0, 1, 2
 FP_X87, FP_SSE = 0, 1  # mofreak_params.brisk_fp_model
 TABLES_ONLY = -1
 PATH_AUTO, PATH_GATHER = 0, 1
-LOOP_ONE_LANE, LOOP_AUTO, LOOP_TWO_LANES = 0, 1, 2
 
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4")])
 ROW_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("frame_number", "<i4"), ("scale", "<f4"),
@@ -34,7 +33,7 @@ assert ROW_DTYPE.itemsize == 32
 EXPORTS = [
     "mofreak_abi_version", "mofreak_build_flags", "mofreak_default_params", "mofreak_create", "mofreak_destroy", "mofreak_last_error",
     "mofreak_set_stream", "mofreak_synchronize", "mofreak_reserve", "mofreak_check_status",
-    "mofreak_set_profiling", "mofreak_get_profile", "mofreak_set_path", "mofreak_set_loop_pipelining", "mofreak_get_tile_stamps", "mofreak_bgr_to_gray", "mofreak_bow_assign", "mofreak_bow_histogram",
+    "mofreak_set_profiling", "mofreak_get_profile", "mofreak_set_path", "mofreak_get_tile_stamps", "mofreak_bgr_to_gray", "mofreak_bow_assign", "mofreak_bow_histogram",
     "mofreak_extract_pairs", "mofreak_compact_rows", "mofreak_extract_stream", "mofreak_format_rows",
     "mofreak_extract_stream_pipelined", "mofreak_extract_clips", "mofreak_host_alloc", "mofreak_host_free",
     "mofreak_parse_rows", "mofreak_diff_integral", "mofreak_mip19", "mofreak_roi19", "mofreak_freak_info",
@@ -101,7 +100,6 @@ def load() -> C.CDLL:
     L.mofreak_check_status.argtypes = [vp]
     L.mofreak_set_profiling.argtypes = [vp, i32]
     L.mofreak_set_path.argtypes = [vp, i32]
-    L.mofreak_set_loop_pipelining.argtypes = [vp, i32]
     L.mofreak_get_tile_stamps.argtypes = [vp, vp, i32, i32]
     L.mofreak_get_profile.argtypes = [vp, C.POINTER(Profile), i32]
     L.mofreak_bgr_to_gray.argtypes = [vp, vp, i32, i32, i64, i64, i32, vp, C.c_uint]
@@ -247,12 +245,6 @@ class Context:
     def set_path(self, path: int):
         """PATH_AUTO (tile kernel + gather path for large keypoints) or PATH_GATHER (gather path for everything)."""
         self._check(self._lib.mofreak_set_path(self._h, path))
-
-    def set_loop_pipelining(self, mode):
-        """compute_stream's two-lane loop: LOOP_AUTO (default: stacks of more than 128 pairs), LOOP_ONE_LANE, LOOP_TWO_LANES
-        (from 16 pairs up).  True / False are taken as LOOP_TWO_LANES / LOOP_ONE_LANE."""
-        mode = LOOP_TWO_LANES if mode is True else LOOP_ONE_LANE if mode is False else int(mode)
-        self._check(self._lib.mofreak_set_loop_pipelining(self._h, mode))
 
     def get_tile_stamps(self, reset: bool = True) -> np.ndarray:
         out = np.zeros(32, np.uint64)

@@ -63,18 +63,6 @@ struct mofreak_ctx {
         DeviceBuffer d_frames[2], d_rows[2], d_pair_rows[2];
         bool ready = false;
     } pipe;
-    // mofreak_compute_stream on two lanes (this context and `helper`): a lane's stream, events and batch buffers
-    struct Loop {
-        hipStream_t s_lane = nullptr, s_copy = nullptr;
-        hipEvent_t ev_det{}, ev_copy{}, ev_rows{};
-        DeviceBuffer kps, offs, counters;  // counters (lane 0 only): [0] rows so far, the device-side row base
-        int64_t *h_off = nullptr;          // page-locked copy of a batch's CSR offsets (+ the detector's status word)
-        size_t h_off_entries = 0;
-        int64_t kp_per_pair = 8192;        // room per pair in kps; grown when a batch needs more
-        bool ready = false;
-    } loop;
-    mofreak_ctx *helper = nullptr;         // lane 1: a context of its own (stream, workspaces), created on first use
-    int loop_mode = MOFREAK_LOOP_AUTO;  // mofreak_set_loop_pipelining
     int path_mode = MOFREAK_PATH_AUTO;
     int chunk_pairs_hint = 0;
     // optional per-launch timing (mofreak_set_profiling): events around the integral group and the describe launch
@@ -682,19 +670,6 @@ void mofreak_destroy(mofreak_ctx *ctx)
         release(ctx->pipe.d_pair_rows[b]);
     }
     release(ctx->pair_label);
-    if (ctx->helper) mofreak_destroy(ctx->helper);
-    ctx->helper = nullptr;
-    release(ctx->loop.kps);
-    release(ctx->loop.offs);
-    release(ctx->loop.counters);
-    if (ctx->loop.h_off) (void)hipHostFree(ctx->loop.h_off);
-    if (ctx->loop.ready) {
-        for (hipStream_t st : {ctx->loop.s_lane, ctx->loop.s_copy}) {
-            (void)hipStreamSynchronize(st);
-            (void)hipStreamDestroy(st);
-        }
-        for (hipEvent_t ev : {ctx->loop.ev_det, ctx->loop.ev_copy, ctx->loop.ev_rows}) (void)hipEventDestroy(ev);
-    }
     if (ctx->pipe.ready) {
         (void)hipStreamSynchronize(ctx->pipe.s_in);
         (void)hipStreamSynchronize(ctx->pipe.s_out);
@@ -772,14 +747,6 @@ int mofreak_reserve(mofreak_ctx *ctx, int W, int H, int chunk_pairs)
     int rc = ensure(ctx, ctx->integral, (size_t)chunk * (H + 1) * pitch * sizeof(int32_t));
     if (rc) return rc;
     return ensure(ctx, ctx->band_totals, (size_t)chunk * n_bands * pitch * sizeof(int32_t));
-}
-
-int mofreak_set_loop_pipelining(mofreak_ctx *ctx, int enable)
-{
-    if (!ctx) return MOFREAK_ERR_BAD_ARG;
-    if (enable < MOFREAK_LOOP_ONE_LANE || enable > MOFREAK_LOOP_TWO_LANES) return fail(ctx, MOFREAK_ERR_BAD_ARG, "loop mode must be 0, 1 or 2");
-    ctx->loop_mode = enable;
-    return MOFREAK_OK;
 }
 
 int mofreak_set_path(mofreak_ctx *ctx, int path)
@@ -1848,215 +1815,6 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
 
 }  // extern "C"
 
-namespace {
-
-int loop_setup(mofreak_ctx *ctx)
-{
-    mofreak_ctx::Loop &L = ctx->loop;
-    if (L.ready) return MOFREAK_OK;
-    hipStream_t st[2] = {};
-    hipEvent_t ev[3] = {};
-    hipError_t e = hipSuccess;
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking);
-    for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
-    if (e != hipSuccess) {
-        for (auto v : ev)
-            if (v) (void)hipEventDestroy(v);
-        for (auto v : st)
-            if (v) (void)hipStreamDestroy(v);
-        return fail(ctx, MOFREAK_ERR_HIP, std::string("frame-loop pipeline setup: ") + hipGetErrorString(e));
-    }
-    L.s_lane = st[0];
-    L.s_copy = st[1];
-    L.ev_det = ev[0];
-    L.ev_copy = ev[1];
-    L.ev_rows = ev[2];
-    L.ready = true;
-    return MOFREAK_OK;
-}
-
-// The kernels of extract_device go to ctx->stream: run a group of launches on another stream.
-struct StreamSwap {
-    mofreak_ctx *ctx;
-    hipStream_t saved;
-    StreamSwap(mofreak_ctx *c, hipStream_t s) : ctx(c), saved(c->stream) { c->stream = s; }
-    ~StreamSwap() { ctx->stream = saved; }
-};
-
-struct LoopDrain {  // every exit of the two-lane loop waits for both lanes
-    mofreak_ctx *lane[2];
-    ~LoopDrain()
-    {
-        for (mofreak_ctx *c : lane) {
-            (void)hipStreamSynchronize(c->loop.s_lane);
-            (void)hipStreamSynchronize(c->loop.s_copy);
-        }
-    }
-};
-
-// The frame loop of computeMoFREAKFromFile (MoFREAKUtilities.cpp:391-491) over a device-resident stack on TWO LANES.
-// The pairs are taken in batches that alternate between the lanes; a lane runs detector -> descriptors -> row compaction
-// of its batches one after the other on a stream of its own, with workspaces of its own (lane 1 is a helper context).
-// Both chains are made of kernels that wait -- the detector's tie rounds and refinement on memory latency, the gather
-// path of the descriptors on scattered fetches -- next to kernels that keep the vector pipes busy (the corner scores):
-// two chains side by side fill each other's gaps (measured: +29 % detector alone, +19 % descriptors alone, +34 %
-// both, mofreak_amd/tools/overlap_probe.py).  The one host round trip per batch is the copy of its CSR offsets (the
-// descriptor launches are sized from the keypoint count); rows are appended behind a device-side row counter, the
-// compactions of consecutive batches ordered by an event.
-// Returns MOFREAK_ERR_CAPACITY with *need_per_pair set when a batch had more keypoints than its buffer holds.
-int compute_two_lanes(mofreak_ctx *ctx, const uint8_t *d_frames, int n_pairs, int W, int H, int threshold, int octaves, int batch,
-                      mofreak_row *d_rows, int64_t rows_capacity, int64_t *total_rows, int64_t *total_kp, int64_t *need_per_pair)
-{
-    const int gap = ctx->params.gap_for_frame_difference;
-    const int64_t fsz = (int64_t)W * H;
-    const Geometry geo{W, H, W, fsz};
-    DetGeom g;
-    int rc = det_geometry(ctx, W, H, octaves, g);
-    if (rc) return rc;
-    if ((rc = validate_frames(ctx, d_frames, d_frames, W, H, W, fsz, n_pairs))) return rc;
-    if (!ctx->helper) {
-        rc = mofreak_create(ctx->device, &ctx->params, &ctx->helper);
-        if (rc) return fail(ctx, rc, std::string("second lane: ") + mofreak_last_error(nullptr));
-    }
-    mofreak_ctx *lane[2] = {ctx, ctx->helper};
-    lane[1]->path_mode = ctx->path_mode;
-    lane[1]->det_cand_cap = ctx->det_cand_cap;
-    lane[1]->loop.kp_per_pair = ctx->loop.kp_per_pair;
-    const int64_t kp_cap = ctx->loop.kp_per_pair * batch;
-    DetArgs a[2] = {};
-    for (int i = 0; i < 2; ++i) {
-        mofreak_ctx *c = lane[i];
-        mofreak_ctx::Loop &L = c->loop;
-        auto up = [&](int r) { return r && c != ctx ? fail(ctx, r, c->err) : r; };  // a helper's message goes to the caller's context
-        if ((rc = up(loop_setup(c)))) return rc;
-        if ((rc = up(ensure(c, L.kps, (size_t)kp_cap * sizeof(mofreak_keypoint))))) return rc;
-        if ((rc = up(ensure(c, L.offs, (size_t)(batch + 1) * sizeof(int64_t))))) return rc;
-        if (L.h_off_entries < (size_t)batch + 2) {
-            if (L.h_off) {
-                void *old = L.h_off;
-                L.h_off = nullptr;
-                L.h_off_entries = 0;
-                HIP_TRY(ctx, hipHostFree(old));
-            }
-            HIP_TRY(ctx, hipHostMalloc((void **)&L.h_off, ((size_t)batch + 2) * sizeof(int64_t), hipHostMallocDefault));
-            L.h_off_entries = (size_t)batch + 2;
-        }
-        if ((rc = up(ensure(c, c->scratch_desc, (size_t)kp_cap * 16)))) return rc;
-        if ((rc = up(ensure(c, c->scratch_valid, (size_t)kp_cap)))) return rc;
-        if ((rc = up(ensure(c, c->compact_offsets, ((size_t)(kp_cap + kCompactItemsPerBlock - 1) / kCompactItemsPerBlock + 1) * sizeof(int64_t))))) return rc;
-        if ((rc = up(det_workspace(c, g, batch, a[i])))) return rc;  // (uploads the geometry on c->stream from a[i].g)
-        HIP_TRY(ctx, hipMemsetAsync(c->d_status + 1, 0, sizeof(int32_t), c->stream));
-        a[i].threshold = threshold;
-        a[i].safe_threshold = (int)(uint8_t)((float)threshold * 1.0f);  // safeThreshold_ = threshold_ * safetyFactor_ (brisk.cpp:58, 597)
-        a[i].out_response = nullptr;
-        a[i].out_layer = nullptr;
-        a[i].out_capacity = kp_cap;
-        a[i].first_pair = 0;
-        a[i].out_kps = static_cast<mofreak_keypoint *>(L.kps.ptr);
-        a[i].out_offsets = static_cast<int64_t *>(L.offs.ptr);
-    }
-    if ((rc = ensure(ctx, ctx->loop.counters, 64))) return rc;
-    int64_t *row_base = static_cast<int64_t *>(ctx->loop.counters.ptr);
-    HIP_TRY(ctx, hipMemsetAsync(row_base, 0, 64, ctx->stream));
-    for (mofreak_ctx *c : lane) HIP_TRY(ctx, hipStreamSynchronize(c->stream));  // set up; the caller's earlier work on ctx->stream is done too
-    LoopDrain drain{{lane[0], lane[1]}};
-    const int n_batches = (n_pairs + batch - 1) / batch;
-
-    auto enqueue_detect = [&](int k) -> int {
-        mofreak_ctx *c = lane[k & 1];
-        mofreak_ctx::Loop &L = c->loop;
-        DetArgs &d = a[k & 1];
-        const int p0 = k * batch, np = std::min(batch, n_pairs - p0);
-        int64_t *running = static_cast<int64_t *>(c->det_rows.ptr);
-        HIP_TRY(ctx, hipMemsetAsync(running, 0, 16 + c->det_counter_bytes, L.s_lane));  // behind this lane's batch k - 2 (same stream)
-        d.n_pairs = np;
-        d.f = FrameArgs{d_frames + (int64_t)(gap + p0) * fsz, d_frames + (int64_t)p0 * fsz, W, H, W, fsz};
-        int e = launch_det_pyramid(d, L.s_lane);
-        if (!e) e = launch_det_scores(d, L.s_lane);
-        if (!e) e = launch_det_keypoints(d, running, L.s_lane);
-        if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("detector launch: ") + hipGetErrorString((hipError_t)e));
-        HIP_TRY(ctx, hipEventRecord(L.ev_det, L.s_lane));
-        HIP_TRY(ctx, hipStreamWaitEvent(L.s_copy, L.ev_det, 0));
-        HIP_TRY(ctx, hipMemcpyAsync(L.h_off, L.offs.ptr, (size_t)(np + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, L.s_copy));
-        HIP_TRY(ctx, hipMemcpyAsync(L.h_off + batch + 1, c->d_status + 1, sizeof(int32_t), hipMemcpyDeviceToHost, L.s_copy));
-        HIP_TRY(ctx, hipEventRecord(L.ev_copy, L.s_copy));
-        return MOFREAK_OK;
-    };
-
-    int64_t kp_sum = 0;
-    if ((rc = enqueue_detect(0))) return rc;
-    if (n_batches > 1 && (rc = enqueue_detect(1))) return rc;
-    for (int k = 0; k < n_batches; ++k) {
-        mofreak_ctx *c = lane[k & 1];
-        mofreak_ctx::Loop &L = c->loop;
-        const int p0 = k * batch, np = std::min(batch, n_pairs - p0);
-        HIP_TRY(ctx, hipEventSynchronize(L.ev_copy));
-        const int64_t *h_off = L.h_off;
-        const int64_t n_kp = h_off[np];
-        const int32_t st = (int32_t)h_off[batch + 1];
-        if (st & 16) return fail(ctx, MOFREAK_ERR_HIP, "detector: a refinement walk left its staged window (internal error)");
-        if (st & 32) return fail(ctx, MOFREAK_ERR_HIP, "detector: a chain of tied scores did not resolve within its pass budget (internal error)");
-        if (st & 4) return fail(ctx, MOFREAK_ERR_CAPACITY, "more corner candidates in one pair than the detector reserved (mofreak_detect_set_capacity)");
-        if ((st & 8) || n_kp > kp_cap) {
-            if (need_per_pair) *need_per_pair = (n_kp + np - 1) / np;
-            return fail(ctx, MOFREAK_ERR_CAPACITY, "a batch of the frame loop found more keypoints than its buffer holds");
-        }
-        kp_sum += n_kp;
-        if (n_kp > 0) {
-            StreamSwap on_lane(c, L.s_lane);  // (the host has seen ev_copy, which follows ev_det: the keypoints are there)
-            const mofreak_keypoint *kps = static_cast<const mofreak_keypoint *>(L.kps.ptr);
-            const int64_t *d_off = static_cast<const int64_t *>(L.offs.ptr);
-            uint8_t *desc = static_cast<uint8_t *>(c->scratch_desc.ptr), *valid = static_cast<uint8_t *>(c->scratch_valid.ptr);
-            rc = extract_device(c, d_frames + (int64_t)(gap + p0) * fsz, d_frames + (int64_t)p0 * fsz, geo, np, kps, d_off, h_off, n_kp, desc, valid,
-                                nullptr, nullptr);
-            if (rc) return c != ctx ? fail(ctx, rc, c->err) : rc;
-            if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(L.s_lane, lane[(k - 1) & 1]->loop.ev_rows, 0));  // rows of batch k - 1 first
-            const int n_blocks = (int)((n_kp + kCompactItemsPerBlock - 1) / kCompactItemsPerBlock);
-            CompactArgs cp;
-            cp.kps = kps;
-            cp.kp_offsets = d_off;
-            cp.n_kp = n_kp;
-            cp.n_items = n_kp;
-            cp.n_pairs = np;
-            cp.first_frame_number = gap - 1 + p0;  // labels run on across the batches (:401, :488)
-            cp.desc = desc;
-            cp.valid = valid;
-            cp.rows = d_rows;
-            cp.capacity = rows_capacity;
-            cp.block_offsets = static_cast<int64_t *>(c->compact_offsets.ptr);
-            cp.n_blocks = n_blocks;
-            cp.row_base = row_base;
-            const int e = launch_compact(cp, L.s_lane);
-            if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("compact launch: ") + hipGetErrorString((hipError_t)e));
-        } else if (k > 0) {
-            HIP_TRY(ctx, hipStreamWaitEvent(L.s_lane, lane[(k - 1) & 1]->loop.ev_rows, 0));  // keep the chain of row events whole
-        }
-        HIP_TRY(ctx, hipEventRecord(L.ev_rows, L.s_lane));
-        if (k + 2 < n_batches && (rc = enqueue_detect(k + 2))) return rc;  // this lane's next batch, behind what was just queued
-    }
-    for (mofreak_ctx *c : lane) HIP_TRY(ctx, hipStreamSynchronize(c->loop.s_lane));
-    {  // what the helper lane's descriptor kernels flagged (ROI left the image, ...) belongs to the caller's context:
-       // mofreak_check_status(ctx) reads ctx's word only
-        int32_t theirs = 0, ours = 0;
-        HIP_TRY(ctx, hipMemcpy(&theirs, lane[1]->d_status, sizeof(int32_t), hipMemcpyDeviceToHost));
-        if (theirs) {
-            HIP_TRY(ctx, hipMemcpy(&ours, ctx->d_status, sizeof(int32_t), hipMemcpyDeviceToHost));
-            ours |= theirs;
-            theirs = 0;
-            HIP_TRY(ctx, hipMemcpy(ctx->d_status, &ours, sizeof(int32_t), hipMemcpyHostToDevice));
-            HIP_TRY(ctx, hipMemcpy(lane[1]->d_status, &theirs, sizeof(int32_t), hipMemcpyHostToDevice));
-        }
-    }
-    int64_t rows = 0;
-    HIP_TRY(ctx, hipMemcpy(&rows, row_base, sizeof(int64_t), hipMemcpyDeviceToHost));
-    *total_rows = rows;
-    *total_kp = kp_sum;
-    if (rows > rows_capacity) return fail(ctx, MOFREAK_ERR_CAPACITY, "rows_out too small: need " + std::to_string(rows));
-    return MOFREAK_OK;
-}
-
-}  // namespace
-
 extern "C" {
 
 int mofreak_compute_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W, int H, int threshold, int octaves, mofreak_row *rows_out,
@@ -2083,28 +1841,6 @@ int mofreak_compute_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W
     if (host) {
         if ((rc = ensure(ctx, ctx->stage[5], (size_t)std::max<int64_t>(rows_capacity, 1) * sizeof(mofreak_row)))) return rc;
         d_rows = static_cast<mofreak_row *>(ctx->stage[5].ptr);
-    }
-    // The two-lane loop: batches as large as two lanes allow (the detector's tie rounds are chains of short launches: the
-    // more pairs share them the better), up to 128 pairs.  By default only for stacks that need more than one such batch
-    // anyway (include/mofreak_hip.h has the measurements); forced: from 16 pairs up.
-    const int batch = n_pairs >= 16 ? std::min((n_pairs + 1) / 2, 128) : 0;
-    const bool two_lanes = ctx->loop_mode == MOFREAK_LOOP_TWO_LANES || (ctx->loop_mode == MOFREAK_LOOP_AUTO && n_pairs > 128);
-    if (batch > 0 && two_lanes) {
-        int64_t total = 0, n_kp = 0;
-        for (int attempt = 0;; ++attempt) {
-            int64_t need = 0;
-            rc = compute_two_lanes(ctx, d_frames, n_pairs, W, H, threshold, octaves, batch, d_rows, rows_capacity, &total, &n_kp, &need);
-            if (rc == MOFREAK_ERR_CAPACITY && need > ctx->loop.kp_per_pair && attempt == 0) {
-                ctx->loop.kp_per_pair = need + need / 4;  // this stream has more keypoints per frame than the buffers were made for
-                continue;
-            }
-            break;
-        }
-        if (n_keypoints_out) *n_keypoints_out = n_kp;
-        if (n_rows_out) *n_rows_out = total;
-        if (rc) return rc;
-        if (host && total) HIP_TRY(ctx, hipMemcpy(rows_out, d_rows, (size_t)total * sizeof(mofreak_row), hipMemcpyDeviceToHost));
-        return MOFREAK_OK;
     }
     // keypoints: room for what the last call needed (at least 4096 per pair), grown once if this stream has more
     int64_t n_kp = 0;

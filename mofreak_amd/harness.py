@@ -256,12 +256,21 @@ def compute_mofreak_files(video_paths: Sequence[str], out_dir: str, mofreak: MoF
     return written
 
 
+def group_exists() -> bool:
+    """A torch.distributed process group has been initialised in this process (any world size, 1 included)."""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return False
+    return dist.is_available() and dist.is_initialized()
+
+
 def _pinned_rows(mofreak, n_rows: int) -> np.ndarray:
-    """A page-locked row buffer of at least n_rows rows, kept on the instance (page-locking memory is slow)."""
+    """A page-locked row buffer of at least n_rows rows, kept on the instance (page-locking memory is slow).  When it has
+    to grow, the old buffer is only let go of: its pages are released with the last view of it (api.host_alloc), so rows
+    a caller still holds from an earlier call stay readable."""
     buf = getattr(mofreak, "_row_buf", None)
     if buf is None or len(buf) < n_rows:
-        if buf is not None:
-            mofreak._ctx.host_free(buf)
         buf = mofreak._row_buf = mofreak._ctx.host_alloc((max(n_rows, 1),), api.ROW_DTYPE)
     return buf
 
@@ -274,24 +283,114 @@ def _pinned_bytes(mofreak, n: int):
     return buf[:n]
 
 
+def plan_batches(shard: Sequence[int], nbytes: Sequence[int], batch_bytes: int) -> list[list[int]]:
+    """A rank's videos (ascending) cut into consecutive batches of at most batch_bytes of frames (at least one video
+    each): what is loaded, extracted, gathered, written and let go of together.  Host memory, HBM and the amount of work
+    a crash can lose are bounded by the batch, not by the dataset."""
+    out: list[list[int]] = []
+    cur: list[int] = []
+    acc = 0
+    for i in shard:
+        if cur and acc + nbytes[i] > batch_bytes:
+            out.append(cur)
+            cur, acc = [], 0
+        cur.append(i)
+        acc += nbytes[i]
+    if cur:
+        out.append(cur)
+    return out
+
+
+def _extract_batch(mofreak, stacks, use_batched: bool, to_device, workers: int):
+    """Rows of one batch of clips, clip after clip.  Returns (rows, n_rows, per-clip counts): rows is a uint8 CUDA tensor
+    when to_device is a device (batched mode only), else a ROW_DTYPE array.  Clips of different frame sizes are handed to
+    mofreak_extract_clips size by size (it takes one W x H per call) and their rows put back in the batch's clip order."""
+    import torch
+
+    if not stacks:
+        return (torch.empty(0, dtype=torch.uint8, device=to_device) if to_device is not None else np.zeros(0, api.ROW_DTYPE)), 0, []
+    if not use_batched:
+        if workers > 1 and len(stacks) > 1:
+            import queue
+            from concurrent.futures import ThreadPoolExecutor
+
+            pool = queue.SimpleQueue()
+            for m in mofreak.workers(min(workers, len(stacks))):
+                pool.put(m)
+
+            def one(st):
+                m = pool.get()  # an instance nobody else is using
+                try:
+                    return m.extract_rows(st)
+                finally:
+                    pool.put(m)
+
+            with ThreadPoolExecutor(max_workers=min(workers, len(stacks))) as ex:
+                parts = list(ex.map(one, stacks))  # in clip order, whichever thread did what
+        else:
+            parts = [mofreak.extract_rows(st) for st in stacks]
+        rows = np.concatenate(parts) if parts else np.zeros(0, api.ROW_DTYPE)
+        return rows, len(rows), [len(p) for p in parts]
+    # batched: one pipelined call per frame size
+    gap = mofreak._ctx.params.gap_for_frame_difference
+    prov = mofreak.keypoint_provider
+    sizes: dict[tuple[int, int], list[int]] = {}
+    for j, st in enumerate(stacks):
+        sizes.setdefault((st.shape[1], st.shape[2]), []).append(j)
+    counts = [0] * len(stacks)
+    pieces = []  # (rows of the group, offsets, member indices)
+    for (H, W), members in sizes.items():
+        kps = prov(gap, W, H)
+        group = [stacks[j] for j in members]
+        cap = int(sum(max(s.shape[0] - gap, 0) for s in group)) * len(kps)
+        if to_device is not None:
+            buf = torch.empty(max(cap, 1) * 32, dtype=torch.uint8, device=to_device)
+            n_rows, offs = mofreak._ctx.extract_clips(group, kps, rows_out=buf)
+        elif len(sizes) == 1:
+            # the rows are wanted on this host: they travel back window by window under the pipeline's kernels, into
+            # page-locked memory kept across calls
+            buf, offs = mofreak._ctx.extract_clips(group, kps, rows_out=_pinned_rows(mofreak, cap))
+        else:
+            buf, offs = mofreak._ctx.extract_clips(group, kps)
+        for k, j in enumerate(members):
+            counts[j] = int(offs[k + 1] - offs[k])
+        pieces.append((buf, offs, members))
+    total = int(sum(counts))
+    if len(pieces) == 1:
+        return pieces[0][0], total, counts
+    seg = {}
+    for buf, offs, members in pieces:
+        for k, j in enumerate(members):
+            seg[j] = buf[int(offs[k]) * 32: int(offs[k + 1]) * 32] if to_device is not None else buf[int(offs[k]): int(offs[k + 1])]
+    ordered = [seg[j] for j in range(len(stacks))]
+    if to_device is not None:
+        return (torch.cat(ordered) if total else torch.empty(0, dtype=torch.uint8, device=to_device)), total, counts
+    return np.concatenate(ordered), total, counts
+
+
 def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mofreak: MoFREAKUtilities, rank: int = 0,
                 world_size: int = 1, costs: Sequence[float] | None = None, group=None, on_device: bool = False,
-                workers: int = 1, batched: bool = True, keep_rows: bool = True) -> dict:
+                workers: int = 1, batched: bool = True, keep_rows: bool = True, batch_bytes: int = 4 << 30) -> dict:
     """BASELINE config 4 end to end (main.cpp:854-924 over a whole dataset).
 
     videos[i]: a (T, H, W) uint8 gray stack or the path of a .npy file holding one; names[i]: its output stem.
-    1. shard: longest-processing-time-first over `costs` (default: frame counts), one video per GPU at a time;
-    2. every rank extracts its videos' rows (no collective on the data path).  batched (a shared keypoint list, i.e. a
-       dense grid): ALL of the rank's clips in one mofreak_extract_clips call -- the clips share launches and the
-       three-stream copy/compute pipeline, and the rows stay in HBM (`on_device`).  Otherwise (detector keypoints,
-       per-frame providers): one C-ABI call per clip, `workers` host threads with a context each;
-    3. the one exchange: counts per video (all_reduce) + gather_rows of the 32-byte rows to rank 0 -- device to device
-       over RCCL when on_device, then ONE device-to-host copy on the root;
-    4. rank 0 writes <out_dir>/<name>.mofreak for every video, rows in (video, frame, keypoint) order -- the bytes a
-       1-rank run writes (out_dir None: nothing is written, the gathered rows are still returned on rank 0).
-    Returns timings and, on rank 0, `rows_per_video` -- views into a page-locked buffer that belongs to `mofreak` and is
-    reused by its next run_dataset call: copy what has to outlive that (keep_rows=False: no rows are brought to the host
-    at all, only the counts).
+    1. shard: longest-processing-time-first over `costs` (default: frame counts), one video per GPU at a time; a rank's
+       shard is cut into batches of at most `batch_bytes` of frames (plan_batches), and the ranks walk their batches in
+       step, one round per batch -- load, extract, gather, write, let go;
+    2. every rank extracts the rows of its batch (no collective on the data path).  batched (a shared keypoint list, i.e.
+       a dense grid): all clips of the batch in one mofreak_extract_clips call per frame size -- the clips share
+       launches and the three-stream copy/compute pipeline, and with a process group the rows stay in HBM.  Otherwise
+       (detector keypoints, per-frame providers): one C-ABI call per clip, `workers` host threads with a context each;
+    3. the one exchange, whenever a process group exists (world size 1 included: the same code runs): counts per video
+       (all_reduce) + gather_rows of the 32-byte rows to rank 0 -- device to device over RCCL when on_device, then ONE
+       device-to-host copy on the root;
+    4. rank 0 writes <out_dir>/<name>.mofreak for the round's videos, rows in (video, frame, keypoint) order -- the
+       bytes a 1-rank run writes; the files of a finished round are on disk before the next round starts (out_dir None:
+       nothing is written).  keep_rows=False: rows are not kept after their round (with out_dir they are still
+       written); without out_dir and without keep_rows nothing but the counts comes to the host.
+    Returns timings and, on rank 0 with keep_rows, `rows_per_video`: in a one-round run views into a page-locked buffer
+    that belongs to `mofreak` and is reused by its next run_dataset call (copy what has to outlive that), otherwise
+    copies.
     """
     import time
 
@@ -302,112 +401,96 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
         return np.load(v, mmap_mode="r") if isinstance(v, str) else v
 
     n = len(videos)
+    shapes = [tuple(stack_of(v).shape) for v in videos]  # a .npy header each; the same on every rank
     if costs is None:
-        costs = [stack_of(v).shape[0] for v in videos]
-    mine = shard_videos(costs, world_size)[rank]
-    t0 = time.perf_counter()
-    counts = np.zeros(n, np.int64)
+        costs = [s[0] for s in shapes]
+    nbytes = [int(np.prod(s)) for s in shapes]
+    shards = shard_videos(costs, world_size)
+    plans = [plan_batches(s, nbytes, batch_bytes) for s in shards]
+    n_rounds = max((len(p) for p in plans), default=0)
+    distributed = world_size > 1 or group_exists()
     prov = getattr(mofreak, "keypoint_provider", None)
-    use_batched = batched and not isinstance(prov, str) and getattr(prov, "shared", False) and len(mine) > 0
-    d_rows = None  # this rank's rows in HBM (batched + a CUDA device)
-    if use_batched:
+    use_batched = batched and not isinstance(prov, str) and getattr(prov, "shared", False)
+    cuda = torch.cuda.is_available()
+    rows_dev = torch.device("cuda", mofreak._device) if (use_batched and distributed and cuda) else None
+    want_rows = keep_rows or out_dir is not None
+    if rank == 0 and out_dir is not None:
+        os.makedirs(out_dir, exist_ok=True)
+
+    counts = np.zeros(n, np.int64)
+    rows_per_video: dict[int, np.ndarray] = {}
+    t_compute = t_gather = t_write = 0.0
+    rows_here = total_rows = 0
+    for r in range(n_rounds):
+        mine = plans[rank][r] if r < len(plans[rank]) else []
+        round_ids = [i for p in plans if r < len(p) for i in p[r]]  # rank order, ascending inside a rank: the gathered order
+        t0 = time.perf_counter()
         stacks = [np.ascontiguousarray(stack_of(videos[i])) for i in mine]
-        gap = mofreak._ctx.params.gap_for_frame_difference
-        H, W = stacks[0].shape[1:]
-        kps = prov(gap, W, H)
-        cap = int(sum(max(s.shape[0] - gap, 0) for s in stacks)) * len(kps)
-        if world_size > 1 and torch.cuda.is_available():
-            # rows stay in HBM until the gather has brought them to the root
-            d_rows = torch.empty(max(cap, 1) * 32, dtype=torch.uint8, device=torch.device("cuda", mofreak._device))
-            n_local, offs = mofreak._ctx.extract_clips(stacks, kps, rows_out=d_rows)
-            local = None
-        else:
-            # one rank: the rows are wanted on this host -- they travel back window by window under the pipeline's
-            # kernels, into page-locked memory (kept across calls).  (No device: the C ABI says so, MOFREAK_ERR_NO_DEVICE.)
-            local, offs = mofreak._ctx.extract_clips(stacks, kps, rows_out=_pinned_rows(mofreak, cap))
-            n_local = len(local)
-        for j, i in enumerate(mine):
-            counts[i] = offs[j + 1] - offs[j]
-    else:
-        if workers > 1 and len(mine) > 1:
-            import queue
-            from concurrent.futures import ThreadPoolExecutor
+        local, n_local, local_counts = _extract_batch(mofreak, stacks, use_batched, rows_dev, workers)
+        del stacks
+        rows_here += n_local
+        t_compute += time.perf_counter() - t0
 
-            pool = queue.SimpleQueue()
-            for m in mofreak.workers(min(workers, len(mine))):
-                pool.put(m)
-
-            def one(i):
-                m = pool.get()  # an instance nobody else is using
-                try:
-                    return m.extract_rows(np.ascontiguousarray(stack_of(videos[i])))
-                finally:
-                    pool.put(m)
-
-            with ThreadPoolExecutor(max_workers=min(workers, len(mine))) as ex:
-                parts = list(ex.map(one, mine))  # in the order of `mine`, whichever thread did what
-        else:
-            parts = [mofreak.extract_rows(np.ascontiguousarray(stack_of(videos[i]))) for i in mine]
-        for i, rows in zip(mine, parts):
-            counts[i] = len(rows)
-        local = np.concatenate(parts) if parts else np.zeros(0, api.ROW_DTYPE)
-        n_local = len(local)
-    t_compute = time.perf_counter() - t0
-
-    t1 = time.perf_counter()
-    all_rows = None
-    if world_size > 1:
-        dev = torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu")
-        c = torch.from_numpy(counts).to(dev)
-        dist.all_reduce(c, group=group)  # every video belongs to exactly one rank: the sum is the per-video count
-        counts = c.cpu().numpy()
-        if d_rows is not None:
-            buf = d_rows if on_device else d_rows[: n_local * 32].cpu()
-        else:
-            buf = torch.from_numpy(local.view(np.uint8).reshape(-1).copy()).to(dev)
-        gathered, per_rank = gather_rows(buf, n_local, dst=0, group=group)
-        if on_device:
-            torch.cuda.synchronize()
-        if rank == 0 and keep_rows:
-            if gathered.is_cuda:  # the root's one device-to-host copy, into page-locked memory kept across calls
-                host = _pinned_bytes(mofreak, gathered.numel())
-                host.copy_(gathered, non_blocking=True)
-                torch.cuda.synchronize()
-                all_rows = host.numpy().view(api.ROW_DTYPE).reshape(-1)
+        t1 = time.perf_counter()
+        round_counts = np.zeros(len(round_ids), np.int64)
+        pos = {i: k for k, i in enumerate(round_ids)}
+        for i, c in zip(mine, local_counts):
+            round_counts[pos[i]] = c
+        all_rows = None
+        if distributed:
+            dev = torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu")
+            c = torch.from_numpy(round_counts).to(dev)
+            dist.all_reduce(c, group=group)  # every video belongs to exactly one rank: the sum is the per-video count
+            round_counts = c.cpu().numpy()
+            if rows_dev is not None:
+                buf = local if on_device else local[: n_local * 32].cpu()
             else:
-                all_rows = gathered.numpy().view(api.ROW_DTYPE).reshape(-1)
-    else:
-        per_rank = [n_local]
-        if keep_rows:
-            all_rows = local if d_rows is None else d_rows[: n_local * 32].cpu().numpy().view(api.ROW_DTYPE).reshape(-1)
-    t_gather = time.perf_counter() - t1
+                buf = torch.from_numpy(np.ascontiguousarray(local).view(np.uint8).reshape(-1).copy()).to(dev)
+            gathered, per_rank = gather_rows(buf, n_local, dst=0, group=group)
+            if on_device:
+                torch.cuda.synchronize()
+            if rank == 0 and want_rows:
+                if gathered.is_cuda:  # the root's one device-to-host copy, into page-locked memory kept across calls
+                    host = _pinned_bytes(mofreak, gathered.numel())
+                    host.copy_(gathered, non_blocking=True)
+                    torch.cuda.synchronize()
+                    all_rows = host.numpy().view(api.ROW_DTYPE).reshape(-1)
+                else:
+                    all_rows = gathered.numpy().view(api.ROW_DTYPE).reshape(-1)
+            del gathered, buf
+        else:
+            per_rank = [n_local]
+            if want_rows:
+                all_rows = local if rows_dev is None else local[: n_local * 32].cpu().numpy().view(api.ROW_DTYPE).reshape(-1)
+        del local
+        t_gather += time.perf_counter() - t1
+        for i, c in zip(round_ids, round_counts):
+            counts[i] = c
+        if rank == 0:
+            total_rows += int(sum(per_rank))
+            assert int(sum(per_rank)) == int(round_counts.sum())
+        if rank == 0 and want_rows:
+            assert len(all_rows) == int(round_counts.sum())
+            t2 = time.perf_counter()
+            off = 0
+            for i, c in zip(round_ids, round_counts):
+                seg = all_rows[off: off + int(c)]
+                off += int(c)
+                if out_dir is not None:
+                    write_atomic(os.path.join(out_dir, names[i] + ".mofreak"), [api.format_rows(seg)])
+                if keep_rows:
+                    rows_per_video[i] = seg if n_rounds == 1 else seg.copy()
+            t_write += time.perf_counter() - t2
 
-    out = {"compute_s": t_compute, "gather_s": t_gather, "videos_here": len(mine), "rows_here": int(n_local),
-           "batched": bool(use_batched)}
+    out = {"compute_s": t_compute, "gather_s": t_gather, "videos_here": len(shards[rank]), "rows_here": int(rows_here),
+           "batched": bool(use_batched), "rounds": n_rounds, "distributed": bool(distributed)}
     if rank == 0:
-        out["total_rows"] = int(sum(per_rank))
-        assert out["total_rows"] == int(counts.sum())
-    if rank == 0 and keep_rows:
-        # rank r's rows sit at offset sum(per_rank[:r]), its videos in ascending index order
-        shards = shard_videos(costs, world_size)
-        start = {}
-        off = 0
-        for r in range(world_size):
-            for i in shards[r]:
-                start[i] = off
-                off += int(counts[i])
-        assert off == len(all_rows) == sum(per_rank)
-        t2 = time.perf_counter()
-        rows_per_video = {}
-        if out_dir is not None:
-            os.makedirs(out_dir, exist_ok=True)
-        for i in range(n):
-            seg = all_rows[start[i]: start[i] + int(counts[i])]
-            rows_per_video[i] = seg
-            if out_dir is not None:
-                write_atomic(os.path.join(out_dir, names[i] + ".mofreak"), [api.format_rows(seg)])
-        out["write_s"] = time.perf_counter() - t2
-        out["rows_per_video"] = rows_per_video
+        out["total_rows"] = int(total_rows)
+        out["rows_per_video_counts"] = counts
+        if want_rows:
+            out["write_s"] = t_write
+        if keep_rows:
+            out["rows_per_video"] = {i: rows_per_video.get(i, np.zeros(0, api.ROW_DTYPE)) for i in range(n)}
     return out
 
 
@@ -441,24 +524,41 @@ def run_stream_sharded(frames, mofreak: MoFREAKUtilities, rank: int = 0, world_s
     if isinstance(prov, str) or not getattr(prov, "shared", False):
         raise ValueError("run_stream_sharded needs a shared keypoint list (dense grid)")
     f0, f1 = split_stream(T, world_size, gap)[rank]
+    distributed = world_size > 1 or group_exists()
+    # with a device-side gather the piece's rows never visit the host on their way: frames down, rows straight into the
+    # tensor the gather sends from (the one-clip case of mofreak_extract_clips with MOFREAK_ROWS_DEVICE)
+    rows_dev = torch.device("cuda", mofreak._device) if (distributed and on_device and torch.cuda.is_available()) else None
+    kps = prov(gap, W, H)
     t0 = time.perf_counter()
+    rows, d_rows, n_rows = np.zeros(0, api.ROW_DTYPE), None, 0
     if f1 > f0:
         piece = np.ascontiguousarray(frames[f0:f1])
-        rows = mofreak._ctx.extract_stream_pipelined_host(piece, prov(gap, W, H), chunk_frames=chunk_frames)
-        rows["frame_number"] += f0  # labels run on across the pieces (:401, :488)
-    else:
-        rows = np.zeros(0, api.ROW_DTYPE)
+        if rows_dev is not None:
+            d_rows = torch.empty(max((f1 - f0 - gap) * len(kps), 1) * 32, dtype=torch.uint8, device=rows_dev)
+            n_rows, _ = mofreak._ctx.extract_clips([piece], kps, chunk_frames=chunk_frames, rows_out=d_rows)
+            if f0 and n_rows:  # labels run on across the pieces (:401, :488): frame_number is the third 32-bit field of a row
+                d_rows.view(torch.int32).view(-1, 8)[:n_rows, 2] += f0
+        else:
+            rows = mofreak._ctx.extract_stream_pipelined_host(piece, kps, chunk_frames=chunk_frames)
+            rows["frame_number"] += f0
+            n_rows = len(rows)
+    elif rows_dev is not None:
+        d_rows = torch.empty(32, dtype=torch.uint8, device=rows_dev)
     t_compute = time.perf_counter() - t0
     t1 = time.perf_counter()
-    if world_size > 1:
-        dev = torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu")
-        buf = torch.from_numpy(rows.view(np.uint8).reshape(-1).copy()).to(dev)
-        gathered, per_rank = gather_rows(buf, len(rows), dst=0, group=group)
-        all_rows = gathered.cpu().numpy().view(api.ROW_DTYPE).reshape(-1) if rank == 0 else None
+    if distributed:
+        if d_rows is not None:
+            buf = d_rows
+        else:
+            buf = torch.from_numpy(rows.view(np.uint8).reshape(-1).copy())
+            if on_device:
+                buf = buf.to(torch.device("cuda", torch.cuda.current_device()))
+        gathered, per_rank = gather_rows(buf, n_rows, dst=0, group=group)
+        all_rows = gathered.cpu().numpy().view(api.ROW_DTYPE).reshape(-1) if rank == 0 else None  # the root's one copy to the host
     else:
-        all_rows, per_rank = rows, [len(rows)]
-    out = {"compute_s": t_compute, "gather_s": time.perf_counter() - t1, "frames_here": (f0, f1), "rows_here": int(len(rows)),
-           "rows_per_rank": per_rank}
+        all_rows, per_rank = rows, [n_rows]
+    out = {"compute_s": t_compute, "gather_s": time.perf_counter() - t1, "frames_here": (f0, f1), "rows_here": int(n_rows),
+           "rows_per_rank": per_rank, "rows_in_hbm": d_rows is not None, "distributed": bool(distributed)}
     if rank == 0:
         out["rows"] = all_rows
     return out

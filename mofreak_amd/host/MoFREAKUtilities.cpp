@@ -2,6 +2,8 @@
 // Reference lines cited are src/MoFREAK/MoFREAKUtilities.cpp of ChrisWhiten/MoFREAK.
 #include "MoFREAKUtilities.h"
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -180,51 +182,62 @@ void MoFREAKUtilities::computeMoFREAKFromFiles(const std::vector<std::string> &v
         for (size_t i = 0; i < video_filenames.size(); ++i) computeMoFREAKFromFile(video_filenames[i], mofreak_filenames[i], true);
         return;
     }
+    // Bounded batches: videos are loaded in the order given until the batch holds batch_bytes_ of frames (or the frame size
+    // changes), handed to ONE mofreak_extract_clips call, their files written, their frames let go -- host memory and the
+    // work a crash can lose are bounded by the batch, not by the dataset (the per-video file is the checkpoint).
     struct Clip {
         std::vector<uint8_t> frames;
-        int T = 0, H = 0, W = 0;
-        bool ok = false;
+        size_t index = 0;
+        int T = 0;
     };
-    std::vector<Clip> clips(video_filenames.size());
-    for (size_t i = 0; i < clips.size(); ++i) {
-        clips[i].ok = load_npy_u8_3d(video_filenames[i], clips[i].frames, clips[i].T, clips[i].H, clips[i].W);
-        if (!clips[i].ok) cout << "Could not open file: " << video_filenames[i] << endl;  // :383-386
-    }
     mofreak_ctx *ctx = context();
     const int gap = params_.gap_for_frame_difference;
-    std::vector<char> done(clips.size(), 0);
-    for (size_t first = 0; first < clips.size(); ++first) {
-        if (done[first] || !clips[first].ok) continue;
-        // every clip of this frame size, in the order they were given
-        const int W = clips[first].W, H = clips[first].H;
-        std::vector<size_t> idx;
-        for (size_t i = first; i < clips.size(); ++i)
-            if (!done[i] && clips[i].ok && clips[i].W == W && clips[i].H == H) idx.push_back(i);
-        std::vector<const uint8_t *> ptr(idx.size());
-        std::vector<int32_t> len(idx.size());
-        const std::vector<mofreak_keypoint> kps = provider_(gap, W, H);
+    std::vector<Clip> batch;
+    int bW = 0, bH = 0;
+    size_t bytes = 0;
+    auto flush = [&]() {
+        if (batch.empty()) return;
+        std::vector<const uint8_t *> ptr(batch.size());
+        std::vector<int32_t> len(batch.size());
+        const std::vector<mofreak_keypoint> kps = provider_(gap, bW, bH);
         int64_t capacity = 0;
-        for (size_t k = 0; k < idx.size(); ++k) {
-            ptr[k] = clips[idx[k]].frames.data();
-            len[k] = clips[idx[k]].T;
+        for (size_t k = 0; k < batch.size(); ++k) {
+            ptr[k] = batch[k].frames.data();
+            len[k] = batch[k].T;
             capacity += (int64_t)std::max(len[k] - gap, 0) * (int64_t)kps.size();
         }
         std::vector<mofreak_row> rows((size_t)std::max<int64_t>(capacity, 1));
-        std::vector<int64_t> offs(idx.size() + 1, 0);
+        std::vector<int64_t> offs(batch.size() + 1, 0);
         int64_t n_rows = 0;
         check(ctx,
-              mofreak_extract_clips(ctx, ptr.data(), len.data(), (int)idx.size(), W, H, /*chunk_frames*/ 0, kps.data(), (int64_t)kps.size(),
+              mofreak_extract_clips(ctx, ptr.data(), len.data(), (int)batch.size(), bW, bH, /*chunk_frames*/ 0, kps.data(), (int64_t)kps.size(),
                                     rows.data(), capacity, offs.data(), &n_rows, 0),
               "mofreak_extract_clips");
-        for (size_t k = 0; k < idx.size(); ++k) {
-            const size_t i = idx[k];
+        for (size_t k = 0; k < batch.size(); ++k) {
+            const size_t i = batch[k].index;
             appendRows(rows.data() + offs[k], offs[k + 1] - offs[k], video_filenames[i]);  // behind whatever is there (:374-498 appends)
             cout << "Writing this mofreak file: " << mofreak_filenames[i] << endl;
             writeMoFREAKFeaturesToFile(mofreak_filenames[i]);
             features.clear();  // clear_features_after_computation = true
-            done[i] = 1;
         }
+        batch.clear();
+        bytes = 0;
+    };
+    for (size_t i = 0; i < video_filenames.size(); ++i) {
+        Clip c;
+        int W = 0, H = 0;
+        if (!load_npy_u8_3d(video_filenames[i], c.frames, c.T, H, W)) {
+            cout << "Could not open file: " << video_filenames[i] << endl;  // :383-386
+            continue;
+        }
+        c.index = i;
+        if (!batch.empty() && (W != bW || H != bH || bytes + c.frames.size() > batch_bytes_)) flush();
+        bW = W;
+        bH = H;
+        bytes += c.frames.size();
+        batch.push_back(std::move(c));
     }
+    flush();
 }
 
 void MoFREAKUtilities::computeMoFREAKFromFrames(const uint8_t *frames, int T, int W, int H,
@@ -362,7 +375,9 @@ void MoFREAKUtilities::writeMoFREAKFeaturesToFile(string output_file)
             throw std::runtime_error("short write to " + tmp);
         }
     }
-    if (std::fclose(out) != 0 || std::rename(tmp.c_str(), output_file.c_str()) != 0)
+    // on disk before the name exists: the same durability as the Python mirror's write_atomic (flush, fsync, rename)
+    const bool synced = std::fflush(out) == 0 && fsync(fileno(out)) == 0;
+    if (std::fclose(out) != 0 || !synced || std::rename(tmp.c_str(), output_file.c_str()) != 0)
         throw std::runtime_error("cannot finish " + output_file);
 }
 

@@ -93,10 +93,13 @@ public:
     void computeMoFREAKFromFrames(const uint8_t *frames, int T, int W, int H, const std::string &video_filename);
     // The body of computeMoFREAKFiles' loops (main.cpp:862-921) for many videos at once: what
     //     for (i...) computeMoFREAKFromFile(video_filenames[i], mofreak_filenames[i], true);
-    // does -- every video's features written to its own file, nothing kept -- with the videos of one frame size going
-    // through ONE mofreak_extract_clips call (shared launches, copies under kernels) when the keypoints are a shared
-    // list (dense grid); other keypoint sources fall back to the loop above.  Files come out byte-identical to it.
+    // does -- every video's features written to its own file, nothing kept -- with consecutive videos of one frame size
+    // going through ONE mofreak_extract_clips call (shared launches, copies under kernels) per batch of at most
+    // setBatchBytes() of frames when the keypoints are a shared list (dense grid); other keypoint sources fall back to the
+    // loop above.  A batch is loaded, extracted, written and freed before the next one is read: memory and the work a
+    // crash loses are bounded by the batch.  Files come out byte-identical to the loop's.
     void computeMoFREAKFromFiles(const std::vector<std::string> &video_filenames, const std::vector<std::string> &mofreak_filenames);
+    void setBatchBytes(size_t bytes) { batch_bytes_ = bytes > 0 ? bytes : 1; }  // default 2 GiB of frames per batch
 
 private:
     void readMetadata(const std::string &filename, int &action, int &video_number, int &person);
@@ -110,6 +113,7 @@ private:
     mofreak_ctx *ctx_;
     KeypointProvider provider_;
     bool provider_shared_;
+    size_t batch_bytes_ = (size_t)2 << 30;
     bool use_brisk_;
     int brisk_threshold_, brisk_octaves_;
 };

@@ -109,7 +109,6 @@ int main()
         CHECK(mofreak_extract_clips(ctx, clips, lens, 0, 8, 8, 0, &kp, 1, &row, 1, offs, &n_rows, 0) == MOFREAK_OK && n_rows == 0);
         CHECK(mofreak_extract_clips(ctx, clips, lens, 3, 8, 8, 0, &kp, 1, &row, 1, offs, &n_rows, 0) == MOFREAK_ERR_NO_DEVICE);
         CHECK(mofreak_extract_stream_pipelined(ctx, frame, 1, 8, 8, 0, &kp, 1, &row, 1, &n_rows) == MOFREAK_OK && n_rows == 0);  // T <= gap: no rows, no device needed
-        CHECK(mofreak_set_loop_pipelining(ctx, 0) == MOFREAK_OK && mofreak_set_loop_pipelining(nullptr, 1) == MOFREAK_ERR_BAD_ARG);
         uint16_t pos[320];
         int32_t n_pos = 0;
         for (int L = 1; L <= 16; ++L) CHECK(mofreak_table_mip_positions(ctx, L, pos, &n_pos) == MOFREAK_OK && n_pos == 300);

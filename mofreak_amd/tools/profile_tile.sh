@@ -21,8 +21,9 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CU_C
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-detector > $out/pmc$i.log 2>&1
 done
 python3 - $tag $out <<'PY'
-import csv, glob, collections, json, sys
+import csv, glob, collections, hashlib, json, sys
 tag, out = sys.argv[1], sys.argv[2]
+lib_hash = hashlib.sha256(open('mofreak_amd/libmofreak_hip.so', 'rb').read()).hexdigest()[:16]  # the build these counters belong to
 tot = collections.defaultdict(list)
 rows = []
 for f in sorted(glob.glob(f'{out}/pmc*/*/*counter_collection.csv')):
@@ -43,7 +44,7 @@ with open(f'gpurun_out/{tag}_pmc_tile_kernel.csv', 'w') as fh:
 b_alg = 2 * 1920 * 1080 + 28 * n_kp
 traffic = (2 * avg['FETCH_SIZE'] + avg['WRITE_SIZE']) * 1024
 pd = {k: round(avg[k] / n, 3) for k in avg if k.startswith('SQ_')}
-tj = {"kernel": "tile_kernel", "pairs_per_launch": pairs, "FETCH_SIZE_KB": avg['FETCH_SIZE'], "WRITE_SIZE_KB": avg['WRITE_SIZE'],
+tj = {"kernel": "tile_kernel", "library_sha256_16": lib_hash, "pairs_per_launch": pairs, "FETCH_SIZE_KB": avg['FETCH_SIZE'], "WRITE_SIZE_KB": avg['WRITE_SIZE'],
       "TCC_HIT_sum": avg['TCC_HIT_sum'], "TCC_MISS_sum": avg['TCC_MISS_sum'],
       "l2_hit_rate": avg['TCC_HIT_sum'] / (avg['TCC_HIT_sum'] + avg['TCC_MISS_sum']),
       "tile_kernel_hbm_bytes_per_launch": traffic,

@@ -87,14 +87,12 @@ def main():
                       print(f"CLIPS MISMATCH round {rounds} seed {seed}: {Wc}x{Hc} lengths {lengths}")
                       sys.exit(1)
                   clip_rounds += 1
-              if rounds % 11 == 0 and not par:  # the frame loop on two lanes == on one lane
+              if rounds % 11 == 0 and not par:  # the frame loop in one call == detector, then descriptors
                   Wl, Hl, Tl = int(rng.choice([160, 320, 400])), int(rng.choice([120, 240])), int(rng.choice([21, 26, 38, 70]))
                   frl = synth.moving_objects_stack(Tl, Wl, Hl, seed=int(rng.integers(0, 1 << 30)))
-                  ctx.set_loop_pipelining(True)
                   two = ctx.compute_stream_host(frl)
-                  ctx.set_loop_pipelining(False)
-                  one = ctx.compute_stream_host(frl)
-                  ctx.set_loop_pipelining(M.api.LOOP_AUTO)
+                  kl, ol, _, _ = ctx.detect_pairs_host(frl[5:], frl[:-5])
+                  one = ctx.extract_stream_host(frl, kl, kp_offsets=ol)
                   if two.tobytes() != one.tobytes():
                       print(f"FRAME LOOP MISMATCH round {rounds} seed {seed}: {Wl}x{Hl} T {Tl}: {len(two)} vs {len(one)} rows")
                       sys.exit(1)

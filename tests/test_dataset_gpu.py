@@ -56,6 +56,36 @@ def test_c4_dataset_rows_match_the_oracle_and_files_are_ordered(oracle, tmp_path
     assert res["total_rows"] == total == int(((lengths - 5) * 150).sum())
 
 
+def test_mixed_frame_sizes_and_bounded_rounds(oracle, tmp_path):
+    """A shard whose clips have different frame sizes (HMDB51's widths vary) in rounds of a few MiB: one pipelined call per
+    frame size inside a round, rows back in video order, the files of the one-round run; and out_dir with keep_rows=False
+    still writes them."""
+    clips, names, _ = _clips()
+    clips, names = clips[:9], names[:9]
+    clips[2] = np.ascontiguousarray(synth.synth_stack(19, 400, 300, t0=31))
+    clips[7] = np.ascontiguousarray(synth.synth_stack(11, 352, 288, t0=90))
+    mo = _mofreak()
+    try:
+        one = harness.run_dataset(clips, names, str(tmp_path / "one"), mo)
+        rows_one = {i: r.copy() for i, r in one["rows_per_video"].items()}
+        many = harness.run_dataset(clips, names, str(tmp_path / "many"), mo, batch_bytes=12 << 20)
+        quiet = harness.run_dataset(clips, names, str(tmp_path / "quiet"), mo, batch_bytes=12 << 20, keep_rows=False)
+    finally:
+        mo.close()
+    assert one["rounds"] == 1 and many["rounds"] > 2 and "rows_per_video" not in quiet
+    f = oracle.Freak()
+    c = synth.CONFIGS["C4"]
+    for i, clip in enumerate(clips):
+        kps = synth.dense_grid(clip.shape[2], clip.shape[1], c["step"], c["size"], c["lo"])
+        n_pairs = len(clip) - 5
+        want = f.extract_stream(clip, np.tile(kps, (n_pairs, 1)), np.arange(n_pairs + 1, dtype=np.int64) * len(kps))
+        assert rows_one[i].tobytes() == want.tobytes() == many["rows_per_video"][i].tobytes(), i
+        text = oracle.format_rows(want)
+        for d in ("one", "many", "quiet"):
+            assert (tmp_path / d / (names[i] + ".mofreak")).read_bytes() == text, (d, i)
+    assert quiet["total_rows"] == one["total_rows"] == sum(len(r) for r in rows_one.values())
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -128,64 +128,35 @@ def test_device_equals_the_independent_sequential_restatement(ctx):
 
 
 @pytest.mark.parametrize("T,W,H", [(21, 320, 240), (25, 400, 300), (60, 320, 240), (72, 212, 160)])
-def test_pipelined_frame_loop_rows_equal_the_sequential_loop_and_the_oracle(ctx, T, W, H):
-    """mofreak_compute_stream from 16 processed frames up: batches of frames, the detector of batch k + 1 on one stream
-    beside the descriptors of batch k on another.  Rows byte-identical to the same call without pipelining and to the oracle's
-    frame loop (detector -> FREAK + MIP -> rows), for two even batches, two uneven ones, and several batches of 32 with a
-    short last one."""
+def test_frame_loop_rows_equal_the_three_calls_and_the_oracle(ctx, T, W, H):
+    """mofreak_compute_stream = detector -> descriptors -> rows in one call: byte-identical to the three separate calls and to
+    the oracle's frame loop (detector -> FREAK + MIP -> rows)."""
     fr = synth.moving_objects_stack(T, W, H, seed=T)
-    ctx.set_loop_pipelining(True)
     got = ctx.compute_stream_host(fr)
-    ctx.set_loop_pipelining(False)
-    try:
-        plain = ctx.compute_stream_host(fr)
-    finally:
-        ctx.set_loop_pipelining(M.api.LOOP_AUTO)
-    assert got.tobytes() == plain.tobytes() and len(got) > 200
+    kps_d, offs_d, _, _ = ctx.detect_pairs_host(fr[5:], fr[:-5])
+    assert got.tobytes() == ctx.extract_stream_host(fr, kps_d, kp_offsets=offs_d).tobytes() and len(got) > 200
     lists = [O.brisk_detect(O.absdiff(fr[t], fr[t - 5])) for t in range(5, T)]
     kps = np.concatenate([np.stack([k["x"], k["y"], k["size"]], 1) for k in lists]).astype(np.float32)
     offs = np.concatenate([[0], np.cumsum([len(k) for k in lists])]).astype(np.int64)
     want = O.Freak().extract_stream(fr, kps, offs)
     assert got.tobytes() == want.tobytes()
     assert got["frame_number"].min() == 4 and got["frame_number"].max() == T - 2
-    # again on the same context: the buffers and events of the first call are reused
-    ctx.set_loop_pipelining(True)
-    try:
-        assert ctx.compute_stream_host(fr).tobytes() == want.tobytes()
-    finally:
-        ctx.set_loop_pipelining(M.api.LOOP_AUTO)
+    assert ctx.compute_stream_host(fr).tobytes() == want.tobytes()  # again on the same context: its buffers are reused
 
 
-def test_default_loop_mode_takes_two_lanes_for_long_stacks(ctx):
-    """MOFREAK_LOOP_AUTO: a stack of more than 128 pairs (two batches) goes over two lanes without being asked to; same rows as
-    the one-lane loop."""
-    T, W, H = 140, 160, 120
-    fr = synth.moving_objects_stack(T, W, H, seed=5)
-    ctx.set_loop_pipelining(M.api.LOOP_AUTO)
-    got = ctx.compute_stream_host(fr)
-    ctx.set_loop_pipelining(M.api.LOOP_ONE_LANE)
-    try:
-        plain = ctx.compute_stream_host(fr)
-    finally:
-        ctx.set_loop_pipelining(M.api.LOOP_AUTO)
-    assert got.tobytes() == plain.tobytes() and len(got) > 500
-    assert got["frame_number"].min() == 4 and got["frame_number"].max() == T - 2
-
-
-def test_pipelined_frame_loop_grows_its_keypoint_buffers(ctx):
-    """More keypoints per frame than the batch buffers were made for (8192): reported inside the call, buffers grown, same rows."""
+def test_frame_loop_grows_its_keypoint_buffers(ctx):
+    """More keypoints per frame than the loop's keypoint buffer was made for (4096 per pair): reported inside the call, the
+    buffer grown once to what the stack needs, same rows as the separate calls."""
     rng = np.random.default_rng(3)
     T, W, H = 22, 640, 480
     fr = rng.integers(0, 2, (T, H // 4, W // 4)).astype(np.uint8) * 200
     fr = np.kron(fr, np.ones((1, 4, 4), np.uint8))  # blocky binary noise: corners everywhere
     ctx.set_detect_capacity(1 << 20)
     try:
-        ctx.set_loop_pipelining(True)  # (two lanes from 16 pairs up; the default takes them for stacks of more than 128 pairs)
         got = ctx.compute_stream_host(fr, capacity=T * 40000)
-        ctx.set_loop_pipelining(False)
-        plain = ctx.compute_stream_host(fr, capacity=T * 40000)
+        kps_d, offs_d, _, _ = ctx.detect_pairs_host(fr[5:], fr[:-5], capacity=T * 40000)
+        plain = ctx.extract_stream_host(fr, kps_d, kp_offsets=offs_d)
     finally:
-        ctx.set_loop_pipelining(M.api.LOOP_AUTO)
         ctx.set_detect_capacity(131072)
     assert len(got) > 17 * 8192 and got.tobytes() == plain.tobytes()
 

@@ -248,3 +248,22 @@ def test_sharded_stream_rows_equal_the_one_rank_stream(tmp_path, world):
     mp.spawn(_stream_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / "rows.npy")
     assert got.tobytes() == want.tobytes()
+
+
+def test_plan_batches_bounds_a_rank_s_rounds():
+    """A rank's shard is walked in consecutive batches of at most batch_bytes of frames, at least one video each."""
+    nbytes = [10, 30, 5, 100, 1, 1, 50]
+    assert harness.plan_batches([0, 1, 2, 3, 4, 5, 6], nbytes, 40) == [[0, 1], [2], [3], [4, 5], [6]]
+    assert harness.plan_batches([6, 0], nbytes, 1 << 40) == [[6, 0]]
+    assert harness.plan_batches([], nbytes, 40) == []
+    assert harness.plan_batches([3], nbytes, 1) == [[3]]  # a video larger than the bound still gets its batch
+    rng = np.random.default_rng(1)
+    nb = rng.integers(1, 1000, 300).tolist()
+    for bound in (1, 999, 5000):
+        plan = harness.plan_batches(list(range(300)), nb, bound)
+        assert [i for b in plan for i in b] == list(range(300))
+        assert all(sum(nb[i] for i in b) <= bound or len(b) == 1 for b in plan)
+
+
+def test_group_exists_follows_the_process_group():
+    assert harness.group_exists() is False

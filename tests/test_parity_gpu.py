@@ -301,6 +301,41 @@ def test_bad_arguments_are_reported(gpu_ctx):
     assert e.value.code == -4 and "row_stride" in str(e.value)
 
 
+def test_a_roi_that_leaves_the_image_is_reported_where_the_reference_throws(gpu_ctx, oracle):
+    """size 1100 at the centre of a 1080p pair: FREAK keeps the keypoint (pattern size 339 < 540), its MIP ROI -- side 1100
+    from y - 550 -- leaves the image.  The reference throws cv::Exception out of cv::Mat::operator()(Rect)
+    (MoFREAKUtilities.cpp:296-297; the oracle returns -1, mofreak_oracle.c:433): here the keypoint is invalid with a zero
+    descriptor, its neighbours in the list are untouched, and mofreak_check_status says MOFREAK_ERR_ROI -- once."""
+    fr = synth.synth_stack(6, 1920, 1080)
+    cur, prev = fr[5:6], fr[0:1]
+    kps = np.float32([[960, 540, 12], [960, 540, 1100], [700, 400, 12]])
+    gpu_ctx.check_status()  # nothing pending from earlier tests
+    d, v = gpu_ctx.extract_pairs_host(cur, prev, kps)
+    wd, wv = oracle_pairs(oracle, cur, prev, kps)
+    assert wv.tolist() == [1, 0, 1] and v.tolist() == [1, 0, 1]
+    assert d.tobytes() == wd.tobytes() and not d[1].any()
+    with pytest.raises(M.MoFREAKError) as e:
+        gpu_ctx.check_status()
+    assert e.value.code == M.api.ERR_ROI and "ROI" in str(e.value)
+    gpu_ctx.check_status()  # reading the status clears it
+
+
+def test_a_roi_wider_than_the_resize_tables_is_refused(gpu_ctx, oracle):
+    """ceil(size) = 2049 > 2048, the largest ROI side the host-built cv::resize tap tables cover: MOFREAK_ERR_UNSUPPORTED
+    (status bit 2), the keypoint invalid -- as in the oracle, whose ROI test fails for it too."""
+    fr = synth.synth_stack(6, 1920, 1080)
+    cur, prev = fr[5:6], fr[0:1]
+    kps = np.float32([[960, 540, 2049], [960, 540, 12]])
+    gpu_ctx.check_status()
+    d, v = gpu_ctx.extract_pairs_host(cur, prev, kps)
+    wd, wv = oracle_pairs(oracle, cur, prev, kps)
+    assert wv.tolist() == [0, 1] and v.tolist() == [0, 1] and d.tobytes() == wd.tobytes()
+    with pytest.raises(M.MoFREAKError) as e:
+        gpu_ctx.check_status()
+    assert e.value.code == M.api.ERR_UNSUPPORTED
+    gpu_ctx.check_status()
+
+
 def test_strides_and_unaligned_frames(ctx_path, oracle):
     """row_stride > W, pair_stride with padding, and a frame base that is not 4-byte aligned."""
     W, H, n = 203, 150, 3
