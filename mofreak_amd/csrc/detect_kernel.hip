@@ -261,14 +261,11 @@ __device__ __forceinline__ void arc9_extremes(const int (&p)[16], int &max_of_mi
     min_of_max = min(min3i(hi5[0], hi5[1], hi5[2]), min3i(hi5[3], hi5[4], hi9[15]));
 }
 
-constexpr int kScoreTileW = 64, kScoreTileH = 32, kScoreLdsW = 72;  // LDS rows start at image column x0 - 4: aligned dwords
+constexpr int kScoreTileW = kDetTileW, kScoreTileH = kDetTileH, kScoreLdsW = 72;  // LDS rows start at image column x0 - 4: aligned dwords
 
-__global__ __launch_bounds__(kDetThreads) void det_score_kernel(DetArgs a, int layer)
+// a tile of a layer's image with its 3-pixel ring halo -> LDS (rows of kScoreLdsW bytes, first column x0 - 4)
+__device__ __forceinline__ void score_tile_load(uint8_t *tile, const uint8_t *img, const DetLayer &L, int x0, int y0)
 {
-    __shared__ __attribute__((aligned(4))) uint8_t tile[(kScoreTileH + 6) * kScoreLdsW];
-    const DetLayer L = a.dg->L[layer];
-    const int p = blockIdx.z, x0 = blockIdx.x * kScoreTileW, y0 = blockIdx.y * kScoreTileH;
-    const uint8_t *img = a.img + (int64_t)p * a.dg->plane_bytes + L.off;
     if ((L.w & 3) == 0) {  // rows start on dword boundaries (layer planes are 64-byte aligned): 18 aligned dwords per tile row
         for (int t = threadIdx.x; t < (kScoreTileH + 6) * (kScoreLdsW / 4); t += kDetThreads) {
             const int r = t / (kScoreLdsW / 4), k = t - r * (kScoreLdsW / 4);
@@ -284,49 +281,132 @@ __global__ __launch_bounds__(kDetThreads) void det_score_kernel(DetArgs a, int l
             tile[r * kScoreLdsW + c] = (gx >= 0 && gx < L.w && gy >= 0 && gy < L.h) ? img[(int64_t)gy * L.w + gx] : 0;
         }
     }
+}
+
+// the OAST 9/16 score of the pixel at t (a byte of an image held with row pitch P): Bresenham circle of radius 3 in the
+// order of OastDetector9_16::init_pattern (oast9_16.h:74-92)
+template <int P>
+__device__ __forceinline__ int ring_score(const uint8_t *t)
+{
+    const int c = t[0];
+    int q[16];
+    q[0] = t[-3];
+    q[1] = t[-P - 3];
+    q[2] = t[-2 * P - 2];
+    q[3] = t[-3 * P - 1];
+    q[4] = t[-3 * P];
+    q[5] = t[-3 * P + 1];
+    q[6] = t[-2 * P + 2];
+    q[7] = t[-P + 3];
+    q[8] = t[3];
+    q[9] = t[P + 3];
+    q[10] = t[2 * P + 2];
+    q[11] = t[3 * P + 1];
+    q[12] = t[3 * P];
+    q[13] = t[3 * P - 1];
+    q[14] = t[2 * P - 2];
+    q[15] = t[P - 3];
+    int arc_lo, arc_hi;
+    arc9_extremes(q, arc_lo, arc_hi);
+    const int vb = arc_lo - c, vd = c - arc_hi;  // brightest all-brighter arc margin, darkest all-darker arc margin
+    return max(max(vb, vd) - 1, 0);
+}
+
+// Component entry point (mofreak_brisk_pyramid with scores_out): the score of EVERY pixel of a layer.  The detector itself
+// scores only where the reference does (det_corner_kernel, det_refine_kernel).
+__global__ __launch_bounds__(kDetThreads) void det_dense_score_kernel(DetArgs a, int layer)
+{
+    __shared__ __attribute__((aligned(4))) uint8_t tile[(kScoreTileH + 6) * kScoreLdsW];
+    const DetLayer L = a.dg->L[layer];
+    const int p = blockIdx.z, x0 = blockIdx.x * kScoreTileW, y0 = blockIdx.y * kScoreTileH;
+    score_tile_load(tile, a.img + (int64_t)p * a.dg->plane_bytes + L.off, L, x0, y0);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // the same in every lane: a scalar
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint8_t *score = a.score + (int64_t)p * a.dg->plane_bytes + L.off;
-    uint8_t *touch = a.touch + (int64_t)p * a.dg->plane_bytes + L.off, *status = a.status + (int64_t)p * a.dg->plane_bytes + L.off;
-    int32_t *row_count = a.row_count + (int64_t)p * (a.dg->total_rows + 1) + L.row_base;
 #pragma unroll
     for (int it = 0; it < kScoreTileH / 4; ++it) {
         const int ry = wave + 4 * it, x = x0 + lane, y = y0 + ry;
         int s = 0;
-        if (x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3) {
-            const uint8_t *t = tile + (ry + 3) * kScoreLdsW + lane + 4;
-            const int c = t[0];
-            int q[16];
-            // Bresenham circle of radius 3 in the order of OastDetector9_16::init_pattern (oast9_16.h:74-92)
-            q[0] = t[-3];
-            q[1] = t[-kScoreLdsW - 3];
-            q[2] = t[-2 * kScoreLdsW - 2];
-            q[3] = t[-3 * kScoreLdsW - 1];
-            q[4] = t[-3 * kScoreLdsW];
-            q[5] = t[-3 * kScoreLdsW + 1];
-            q[6] = t[-2 * kScoreLdsW + 2];
-            q[7] = t[-kScoreLdsW + 3];
-            q[8] = t[3];
-            q[9] = t[kScoreLdsW + 3];
-            q[10] = t[2 * kScoreLdsW + 2];
-            q[11] = t[3 * kScoreLdsW + 1];
-            q[12] = t[3 * kScoreLdsW];
-            q[13] = t[3 * kScoreLdsW - 1];
-            q[14] = t[2 * kScoreLdsW - 2];
-            q[15] = t[kScoreLdsW - 3];
-            int arc_lo, arc_hi;
-            arc9_extremes(q, arc_lo, arc_hi);
-            const int vb = arc_lo - c, vd = c - arc_hi;  // brightest all-brighter arc margin, darkest all-darker arc margin
-            s = max(max(vb, vd) - 1, 0);
+        if (x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3) s = ring_score<kScoreLdsW>(tile + (ry + 3) * kScoreLdsW + lane + 4);
+        if (x < L.w && y < L.h) score[(uint32_t)y * (uint32_t)L.w + (uint32_t)x] = (uint8_t)s;
+    }
+}
+
+// ------------------------------------------------------------------ corners (what OastDetector9_16::detect + getAgastPoints leave behind)
+// One workgroup per 64 x 32 tile of a layer, all layers in one launch.  The reference's decision tree answers "is there an
+// arc of 9 ring pixels all brighter than c + t or all darker than c - t" with a handful of comparisons for most pixels;
+// the data-parallel counterpart: (1) a necessary condition on the four compass points of the ring -- an arc of 9 holds at
+// least two of them, so two must be brighter (darker) -- passes a few percent of a difference image's pixels; (2) the
+// survivors of a tile are compacted and only they get the full score (the arc extremes), with full wavefronts.  Leaves,
+// per tile: the score plane (score where >= threshold, 0 elsewhere: the reference's cache after getAgastPoints,
+// brisk.cpp:1676-1690), a 64-bit hit mask per tile row, and the per-row corner counts.
+__global__ __launch_bounds__(kDetThreads) void det_corner_kernel(DetArgs a)
+{
+    __shared__ __attribute__((aligned(4))) uint8_t tile[(kScoreTileH + 6) * kScoreLdsW];
+    __shared__ __attribute__((aligned(8))) uint8_t out[kScoreTileH * kScoreTileW];
+    __shared__ uint16_t list[kScoreTileH * kScoreTileW];
+    __shared__ unsigned long long row_mask[kScoreTileH];
+    __shared__ int n_list;
+    const int p = blockIdx.y, t = blockIdx.x;
+    int layer = 0;  // from the argument block's copy of the geometry with constant indices: scalar compares, no memory
+#pragma unroll
+    for (int k = 1; k < kDetMaxLayers; ++k) layer += (k < a.g.n_layers && t >= a.g.tile_start[k]) ? 1 : 0;
+    const DetLayer L = a.dg->L[layer];
+    const int tiles_x = a.dg->tiles_x[layer], tl = t - a.dg->tile_start[layer];
+    const int ty = tl / tiles_x, tx = tl - ty * tiles_x, x0 = tx * kScoreTileW, y0 = ty * kScoreTileH;
+    const int64_t plane = (int64_t)p * a.dg->plane_bytes + L.off;
+    score_tile_load(tile, a.img + plane, L, x0, y0);
+    for (int k = threadIdx.x; k < kScoreTileH * kScoreTileW / 4; k += kDetThreads) reinterpret_cast<uint32_t *>(out)[k] = 0u;
+    if (threadIdx.x < kScoreTileH) row_mask[threadIdx.x] = 0ull;
+    if (threadIdx.x == 0) n_list = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int thr = a.safe_threshold;
+#pragma unroll
+    for (int it = 0; it < kScoreTileH / 4; ++it) {
+        const int ry = wave + 4 * it, x = x0 + lane, y = y0 + ry;
+        const uint8_t *q = tile + (ry + 3) * kScoreLdsW + lane + 4;
+        const int c = q[0], hi = c + thr, lo = c - thr;
+        const int l = q[-3], u = q[-3 * kScoreLdsW], r = q[3], d = q[3 * kScoreLdsW];
+        const int nb = (l > hi) + (u > hi) + (r > hi) + (d > hi), nd = (l < lo) + (u < lo) + (r < lo) + (d < lo);
+        const bool pass = (nb >= 2 || nd >= 2) && x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3;
+        const unsigned long long m = __ballot(pass);
+        if (m) {  // wave-uniform
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&n_list, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (pass) list[base + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)(ry << 6 | lane);
         }
-        if (x < L.w && y < L.h) {
-            const uint32_t o = (uint32_t)y * (uint32_t)L.w + (uint32_t)x;  // a layer has fewer than 2^32 pixels: uniform base + 32-bit offset
-            score[o] = (uint8_t)s;
-            touch[o] = 0;   // the two bookkeeping maps of the tie logic start empty: cleared here, under the arithmetic,
-            status[o] = 0;  // instead of by two fills of their own
+    }
+    __syncthreads();
+    const int n = n_list;
+    for (int i = threadIdx.x; i < n; i += kDetThreads) {
+        const int e = list[i], ry = e >> 6, lx = e & 63;
+        const int s = ring_score<kScoreLdsW>(tile + (ry + 3) * kScoreLdsW + lx + 4);
+        if (s >= thr) {
+            out[ry * kScoreTileW + lx] = (uint8_t)s;
+            atomicOr(&row_mask[ry], 1ull << lx);
         }
-        const unsigned long long hit = __ballot(s >= a.safe_threshold);
-        if (lane == 0 && hit && y < L.h) atomicAdd(&row_count[y], __popcll(hit));
+    }
+    __syncthreads();
+    // the tile's scores (zeros included: the plane is rewritten by every call), masks and counts
+    uint8_t *score = a.score + plane;
+    if ((L.w & 3) == 0) {
+        for (int k = threadIdx.x; k < kScoreTileH * kScoreTileW / 4; k += kDetThreads) {
+            const int ry = k >> 4, cx = (k & 15) * 4, x = x0 + cx, y = y0 + ry;
+            if (x < L.w && y < L.h) *reinterpret_cast<uint32_t *>(score + (uint32_t)y * (uint32_t)L.w + (uint32_t)x) = reinterpret_cast<const uint32_t *>(out)[k];
+        }
+    } else {
+        for (int k = threadIdx.x; k < kScoreTileH * kScoreTileW; k += kDetThreads) {
+            const int ry = k >> 6, x = x0 + (k & 63), y = y0 + ry;
+            if (x < L.w && y < L.h) score[(uint32_t)y * (uint32_t)L.w + (uint32_t)x] = out[k];
+        }
+    }
+    if (threadIdx.x < kScoreTileH && y0 + (int)threadIdx.x < L.h) {
+        const int y = y0 + threadIdx.x;
+        const unsigned long long m = row_mask[threadIdx.x];
+        a.hit_mask[(int64_t)p * a.dg->mask_words + a.dg->mask_off[layer] + (int64_t)y * tiles_x + tx] = m;
+        if (m) atomicAdd(&a.row_count[(int64_t)p * (a.dg->total_rows + 1) + L.row_base + y], __popcll(m));
     }
 }
 
@@ -369,7 +449,10 @@ __global__ __launch_bounds__(kDetThreads) void det_scan_kernel(DetArgs a)
     }
 }
 
-// one wave per layer row: the row's detections in x order, and the strict part of isMax2D (brisk.cpp:838-872)
+// One wave per layer row: the row's corners in x order (the order of OastDetector9_16::detect), read off the row's hit
+// masks -- a lane per 64-pixel word, a prefix sum over the words' populations, then every lane walks the few bits of
+// its own word -- each classified by the strict part of isMax2D (brisk.cpp:838-872) on the 3 x 3 scores around it.
+// A neighbour that is no corner holds 0 or a true score below the threshold in the score plane: never >= a corner's.
 __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
 {
     // the wave's row is the same in every lane: kept in a scalar register, and so is everything that follows from it alone
@@ -387,62 +470,54 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
     int base = rc[row];
     if (rc[row + 1] == base) return;
     const int64_t plane = (int64_t)p * a.dg->plane_bytes + L.off;
-    const uint8_t *sc = a.score + plane;
+    const uint8_t *srow = a.score + plane + (int64_t)y * L.w;
     const int64_t cbase = (int64_t)p * a.cand_cap;
-    // four pixels per lane where the rows are dword aligned (256 per step), else one; raster order = lane, then byte
-    const bool wide = (L.w & 3) == 0;
-    const int per = wide ? 4 : 1;
-    const uint8_t *srow = sc + (int64_t)y * L.w;
-    constexpr int kSteps = 8;  // a row in chunks of 8 steps of 64 lanes: the chunk's loads are issued together
-    for (int xc = 0; xc < L.w; xc += kSteps * 64 * per) {
-        uint32_t vv[kSteps];
+    const int tiles_x = a.dg->tiles_x[layer];
+    const unsigned long long *mrow = a.hit_mask + (int64_t)p * a.dg->mask_words + a.dg->mask_off[layer] + (int64_t)y * tiles_x;
+    const int tie_base = a.layer_start[(int64_t)p * (kDetMaxLayers + 1) + layer];
+    for (int w0 = 0; w0 < tiles_x; w0 += 64) {
+        const int wi = w0 + lane;
+        unsigned long long m = wi < tiles_x ? mrow[wi] : 0ull;
+        const int cnt = __popcll(m);
+        int incl = cnt;
 #pragma unroll
-        for (int u = 0; u < kSteps; ++u) {
-            const int xl = xc + per * (64 * u + lane);
-            const int xs = min(xl, L.w - per);  // stays inside the row; masked below
-            const uint32_t q = wide ? *reinterpret_cast<const uint32_t *>(srow + xs) : (uint32_t)srow[xs];
-            vv[u] = xl < L.w ? q : 0u;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
         }
+        int idx = base + incl - cnt;
+        base += __shfl(incl, 63);
+        while (m) {
+            const int x = 64 * wi + (__ffsll((long long)m) - 1);
+            m &= m - 1;
+            if (idx < a.cand_cap) {
+                uint32_t r0, r1, r2;  // scores x - 1 .. x + 2 of the three rows (a corner lies >= 3 pixels inside the layer)
+                __builtin_memcpy(&r0, srow + x - 1 - L.w, 4);
+                __builtin_memcpy(&r1, srow + x - 1, 4);
+                __builtin_memcpy(&r2, srow + x - 1 + L.w, 4);
+                const int s = (int)((r1 >> 8) & 0xff);
+                int hi = 0, eq = 0;
 #pragma unroll
-        for (int u = 0; u < kSteps; ++u) {
-            const int xl = xc + per * (64 * u + lane);
-            const uint32_t v4 = vv[u];
-            int below = 0, total = 0;
-            bool hit[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                hit[j] = j < per && (int)((v4 >> (8 * j)) & 0xff) >= a.safe_threshold;  // the score is zero outside the 3-pixel border
-                const unsigned long long m = __ballot(hit[j]);
-                below += __popcll(m & ((1ull << lane) - 1));
-                total += __popcll(m);
-            }
-            if (total == 0) continue;  // wave-uniform
-            int idx = base + below;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (!hit[j]) continue;
-                const int x = xl + j, s = (int)((v4 >> (8 * j)) & 0xff);
-                if (idx < a.cand_cap) {
-                    const uint8_t *q = srow + x;
-                    int hi = 0, eq = 0;
-#pragma unroll
-                    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                        for (int dx = -1; dx <= 1; ++dx) {
-                            if (dx == 0 && dy == 0) continue;
-                            const int v = q[dy * L.w + dx];
-                            hi |= v > s;
-                            eq |= v == s;
-                        }
-                    const uint8_t flag = hi ? kDetNotMax : (eq ? kDetTie : kDetMax);
-                    a.cand_xy[cbase + idx] = (uint32_t)x | ((uint32_t)y << 16);
-                    a.cand_flag[cbase + idx] = flag;
-                    a.cand_emit[cbase + idx] = 0;
-                    if (flag == kDetTie) a.status[plane + (int64_t)y * L.w + x] = kStPending;
+                for (int k = 0; k < 3; ++k) {
+                    const int v0 = (int)((r0 >> (8 * k)) & 0xff), v2 = (int)((r2 >> (8 * k)) & 0xff);
+                    hi |= (v0 > s) | (v2 > s);
+                    eq |= (v0 == s) | (v2 == s);
                 }
-                ++idx;
+                const int vl = (int)(r1 & 0xff), vr = (int)((r1 >> 16) & 0xff);
+                hi |= (vl > s) | (vr > s);
+                eq |= (vl == s) | (vr == s);
+                const uint8_t flag = hi ? kDetNotMax : (eq ? kDetTie : kDetMax);
+                a.cand_xy[cbase + idx] = (uint32_t)x | ((uint32_t)y << 16);
+                a.cand_flag[cbase + idx] = flag;
+                a.cand_emit[cbase + idx] = 0;
+                a.cand_asked[cbase + idx] = 0ull;
+                if (flag == kDetTie) {
+                    a.status[plane + (int64_t)y * L.w + x] = kStPending;
+                    const int k = atomicAdd(&a.tie_count[(int64_t)p * kDetMaxLayers + layer], 1);
+                    a.tie_list[cbase + tie_base + k] = idx;
+                }
             }
-            base += total;
+            ++idx;
         }
     }
 }

@@ -197,7 +197,13 @@ struct DetGeom {
     int32_t n_layers, total_rows;
     int64_t plane_bytes;  // one pair, all layers
     DetLayer L[kDetMaxLayers];
+    // the corner kernel's 64 x 32-pixel tiles: tiles per row of a layer, first tile of a layer in the pair's tile list
+    // (tile_start[n_layers] = tiles per pair); the hit masks -- one 64-bit word per tile row and layer row: bit b of word
+    // (y, tx) = pixel (64 tx + b, y) is a detected corner -- start at word mask_off[l] of the pair's mask_words words
+    int32_t tiles_x[kDetMaxLayers], tile_start[kDetMaxLayers + 1];
+    int64_t mask_off[kDetMaxLayers], mask_words;
 };
+constexpr int kDetTileW = 64, kDetTileH = 32;
 // candidate flags
 enum : uint8_t { kDetNotMax = 0, kDetMax = 1, kDetTie = 2 };
 // status-map values (one byte per pixel, written only by the thread that owns that candidate)
@@ -212,15 +218,22 @@ struct DetArgs {
     int32_t n_pairs;
     int32_t threshold, safe_threshold;
     int32_t fp_x87;     // 1: float expressions as the reference's x87 build evaluates them (mofreak_params.brisk_fp_model)
-    uint8_t *img, *score, *touch, *status;  // [n_pairs][plane_bytes]
+    // [n_pairs][plane_bytes] each.  score: the reference's score cache as far as anyone reads it -- the corner score where a
+    // pixel is a detected corner (>= safe_threshold), elsewhere 0 or, once a refinement walk has computed it, the cell's
+    // true score (< safe_threshold; meaningful only where touch / status say the reference would have cached it).
+    // touch / status are all zero between calls: whoever sets a byte clears it again (det_emit_scatter_kernel).
+    uint8_t *img, *score, *touch, *status;
+    unsigned long long *hit_mask;           // [n_pairs][mask_words]: DetGeom::mask_off
     int32_t *row_count;                     // [n_pairs][total_rows + 1]: counts, then exclusive offsets
     int32_t cand_cap;                       // per pair
     uint32_t *cand_xy;                      // [n_pairs][cand_cap]  x | y << 16
     uint8_t *cand_flag;                     // [n_pairs][cand_cap]
     uint8_t *cand_emit;                     // [n_pairs][cand_cap]
     uint8_t *cand_spec;                     // [n_pairs][cand_cap] ties: emit / reached bits of the refinement run ahead of the decision
-    unsigned long long *cand_asked;         // [n_pairs][cand_cap] ties: cells asked for in the layer above (bit mask over a 6 x 6 window)
-    uint32_t *cand_win;                     // [n_pairs][cand_cap] ties: that window's origin, x | y << 16
+    unsigned long long *cand_asked;         // [n_pairs][cand_cap] cells a walk asked for in the layer above (bit mask over a 6 x 6 window; 0: none)
+    uint32_t *cand_win;                     // [n_pairs][cand_cap] that window's origin, x | y << 16
+    int32_t *tie_list;                      // [n_pairs][cand_cap]: the ties of layer l at [layer_start[l], layer_start[l] + tie_count[l]) in any order
+    int32_t *tie_count;                     // [n_pairs][kDetMaxLayers], zeroed per batch
     DetResult *cand_res;                    // [n_pairs][cand_cap]
     int32_t *layer_start;                   // [n_pairs][kDetMaxLayers + 1]
     int32_t *emit_count;                    // [n_pairs]
@@ -254,7 +267,8 @@ int launch_bow_assign(const uint8_t *desc, const uint8_t *valid, int64_t n, cons
 int launch_bow_normalize(const unsigned int *counts, int n_codewords, float *hist, int32_t *success, void *stream);
 int launch_unpack_integral(const int32_t *src, int pitch, int W, int H, int n_pairs, int32_t *dst, void *stream);
 int launch_det_pyramid(const DetArgs &a, void *stream);   // difference image + the resampled layers
-int launch_det_scores(const DetArgs &a, void *stream);    // dense corner scores + per-row detection counts
+int launch_det_corners(const DetArgs &a, void *stream);   // corner scores where a pixel is a corner (0 elsewhere), hit masks, per-row detection counts
+int launch_det_scores(const DetArgs &a, void *stream);    // component entry point only: the dense corner score of every pixel
 int launch_det_keypoints(const DetArgs &a, int64_t *running, void *stream);  // candidates, maxima, refinement, ordered emission
 
 }  // namespace mofreak
