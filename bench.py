@@ -39,6 +39,29 @@ PCIE_GBS = 63.0        # host link, same guide
 METRIC = "MoFREAK descriptors/sec on dense 1080p frames; achieved HBM GB/s vs peak"
 
 
+_JSON_FD = None  # the process's real standard output (see quiet_stdout)
+
+
+def quiet_stdout():
+    """The job's standard output carries ONE JSON line.  Native libraries print there too (RCCL's version banner at
+    communicator creation, for one): from here on file descriptor 1 is standard error, and emit() writes the line to the
+    descriptor that was standard output when the process started."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def make_stack(T, W, H, t0, workers):
     from mofreak_amd import synth
     out = np.empty((T, H, W), np.uint8)
@@ -445,7 +468,7 @@ def bench_resident(args):
                     out["detector"][f"at_{big_pairs}_pairs_per_call"] = {k: big[k] for k in ("pairs_per_s", "detect_and_describe_pairs_per_s", "frame_loop")}
             except Exception as e:  # never let the side figure take the metric line down
                 out["detector"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        emit(out)
     ctx.set_stream(None)
     ctx.close()
     if grouped(dist):
@@ -489,7 +512,7 @@ def bench_dataset(args):
         n_kp = len(synth.config_grid("C4"))
         n_desc = int(((lengths - 5).clip(min=0) * n_kp).sum())
         assert res["total_rows"] == n_desc
-        print(json.dumps({
+        emit(({
             "metric": "MoFREAK clips/sec on an HMDB51-shaped batch, one video per GPU, rows gathered to rank 0 (BASELINE config 4)",
             "value": n_clips * steps / elapsed, "unit": "clips/s", "descriptors_per_s": n_desc * steps / elapsed,
             "n_gpus": world, "steps": steps, "warmup": 1, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
@@ -503,7 +526,7 @@ def bench_dataset(args):
             "frames_in_GBs": float(lengths.sum() * W * H * steps / elapsed / 1e9),
             "gather_ms": gather_s * 1e3, "ranks_seen": ranks_seen(dist, world), **dist_info(dist, args), "rounds": res["rounds"], "frames_in_MB_per_step": float(lengths.sum() * W * H / 1e6),
             "note": f"host frames in ({'pageable' if args.pageable else 'page-locked'} memory) -> rows on rank 0's host; "
-                    "compute, gather and the root's device-to-host copy are all inside the timed region"}), flush=True)
+                    "compute, gather and the root's device-to-host copy are all inside the timed region"}))
     mo.close()
     if grouped(dist):
         dist.barrier()
@@ -560,7 +583,7 @@ def bench_stream(args):
         value = world * n_desc * steps / elapsed
         # the link is full duplex: one new frame in per processed frame on the way down, 32-byte rows on the way up
         pcie_bound = PCIE_GBS * 1e9 / max(W * H / len(kps), 32.0)
-        print(json.dumps({
+        emit(({
             "metric": "MoFREAK sustained descriptors/sec on a TRECVID-shaped stream, host frames in and rows out included (BASELINE config 5)",
             "value": value, "unit": "descriptors/s", "n_gpus": world, "steps": steps, "warmup": 1,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
@@ -570,7 +593,7 @@ def bench_stream(args):
                        "parallelism": f"one stream per GPU x{world}"},
             "ranks_seen": ranks_seen(dist, world), **dist_info(dist, args), "frames_per_s": world * (T - 5) * steps / elapsed, "resident_descriptors_per_s": resident,
             "pcie_bound_descriptors_per_s": pcie_bound, "frac_of_min_bound": value / world / min(pcie_bound, resident),
-            "h2d_GBs": (T * W * H * steps / elapsed) / 1e9, "d2h_GBs": (n_desc * 32 * steps / elapsed) / 1e9}), flush=True)
+            "h2d_GBs": (T * W * H * steps / elapsed) / 1e9, "d2h_GBs": (n_desc * 32 * steps / elapsed) / 1e9}))
     ctx.host_free(frames)
     ctx.host_free(rows)
     ctx.close()
@@ -610,6 +633,7 @@ def main():
         # `python bench.py --gpus N` by itself: N fresh rank processes, started before this one has made any GPU call
         # (it never makes one); rank 0's line is the job's, a failing rank fails the job.
         raise SystemExit(launch.self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:], timeout_s=args.launch_timeout))
+    quiet_stdout()
     if args.config in ("C2", "C3"):
         bench_resident(args)
     elif args.config == "C4":
