@@ -43,7 +43,8 @@ struct mofreak_ctx {
     DeviceBuffer bow_counts, bow_expanded, pair_label;
     // keypoint detector workspace
     DeviceBuffer det_img, det_score, det_touch, det_status, det_rows, det_cand_xy, det_cand_flag, det_cand_emit, det_cand_spec, det_cand_asked, det_cand_win, det_cand_res, det_layer_start,
-        det_emit_count, det_emit_chunks, det_wait_list, det_geom, det_emit_offsets, det_out_kps, det_out_offsets, det_out_resp, det_out_layer, det_planes_out;
+        det_emit_count, det_emit_chunks, det_geom, det_emit_offsets, det_out_kps, det_out_offsets, det_out_resp, det_out_layer, det_planes_out, det_hit_mask, det_walk_list, det_walk_count, det_cand_cells;
+    bool det_maps_dirty = false;  // a detector call stopped half way: its touch / status bytes may still be set
     int det_cand_cap = 131072;
     size_t det_counter_bytes = 0;  // row counts + tie counters behind the running total in det_rows
     int64_t det_kp_capacity = 0;
@@ -692,8 +693,8 @@ void mofreak_destroy(mofreak_ctx *ctx)
     release(ctx->bow_counts);
     release(ctx->bow_expanded);
     for (DeviceBuffer *b : {&ctx->det_img, &ctx->det_score, &ctx->det_touch, &ctx->det_status, &ctx->det_rows, &ctx->det_cand_xy, &ctx->det_cand_flag,
-                            &ctx->det_cand_emit, &ctx->det_cand_spec, &ctx->det_cand_asked, &ctx->det_cand_win, &ctx->det_cand_res, &ctx->det_layer_start, &ctx->det_emit_count, &ctx->det_emit_chunks, &ctx->det_wait_list, &ctx->det_geom, &ctx->det_emit_offsets,
-                            &ctx->det_out_kps, &ctx->det_out_offsets, &ctx->det_out_resp, &ctx->det_out_layer, &ctx->det_planes_out})
+                            &ctx->det_cand_emit, &ctx->det_cand_spec, &ctx->det_cand_asked, &ctx->det_cand_win, &ctx->det_cand_res, &ctx->det_layer_start, &ctx->det_emit_count, &ctx->det_emit_chunks, &ctx->det_geom, &ctx->det_emit_offsets,
+                            &ctx->det_out_kps, &ctx->det_out_offsets, &ctx->det_out_resp, &ctx->det_out_layer, &ctx->det_planes_out, &ctx->det_hit_mask, &ctx->det_walk_list, &ctx->det_walk_count, &ctx->det_cand_cells})
         release(*b);
     release(ctx->integral);
     release(ctx->band_totals);
@@ -1641,6 +1642,18 @@ int det_geometry(const mofreak_ctx *ctx, int W, int H, int octaves, DetGeom &g)
     }
     g.plane_bytes = off + 64;
     g.total_rows = rows;
+    // the corner kernel's tiles and hit-mask words (one 64-bit word per tile row and layer row)
+    int64_t tiles = 0, words = 0;
+    for (int i = 0; i < g.n_layers; ++i) {
+        g.tiles_x[i] = (g.L[i].w + kDetTileW - 1) / kDetTileW;
+        g.tile_start[i] = (int32_t)tiles;
+        g.mask_off[i] = words;
+        tiles += (int64_t)g.tiles_x[i] * ((g.L[i].h + kDetTileH - 1) / kDetTileH);
+        words += (int64_t)g.tiles_x[i] * g.L[i].h;
+    }
+    if (tiles >= ((int64_t)1 << 31)) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "frame too large for the detector's tile list");
+    for (int i = g.n_layers; i <= kDetMaxLayers; ++i) g.tile_start[i] = (int32_t)tiles;
+    g.mask_words = words;
     return MOFREAK_OK;
 }
 
@@ -1650,13 +1663,26 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     const size_t planes = (size_t)batch * g.plane_bytes, cands = (size_t)batch * ctx->det_cand_cap;
     if ((rc = ensure(ctx, ctx->det_img, planes))) return rc;
     if ((rc = ensure(ctx, ctx->det_score, planes))) return rc;
+    // The two bookkeeping maps of the tie logic are all zero between calls: the emission takes back every byte a call set.
+    // They are filled once when they are (re)allocated, and again after a call that did not run to its end.
+    const void *touch_was = ctx->det_touch.ptr, *status_was = ctx->det_status.ptr;
     if ((rc = ensure(ctx, ctx->det_touch, planes))) return rc;
     if ((rc = ensure(ctx, ctx->det_status, planes))) return rc;
-    // one buffer, one fill: the call's running keypoint total (16 bytes), the per-row counts, the tie counters
-    const size_t n_row_counts = (size_t)batch * (g.total_rows + 1), n_tie_counters = (size_t)batch * kDetMaxLayers * 2;
-    if ((rc = ensure(ctx, ctx->det_rows, 16 + (n_row_counts + n_tie_counters) * sizeof(int32_t)))) return rc;
+    if (ctx->det_touch.ptr != touch_was || ctx->det_status.ptr != status_was || ctx->det_maps_dirty) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->det_touch.ptr, 0, ctx->det_touch.bytes, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->det_status.ptr, 0, ctx->det_status.bytes, ctx->stream));
+        ctx->det_maps_dirty = false;
+    }
+    if ((rc = ensure(ctx, ctx->det_hit_mask, (size_t)batch * g.mask_words * sizeof(unsigned long long)))) return rc;
+    a.walk_chunks = (ctx->det_cand_cap + 511) / 512;
+    if ((rc = ensure(ctx, ctx->det_walk_list, cands * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->det_walk_count, (size_t)batch * a.walk_chunks * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->det_cand_cells, cands * 128))) return rc;
+    // one buffer, one fill: the call's running keypoint total (16 bytes) and the per-row counts
+    const size_t n_row_counts = (size_t)batch * (g.total_rows + 1);
+    if ((rc = ensure(ctx, ctx->det_rows, 16 + n_row_counts * sizeof(int32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_cand_xy, cands * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->det_cand_flag, cands))) return rc;
+    if ((rc = ensure(ctx, ctx->det_cand_flag, cands + 64))) return rc;  // (read sixteen at a time)
     if ((rc = ensure(ctx, ctx->det_cand_emit, cands))) return rc;
     if ((rc = ensure(ctx, ctx->det_cand_spec, cands))) return rc;
     if ((rc = ensure(ctx, ctx->det_cand_asked, cands * sizeof(unsigned long long)))) return rc;
@@ -1675,8 +1701,11 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     a.touch = static_cast<uint8_t *>(ctx->det_touch.ptr);
     a.status = static_cast<uint8_t *>(ctx->det_status.ptr);
     a.row_count = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(ctx->det_rows.ptr) + 16);
-    a.tie_waiting = a.row_count + n_row_counts;
-    ctx->det_counter_bytes = (n_row_counts + n_tie_counters) * sizeof(int32_t);
+    a.hit_mask = static_cast<unsigned long long *>(ctx->det_hit_mask.ptr);
+    a.walk_list = static_cast<int32_t *>(ctx->det_walk_list.ptr);
+    a.walk_count = static_cast<int32_t *>(ctx->det_walk_count.ptr);
+    a.cand_cells = static_cast<uint8_t *>(ctx->det_cand_cells.ptr);
+    ctx->det_counter_bytes = n_row_counts * sizeof(int32_t);
     a.cand_cap = ctx->det_cand_cap;
     a.cand_xy = static_cast<uint32_t *>(ctx->det_cand_xy.ptr);
     a.cand_flag = static_cast<uint8_t *>(ctx->det_cand_flag.ptr);
@@ -1689,19 +1718,18 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     a.emit_count = static_cast<int32_t *>(ctx->det_emit_count.ptr);
     a.emit_offsets = static_cast<int64_t *>(ctx->det_emit_offsets.ptr);
     a.emit_chunks = static_cast<int32_t *>(ctx->det_emit_chunks.ptr);
-    if ((rc = ensure(ctx, ctx->det_wait_list, (size_t)batch * 4096 * sizeof(int32_t)))) return rc;
-    a.wait_list = static_cast<int32_t *>(ctx->det_wait_list.ptr);
     a.status_word = ctx->d_status + 1;  // the detector's own word: clearing it leaves the describe kernels' flags alone
     a.fp_x87 = ctx->params.brisk_fp_model == MOFREAK_FP_X87 ? 1 : 0;
     return MOFREAK_OK;
 }
 
-// pairs per batch: about 4 GiB of planes and candidate records (a small share of the 288 GB): the tie rounds are a
+// pairs per batch: about 8 GiB of planes and candidate records (a small share of the 288 GB): the tie rounds are a
 // chain of short latency-bound launches per batch, so the more pairs share them the better
 int det_batch(const mofreak_ctx *ctx, const DetGeom &g, int n_pairs)
 {
-    const size_t per_pair = 4 * (size_t)g.plane_bytes + (size_t)ctx->det_cand_cap * (sizeof(uint32_t) + 3 + 12 + sizeof(DetResult));
-    const size_t b = std::max<size_t>(1, ((size_t)4 << 30) / per_pair);
+    const size_t per_pair = 4 * (size_t)g.plane_bytes + (size_t)g.mask_words * 8 +
+                            (size_t)ctx->det_cand_cap * (sizeof(uint32_t) + 3 + 12 + sizeof(DetResult) + sizeof(int32_t) + 128);
+    const size_t b = std::max<size_t>(1, ((size_t)8 << 30) / per_pair);
     return (int)std::min<size_t>({b, (size_t)std::max(n_pairs, 1), (size_t)16384});
 }
 
@@ -1775,19 +1803,20 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
     a.out_layer = d_layer;
     a.out_capacity = capacity;
     a.out_offsets = d_off;
+    ctx->det_maps_dirty = true;  // until the call has run to its end (every early return below leaves it set)
     for (int p0 = 0; p0 < n_pairs; p0 += batch) {
         const int np = std::min(batch, n_pairs - p0);
         a.n_pairs = np;
         a.first_pair = p0;
         a.f = FrameArgs{d_cur + (int64_t)p0 * pair_stride, d_prev ? d_prev + (int64_t)p0 * pair_stride : nullptr, W, H, row_stride, pair_stride};
         // the counters of the batch (and, in front of them, the call's running total before its first batch); the touch
-        // and status maps are cleared by det_score_kernel
+        // and status maps are zero already (det_workspace) and are left zero by the emission
         if (p0 == 0)
             HIP_TRY(ctx, hipMemsetAsync(running, 0, 16 + ctx->det_counter_bytes, ctx->stream));
         else
             HIP_TRY(ctx, hipMemsetAsync(a.row_count, 0, ctx->det_counter_bytes, ctx->stream));
         int e = launch_det_pyramid(a, ctx->stream);
-        if (!e) e = launch_det_scores(a, ctx->stream);
+        if (!e) e = launch_det_corners(a, ctx->stream);
         if (!e) e = launch_det_keypoints(a, running, ctx->stream);
         if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("detector launch: ") + hipGetErrorString((hipError_t)e));
     }
@@ -1797,6 +1826,7 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
     HIP_TRY(ctx, hipMemcpyAsync(&st, ctx->d_status + 1, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (n_out) *n_out = total;
+    ctx->det_maps_dirty = (st & (16 | 32)) != 0;  // the emission of every batch has taken its bytes back
     if (st & 16) return fail(ctx, MOFREAK_ERR_HIP, "detector: a refinement walk left its staged window (internal error)");
     if (st & 32) return fail(ctx, MOFREAK_ERR_HIP, "detector: a chain of tied scores did not resolve within its pass budget (internal error)");
     if (st & 4) return fail(ctx, MOFREAK_ERR_CAPACITY, "more corner candidates in one pair than the detector reserved (mofreak_detect_set_capacity)");

@@ -36,11 +36,14 @@ namespace mofreak {
 namespace {
 
 constexpr int kDetThreads = 256;
+// cand_spec bits (kWasTie: set by the candidate kernel; the others by the refinement run ahead of a tie's decision)
+constexpr uint8_t kEmit = 1, kReached = 2, kWasTie = 0x80;
 
 struct PairView {
     const DetGeom *g;
     const uint8_t *img;
     const uint8_t *score;
+    uint8_t *score_rw;  // the same plane, for the refinement's writes
     uint8_t *touch;
     uint8_t *status;
 };
@@ -66,6 +69,7 @@ __device__ __forceinline__ PairView pair_view(const DetArgs &a, int p)
     const int64_t o = (int64_t)p * a.dg->plane_bytes;
     v.img = a.img + o;
     v.score = a.score + o;
+    v.score_rw = a.score + o;
     v.touch = a.touch + o;
     v.status = a.status + o;
     return v;
@@ -261,13 +265,14 @@ __device__ __forceinline__ void arc9_extremes(const int (&p)[16], int &max_of_mi
     min_of_max = min(min3i(hi5[0], hi5[1], hi5[2]), min3i(hi5[3], hi5[4], hi9[15]));
 }
 
-constexpr int kScoreTileW = kDetTileW, kScoreTileH = kDetTileH, kScoreLdsW = 72;  // LDS rows start at image column x0 - 4: aligned dwords
+constexpr int kScoreTileW = 64, kScoreTileH = 32, kScoreLdsW = 72;  // LDS rows start at image column x0 - 4: aligned dwords
 
-// a tile of a layer's image with its 3-pixel ring halo -> LDS (rows of kScoreLdsW bytes, first column x0 - 4)
+// a tile of TILE_H rows of a layer's image with its 3-pixel ring halo -> LDS (rows of kScoreLdsW bytes, first column x0 - 4)
+template <int TILE_H>
 __device__ __forceinline__ void score_tile_load(uint8_t *tile, const uint8_t *img, const DetLayer &L, int x0, int y0)
 {
     if ((L.w & 3) == 0) {  // rows start on dword boundaries (layer planes are 64-byte aligned): 18 aligned dwords per tile row
-        for (int t = threadIdx.x; t < (kScoreTileH + 6) * (kScoreLdsW / 4); t += kDetThreads) {
+        for (int t = threadIdx.x; t < (TILE_H + 6) * (kScoreLdsW / 4); t += kDetThreads) {
             const int r = t / (kScoreLdsW / 4), k = t - r * (kScoreLdsW / 4);
             const int gx = x0 - 4 + 4 * k, gy = y0 - 3 + r;
             const bool in = gx >= 0 && gx < L.w && gy >= 0 && gy < L.h;
@@ -275,7 +280,7 @@ __device__ __forceinline__ void score_tile_load(uint8_t *tile, const uint8_t *im
             *reinterpret_cast<uint32_t *>(tile + r * kScoreLdsW + 4 * k) = v;
         }
     } else {
-        for (int t = threadIdx.x; t < (kScoreTileH + 6) * kScoreLdsW; t += kDetThreads) {
+        for (int t = threadIdx.x; t < (TILE_H + 6) * kScoreLdsW; t += kDetThreads) {
             const int r = t / kScoreLdsW, c = t - r * kScoreLdsW;
             const int gx = x0 - 4 + c, gy = y0 - 3 + r;
             tile[r * kScoreLdsW + c] = (gx >= 0 && gx < L.w && gy >= 0 && gy < L.h) ? img[(int64_t)gy * L.w + gx] : 0;
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(kDetThreads) void det_dense_score_kernel(DetArgs a,
     __shared__ __attribute__((aligned(4))) uint8_t tile[(kScoreTileH + 6) * kScoreLdsW];
     const DetLayer L = a.dg->L[layer];
     const int p = blockIdx.z, x0 = blockIdx.x * kScoreTileW, y0 = blockIdx.y * kScoreTileH;
-    score_tile_load(tile, a.img + (int64_t)p * a.dg->plane_bytes + L.off, L, x0, y0);
+    score_tile_load<kScoreTileH>(tile, a.img + (int64_t)p * a.dg->plane_bytes + L.off, L, x0, y0);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint8_t *score = a.score + (int64_t)p * a.dg->plane_bytes + L.off;
@@ -333,19 +338,48 @@ __global__ __launch_bounds__(kDetThreads) void det_dense_score_kernel(DetArgs a,
 }
 
 // ------------------------------------------------------------------ corners (what OastDetector9_16::detect + getAgastPoints leave behind)
-// One workgroup per 64 x 32 tile of a layer, all layers in one launch.  The reference's decision tree answers "is there an
+// One workgroup per 64 x 64 tile of a layer, all layers in one launch.  The reference's decision tree answers "is there an
 // arc of 9 ring pixels all brighter than c + t or all darker than c - t" with a handful of comparisons for most pixels;
 // the data-parallel counterpart: (1) a necessary condition on the four compass points of the ring -- an arc of 9 holds at
-// least two of them, so two must be brighter (darker) -- passes a few percent of a difference image's pixels; (2) the
-// survivors of a tile are compacted and only they get the full score (the arc extremes), with full wavefronts.  Leaves,
-// per tile: the score plane (score where >= threshold, 0 elsewhere: the reference's cache after getAgastPoints,
-// brisk.cpp:1676-1690), a 64-bit hit mask per tile row, and the per-row corner counts.
+// least two of them, so the second largest of their differences to the centre must exceed t (or the second smallest lie
+// below -t) -- evaluated for four neighbouring pixels per lane on aligned dwords with packed 16-bit arithmetic (14
+// vector operations per pixel; the kernel is bound by vector issue); it passes a few percent of a difference image's
+// pixels; (2) the survivors of a tile are compacted and only they get the full score (the arc extremes), with full
+// wavefronts.  Leaves, per tile: the score plane (score where >= threshold, 0 elsewhere: the reference's cache after
+// getAgastPoints, brisk.cpp:1676-1690), a 64-bit hit mask per tile row, and the per-row corner counts.
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s as_v2s(uint32_t x) { return __builtin_bit_cast(v2s, x); }
+__device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_cast(uint32_t, x); }
+
+// bit i: pixel i of the dword C (its left / right neighbours at distance 3 in L4 / R4, upper / lower in U / D) passes
+__device__ __forceinline__ uint32_t compass_test4(uint32_t C, uint32_t L4, uint32_t R4, uint32_t U, uint32_t D, int t)
+{
+    const v2s T1 = {(short)(t + 1), (short)(t + 1)}, T = {(short)t, (short)t};
+    uint32_t res = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t sel = h ? 0x0c030c02u : 0x0c010c00u;  // bytes (2, 3) / (0, 1), zero-extended to 16 bits each
+        const v2s c = as_v2s(__builtin_amdgcn_perm(C, C, sel)), l = as_v2s(__builtin_amdgcn_perm(L4, L4, sel)), r = as_v2s(__builtin_amdgcn_perm(R4, R4, sel)),
+                  u = as_v2s(__builtin_amdgcn_perm(U, U, sel)), d = as_v2s(__builtin_amdgcn_perm(D, D, sel));
+        const v2s dl = l - c, dr = r - c, du = u - c, dd = d - c;
+        const v2s mx1 = __builtin_elementwise_max(dl, dr), mn1 = __builtin_elementwise_min(dl, dr), mx2 = __builtin_elementwise_max(du, dd),
+                  mn2 = __builtin_elementwise_min(du, dd);
+        const v2s lo_of_max = __builtin_elementwise_min(mx1, mx2), hi_of_min = __builtin_elementwise_max(mn1, mn2);
+        const v2s second_largest = __builtin_elementwise_max(lo_of_max, hi_of_min), second_smallest = __builtin_elementwise_min(lo_of_max, hi_of_min);
+        // second_largest >= t + 1 (sign of the difference clear) or second_smallest + t < 0 (sign set), per 16-bit half
+        const uint32_t m = (~as_u32(second_largest - T1) | as_u32(second_smallest + T)) & 0x80008000u;
+        res |= ((m >> 15) & 1u) << (2 * h) | (m >> 31) << (2 * h + 1);
+    }
+    return res;
+}
+
 __global__ __launch_bounds__(kDetThreads) void det_corner_kernel(DetArgs a)
 {
-    __shared__ __attribute__((aligned(4))) uint8_t tile[(kScoreTileH + 6) * kScoreLdsW];
-    __shared__ __attribute__((aligned(8))) uint8_t out[kScoreTileH * kScoreTileW];
-    __shared__ uint16_t list[kScoreTileH * kScoreTileW];
-    __shared__ unsigned long long row_mask[kScoreTileH];
+    constexpr int kPasses = kDetTileH / 16;  // 16 rows of 16 four-pixel groups per pass of the 256 threads
+    __shared__ __attribute__((aligned(16))) uint8_t tile[(kDetTileH + 6) * kScoreLdsW];
+    __shared__ __attribute__((aligned(16))) uint8_t out[kDetTileH * kDetTileW];
+    __shared__ uint16_t list[kDetTileH * kDetTileW];
+    __shared__ unsigned long long row_mask[kDetTileH];
     __shared__ int n_list;
     const int p = blockIdx.y, t = blockIdx.x;
     int layer = 0;  // from the argument block's copy of the geometry with constant indices: scalar compares, no memory
@@ -353,56 +387,77 @@ __global__ __launch_bounds__(kDetThreads) void det_corner_kernel(DetArgs a)
     for (int k = 1; k < kDetMaxLayers; ++k) layer += (k < a.g.n_layers && t >= a.g.tile_start[k]) ? 1 : 0;
     const DetLayer L = a.dg->L[layer];
     const int tiles_x = a.dg->tiles_x[layer], tl = t - a.dg->tile_start[layer];
-    const int ty = tl / tiles_x, tx = tl - ty * tiles_x, x0 = tx * kScoreTileW, y0 = ty * kScoreTileH;
+    const int ty = tl / tiles_x, tx = tl - ty * tiles_x, x0 = tx * kDetTileW, y0 = ty * kDetTileH;
     const int64_t plane = (int64_t)p * a.dg->plane_bytes + L.off;
-    score_tile_load(tile, a.img + plane, L, x0, y0);
-    for (int k = threadIdx.x; k < kScoreTileH * kScoreTileW / 4; k += kDetThreads) reinterpret_cast<uint32_t *>(out)[k] = 0u;
-    if (threadIdx.x < kScoreTileH) row_mask[threadIdx.x] = 0ull;
+    score_tile_load<kDetTileH>(tile, a.img + plane, L, x0, y0);
+    static_assert(kDetTileH * kDetTileW == 16 * kDetThreads, "a thread clears 16 bytes of the tile's scores");
+    reinterpret_cast<uint4 *>(out)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < kDetTileH) row_mask[threadIdx.x] = 0ull;
     if (threadIdx.x == 0) n_list = 0;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     const int thr = a.safe_threshold;
+    // (1) the compass test: thread = (row r0 of a pass, group g of four pixels); survivors per pass and pixel as ballots,
+    // then ONE reservation in the tile's list for all of the wave's survivors
+    const int g = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+    uint32_t colmask = 0;  // which of the group's four columns lie inside the scored region
 #pragma unroll
-    for (int it = 0; it < kScoreTileH / 4; ++it) {
-        const int ry = wave + 4 * it, x = x0 + lane, y = y0 + ry;
-        const uint8_t *q = tile + (ry + 3) * kScoreLdsW + lane + 4;
-        const int c = q[0], hi = c + thr, lo = c - thr;
-        const int l = q[-3], u = q[-3 * kScoreLdsW], r = q[3], d = q[3 * kScoreLdsW];
-        const int nb = (l > hi) + (u > hi) + (r > hi) + (d > hi), nd = (l < lo) + (u < lo) + (r < lo) + (d < lo);
-        const bool pass = (nb >= 2 || nd >= 2) && x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3;
-        const unsigned long long m = __ballot(pass);
-        if (m) {  // wave-uniform
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&n_list, __popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (pass) list[base + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)(ry << 6 | lane);
+    for (int i = 0; i < 4; ++i) colmask |= (x0 + 4 * g + i >= 3 && x0 + 4 * g + i < L.w - 3) ? 1u << i : 0u;
+    unsigned long long pm[kPasses][4];
+    int n_wave = 0;
+#pragma unroll
+    for (int j = 0; j < kPasses; ++j) {
+        const int ry = r0 + 16 * j, y = y0 + ry;
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(tile + (ry + 3) * kScoreLdsW) + g + 1;  // the dword of columns 4g .. 4g + 3
+        const uint32_t C = q[0], Cp = q[-1], Cn = q[1], U = q[-3 * (kScoreLdsW / 4)], D = q[3 * (kScoreLdsW / 4)];
+        uint32_t m4 = compass_test4(C, __builtin_amdgcn_alignbyte(C, Cp, 1), __builtin_amdgcn_alignbyte(Cn, C, 3), U, D, thr);
+        m4 = (y >= 3 && y < L.h - 3) ? (m4 & colmask) : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pm[j][i] = __ballot((m4 >> i) & 1u);
+            n_wave += __popcll(pm[j][i]);
         }
     }
+    if (n_wave) {  // wave-uniform
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&n_list, n_wave);
+        base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+        for (int j = 0; j < kPasses; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned long long m = pm[j][i];
+                if ((m >> lane) & 1) list[base + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)((r0 + 16 * j) << 6 | (4 * g + i));
+                base += __popcll(m);
+            }
+    }
     __syncthreads();
+    // (2) the survivors' scores
     const int n = n_list;
     for (int i = threadIdx.x; i < n; i += kDetThreads) {
         const int e = list[i], ry = e >> 6, lx = e & 63;
         const int s = ring_score<kScoreLdsW>(tile + (ry + 3) * kScoreLdsW + lx + 4);
         if (s >= thr) {
-            out[ry * kScoreTileW + lx] = (uint8_t)s;
+            out[ry * kDetTileW + lx] = (uint8_t)s;
             atomicOr(&row_mask[ry], 1ull << lx);
         }
     }
     __syncthreads();
     // the tile's scores (zeros included: the plane is rewritten by every call), masks and counts
-    uint8_t *score = a.score + plane;
-    if ((L.w & 3) == 0) {
-        for (int k = threadIdx.x; k < kScoreTileH * kScoreTileW / 4; k += kDetThreads) {
-            const int ry = k >> 4, cx = (k & 15) * 4, x = x0 + cx, y = y0 + ry;
-            if (x < L.w && y < L.h) *reinterpret_cast<uint32_t *>(score + (uint32_t)y * (uint32_t)L.w + (uint32_t)x) = reinterpret_cast<const uint32_t *>(out)[k];
-        }
-    } else {
-        for (int k = threadIdx.x; k < kScoreTileH * kScoreTileW; k += kDetThreads) {
-            const int ry = k >> 6, x = x0 + (k & 63), y = y0 + ry;
-            if (x < L.w && y < L.h) score[(uint32_t)y * (uint32_t)L.w + (uint32_t)x] = out[k];
+    {
+        uint8_t *score = a.score + plane;
+        const int ry = threadIdx.x >> 2, cx = (threadIdx.x & 3) * 16, x = x0 + cx, y = y0 + ry;
+        if (y < L.h && x < L.w) {
+            uint8_t *dst = score + (uint32_t)y * (uint32_t)L.w + (uint32_t)x;
+            const uint4 v = reinterpret_cast<const uint4 *>(out)[threadIdx.x];
+            if (x + 16 <= L.w) {
+                __builtin_memcpy(dst, &v, 16);
+            } else {
+                for (int k = 0; k < L.w - x; ++k) dst[k] = out[ry * kDetTileW + cx + k];
+            }
         }
     }
-    if (threadIdx.x < kScoreTileH && y0 + (int)threadIdx.x < L.h) {
+    if (threadIdx.x < kDetTileH && y0 + (int)threadIdx.x < L.h) {
         const int y = y0 + threadIdx.x;
         const unsigned long long m = row_mask[threadIdx.x];
         a.hit_mask[(int64_t)p * a.dg->mask_words + a.dg->mask_off[layer] + (int64_t)y * tiles_x + tx] = m;
@@ -474,10 +529,9 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
     const int64_t cbase = (int64_t)p * a.cand_cap;
     const int tiles_x = a.dg->tiles_x[layer];
     const unsigned long long *mrow = a.hit_mask + (int64_t)p * a.dg->mask_words + a.dg->mask_off[layer] + (int64_t)y * tiles_x;
-    const int tie_base = a.layer_start[(int64_t)p * (kDetMaxLayers + 1) + layer];
     for (int w0 = 0; w0 < tiles_x; w0 += 64) {
         const int wi = w0 + lane;
-        unsigned long long m = wi < tiles_x ? mrow[wi] : 0ull;
+        const unsigned long long m = wi < tiles_x ? mrow[wi] : 0ull;
         const int cnt = __popcll(m);
         int incl = cnt;
 #pragma unroll
@@ -485,12 +539,44 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
             const int t = __shfl_up(incl, o);
             if (lane >= o) incl += t;
         }
-        int idx = base + incl - cnt;
-        base += __shfl(incl, 63);
-        while (m) {
-            const int x = 64 * wi + (__ffsll((long long)m) - 1);
-            m &= m - 1;
-            if (idx < a.cand_cap) {
+        const int total = __shfl(incl, 63);
+        // a lane per corner (the corners of a row cluster in few words: a lane per word would walk them one latency at
+        // a time): corner j of this stretch sits in the first word whose running count exceeds j ...
+        for (int j0 = 0; j0 < total; j0 += 64) {  // (wave-uniform trip count: the shuffles below read every lane)
+            const int j = j0 + lane;
+            int w = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const int probe = __shfl(incl, w + step - 1);  // words 0 .. w + step - 1 hold <= j corners in all?
+                if (probe <= j) w += step;
+            }
+            w = min(w, 63);
+            const int before = __shfl(incl - cnt, w);
+            const uint32_t mlo = (uint32_t)__shfl((int)(uint32_t)m, w), mhi = (uint32_t)__shfl((int)(uint32_t)(m >> 32), w);
+            // ... and is that word's (j - before)-th set bit, found by halving
+            int k = j - before, pos = 0;
+            uint32_t part = mlo;
+            {
+                const int c = __popc(mlo);
+                if (k >= c) {
+                    k -= c;
+                    pos = 32;
+                    part = mhi;
+                }
+            }
+#pragma unroll
+            for (int width = 16; width >= 1; width >>= 1) {
+                const uint32_t lowmask = (1u << width) - 1u;
+                const int c = __popc(part & lowmask);
+                if (k >= c) {
+                    k -= c;
+                    pos += width;
+                    part >>= width;
+                }
+                part &= lowmask;
+            }
+            const int x = 64 * (w0 + w) + pos, idx = base + j;
+            if (j < total && idx < a.cand_cap) {
                 uint32_t r0, r1, r2;  // scores x - 1 .. x + 2 of the three rows (a corner lies >= 3 pixels inside the layer)
                 __builtin_memcpy(&r0, srow + x - 1 - L.w, 4);
                 __builtin_memcpy(&r1, srow + x - 1, 4);
@@ -498,8 +584,8 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
                 const int s = (int)((r1 >> 8) & 0xff);
                 int hi = 0, eq = 0;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int v0 = (int)((r0 >> (8 * k)) & 0xff), v2 = (int)((r2 >> (8 * k)) & 0xff);
+                for (int q = 0; q < 3; ++q) {
+                    const int v0 = (int)((r0 >> (8 * q)) & 0xff), v2 = (int)((r2 >> (8 * q)) & 0xff);
                     hi |= (v0 > s) | (v2 > s);
                     eq |= (v0 == s) | (v2 == s);
                 }
@@ -510,36 +596,30 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
                 a.cand_xy[cbase + idx] = (uint32_t)x | ((uint32_t)y << 16);
                 a.cand_flag[cbase + idx] = flag;
                 a.cand_emit[cbase + idx] = 0;
+                a.cand_spec[cbase + idx] = flag == kDetTie ? kWasTie : 0;
                 a.cand_asked[cbase + idx] = 0ull;
-                if (flag == kDetTie) {
-                    a.status[plane + (int64_t)y * L.w + x] = kStPending;
-                    const int k = atomicAdd(&a.tie_count[(int64_t)p * kDetMaxLayers + layer], 1);
-                    a.tie_list[cbase + tie_base + k] = idx;
-                }
+                if (flag == kDetTie) a.status[plane + (int64_t)y * L.w + x] = kStPending;
             }
-            ++idx;
         }
+        base += total;
     }
 }
 
 // ------------------------------------------------------------------ refinement (thread per maximum)
-// BriskLayer::getAgastScore(int, int, 1) (brisk.cpp:1685-1694) on the dense map.  MARK: record that the reference
-// would have asked for (and therefore cached) this cell -- only cells of the layer ABOVE the walker matter later.
-template <bool MARK>
-__device__ __forceinline__ int score_at(const PairView &v, int layer, int x, int y)
-{
-    const DetLayer &L = v.g->L[layer];
-    const bool in = x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3;
-    const int64_t o = L.off + (in ? (int64_t)y * L.w + x : 0);  // unconditional load: independent loads overlap
-    const int s = v.score[o];
-    return in ? s : 0;
-}
-
-// The part of a neighbouring layer's score map one refinement walk can reach -- at most 5 x 5 cells from the corner
-// ((int)x_1 - 1, (int)y_1 - 1) of getScoreMaxAbove/Below's sampling square, patch and tie rings included -- fetched with six
-// independent 8-byte loads into the thread's own 48 bytes of LDS.  The walk itself is a chain of data-dependent early
-// exits: on global memory every step would pay a full memory latency.
-constexpr int kWinSide = 6, kWinRow = 8, kWinBytes = 48, kWinStride = 108;  // two windows (above, below) of 6 rows of 8 bytes per thread; 27 dwords apart: neighbouring threads hit different banks
+// BriskLayer::getAgastScore(int, int, 1) (brisk.cpp:1685-1694) -- the corner score of an arbitrary cell, bisected from 1 --
+// is computed here where the reference computes it: for the cells a refinement walk can ask for.  A walk reads at most
+// 5 x 5 cells of a neighbouring layer, from the corner ((int)x_1 - 1, (int)y_1 - 1) of getScoreMaxAbove/Below's sampling
+// square (patch and tie rings included), and its own 3 x 3 patch.  det_window_kernel scores those cells -- a thread per
+// (walker, window), the 11 x 11 image bytes behind a window held in registers -- into a 128-byte record per walker;
+// det_walk_kernel copies the record's windows into the thread's LDS and walks on them (the walk itself is a chain of
+// data-dependent early exits: cell by cell on global memory it would pay a latency per step).
+constexpr int kWinSide = 6, kWinRow = 8, kWinBytes = 48;   // a window in LDS: 6 rows of 8 bytes (5 x 5 cells are filled; a walk that asks for more is reported)
+constexpr int kWinCells = 5;
+constexpr int kPatchRows = kWinCells + 6;                   // image rows oy - 3 .. oy + 7, 16 bytes from column ox - 3
+constexpr int kWinStride = 2 * kWinBytes + 4;               // 100 bytes = 25 dwords per thread: odd, neighbouring threads on different banks
+// a walker's record: the 5 x 5 cells of the window above (5 rows of 8 bytes), of the window below, the own 3 x 3 patch
+// (first index x) and, on layer 0, the nine 5/8 scores of the guessed layer below
+constexpr int kRecBytes = 128, kRecAbove = 0, kRecBelow = 40, kRecOwn = 80, kRec58 = 96;
 struct Window {
     uint8_t *cells;
     int ox, oy, layer;
@@ -547,84 +627,66 @@ struct Window {
     bool escaped;              // the walk left the window (cannot happen by construction; reported if it does)
 };
 
-struct WindowRows {
-    unsigned long long r[kWinSide];
+// kPatchRows image rows of 16 bytes from (x0, y0) of a layer, in registers: byte c of row r = image (x0 + c, y0 + r).
+// Addresses are clamped into the layer: what a clamp brings in stands for positions outside the image, which no
+// in-region cell's ring touches (a start clamped at the left border is shifted back into place).
+struct Patch {
+    uint32_t w[kPatchRows][4];
 };
-__device__ __forceinline__ WindowRows window_fetch(const PairView &v, const Window &w)
+__device__ __forceinline__ Patch patch_fetch(const uint8_t *img, const DetLayer &L, int x0, int y0)
 {
-    const DetLayer &L = v.g->L[w.layer];
-    // which of the six columns lie inside the scored region (3-pixel border): a byte mask over one 8-byte row
-    unsigned long long colmask = 0;
+    Patch q;
+    const int xs = min(max(x0, 0), max(L.w - 1, 0));
+    const int shift = xs - x0;  // 0 but for windows at the left border (1..3 there)
 #pragma unroll
-    for (int k = 0; k < kWinSide; ++k) {
-        const int x = w.ox + k;
-        if (x >= 3 && x < L.w - 3) colmask |= 0xffull << (8 * k);
+    for (int r = 0; r < kPatchRows; ++r) {  // unaligned 16-byte loads, all in flight together; the layer planes are padded by 64 bytes
+        const int yc = min(max(y0 + r, 0), max(L.h - 1, 0));
+        uint4 v;
+        __builtin_memcpy(&v, img + L.off + (int64_t)yc * L.w + xs, 16);
+        q.w[r][0] = v.x;
+        q.w[r][1] = v.y;
+        q.w[r][2] = v.z;
+        q.w[r][3] = v.w;
     }
-    const int oxc = min(max(w.ox, 0), max(L.w - 1, 0));  // ox >= 0 by construction; the clamp only keeps the address sane
-    if (oxc != w.ox) colmask = 0;
-    WindowRows rows;
+    if (shift > 0) {
+        const int sh = 8 * min(shift, 3);
 #pragma unroll
-    for (int r = 0; r < kWinSide; ++r) {  // one unaligned 8-byte load per row, all six in flight together; the plane is
-        const int y = w.oy + r;           // padded, so the two bytes past the window never leave the allocation
-        const int yc = min(max(y, 0), max(L.h - 1, 0));
-        unsigned long long q;
-        __builtin_memcpy(&q, v.score + L.off + (int64_t)yc * L.w + oxc, 8);
-        rows.r[r] = (y >= 3 && y < L.h - 3) ? (q & colmask) : 0ull;
+        for (int r = 0; r < kPatchRows; ++r) {
+            q.w[r][3] = (q.w[r][3] << sh) | (q.w[r][2] >> (32 - sh));
+            q.w[r][2] = (q.w[r][2] << sh) | (q.w[r][1] >> (32 - sh));
+            q.w[r][1] = (q.w[r][1] << sh) | (q.w[r][0] >> (32 - sh));
+            q.w[r][0] = q.w[r][0] << sh;
+        }
     }
-    return rows;
+    return q;
 }
-__device__ __forceinline__ void window_store(const Window &w, const WindowRows &rows)
+__device__ __forceinline__ int patch_byte(const Patch &q, int r, int c) { return (int)((q.w[r][c >> 2] >> (8 * (c & 3))) & 0xff); }
+
+// the OAST 9/16 score of the image byte at patch position (r, c) -- r, c compile-time constants after unrolling
+__device__ __forceinline__ int patch_ring_score(const Patch &q, int r, int c)
 {
+    constexpr int dx[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
+    constexpr int dy[16] = {0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1};  // OastDetector9_16::init_pattern (oast9_16.h:74-92)
+    int p[16];
 #pragma unroll
-    for (int r = 0; r < kWinSide; ++r) {
-        *reinterpret_cast<uint32_t *>(w.cells + r * kWinRow) = (uint32_t)rows.r[r];
-        *reinterpret_cast<uint32_t *>(w.cells + r * kWinRow + 4) = (uint32_t)(rows.r[r] >> 32);
-    }
+    for (int k = 0; k < 16; ++k) p[k] = patch_byte(q, r + dy[k], c + dx[k]);
+    const int ctr = patch_byte(q, r, c);
+    int arc_lo, arc_hi;
+    arc9_extremes(p, arc_lo, arc_hi);
+    return max(max(arc_lo - ctr, ctr - arc_hi) - 1, 0);
 }
 
-template <bool MARK>
-__device__ __forceinline__ int window_at(const PairView &v, Window &w, int x, int y)
+// AgastDetector5_8::cornerScore from b = 0 (agast5_8_nms.cc:42; brisk.cpp:1696-1703): 5 contiguous of the 8 neighbours of
+// the image byte at patch position (r, c), neighbours in init_pattern order (agast5_8.h:66-76).  For a candidate, which
+// lies at least 3 pixels inside the layer, none of the nine positions asked for touches the 2-pixel border where
+// BriskLayer::getAgastScore_5_8 returns 0.
+__device__ __forceinline__ int patch_score_5_8(const Patch &q, int r, int c)
 {
-    const int ix = x - w.ox, iy = y - w.oy;
-    if ((unsigned)ix >= (unsigned)kWinSide || (unsigned)iy >= (unsigned)kWinSide) {
-        w.escaped = true;
-        return score_at<false>(v, w.layer, x, y);
-    }
-    if (MARK) {
-        const DetLayer &L = v.g->L[w.layer];
-        if (x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3) w.asked |= 1ull << (iy * kWinSide + ix);
-    }
-    return w.cells[iy * kWinRow + ix];
-}
-
-// The cells a walk asked for in the layer above become "cached" there -- once the walker is known to be a maximum.
-__device__ __forceinline__ void apply_asked(const PairView &v, int layer_above, int ox, int oy, unsigned long long asked)
-{
-    const DetLayer &L = v.g->L[layer_above];
-    while (asked) {
-        const int k = __ffsll((long long)asked) - 1;
-        asked &= asked - 1;
-        v.touch[L.off + (int64_t)(oy + k / kWinSide) * L.w + ox + k % kWinSide] = 1;
-    }
-}
-
-// AgastDetector5_8::cornerScore from b = 0 (agast5_8_nms.cc:42; brisk.cpp:1696-1703): 5 contiguous of the 8 neighbours,
-// on a 5x5 image block held in registers (rows py-2 .. py+2, bytes = columns px-2 ..): the score at (px + ax, py + ay),
-// neighbours in init_pattern order (agast5_8.h:66-76).  For a candidate, which lies at least 3 pixels inside the layer,
-// none of the nine positions asked for touches the 2-pixel border where BriskLayer::getAgastScore_5_8 returns 0.
-__device__ __forceinline__ int score_5_8_block(const unsigned long long (&im)[5], int ax, int ay)
-{
-    auto at = [&](int dx, int dy) { return (int)((im[ay + dy + 2] >> (8 * (ax + dx + 2))) & 0xff); };
-    const int c = at(0, 0);
+    constexpr int dx[8] = {-1, -1, 0, 1, 1, 1, 0, -1}, dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+    const int v = patch_byte(q, r, c);
     int d[8];
-    d[0] = at(-1, 0) - c;
-    d[1] = at(-1, -1) - c;
-    d[2] = at(0, -1) - c;
-    d[3] = at(1, -1) - c;
-    d[4] = at(1, 0) - c;
-    d[5] = at(1, 1) - c;
-    d[6] = at(0, 1) - c;
-    d[7] = at(-1, 1) - c;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d[k] = patch_byte(q, r + dy[k], c + dx[k]) - v;
     int vb = -256, vd = -256;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -638,6 +700,47 @@ __device__ __forceinline__ int score_5_8_block(const unsigned long long (&im)[5]
         vd = max(vd, -mx);
     }
     return max(max(vb, vd) - 1, 0);
+}
+
+template <bool MARK>
+__device__ __forceinline__ int window_at(const PairView &v, Window &w, int x, int y)
+{
+    const int ix = x - w.ox, iy = y - w.oy;
+    if ((unsigned)ix >= (unsigned)kWinCells || (unsigned)iy >= (unsigned)kWinCells) {
+        w.escaped = true;
+        return 0;
+    }
+    if (MARK) {
+        const DetLayer &L = v.g->L[w.layer];
+        if (x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3) w.asked |= 1ull << (iy * kWinSide + ix);
+    }
+    return w.cells[iy * kWinRow + ix];
+}
+
+// The cells a walk asked for in the layer above: their true scores go into that layer's score plane right away (a
+// cell's score is what it is, whoever computes it and whenever; nobody reads a cell below the threshold unless a touch or
+// status byte says the reference would have cached it) ...
+__device__ __forceinline__ void publish_scores(const PairView &v, const Window &w)
+{
+    const DetLayer &L = v.g->L[w.layer];
+    unsigned long long asked = w.asked;
+    while (asked) {
+        const int k = __ffsll((long long)asked) - 1;
+        asked &= asked - 1;
+        const int iy = k / kWinSide, ix = k % kWinSide;
+        v.score_rw[L.off + (int64_t)(w.oy + iy) * L.w + w.ox + ix] = w.cells[iy * kWinRow + ix];
+    }
+}
+
+// ... and they become "cached" there -- touch -- once the walker is known to be a maximum.
+__device__ __forceinline__ void apply_asked(const PairView &v, int layer_above, int ox, int oy, unsigned long long asked)
+{
+    const DetLayer &L = v.g->L[layer_above];
+    while (asked) {
+        const int k = __ffsll((long long)asked) - 1;
+        asked &= asked - 1;
+        v.touch[L.off + (int64_t)(oy + k / kWinSide) * L.w + ox + k % kWinSide] = 1;
+    }
 }
 
 // BriskScaleSpace::subpixel2D (brisk.cpp:1535-1644); s = s_0_0, s_0_1, s_0_2, s_1_0, ... (first index x)
@@ -995,10 +1098,13 @@ struct Refined {
 
 // What getKeypoints does with one 2-D maximum (brisk.cpp:609-702), refine3D included (:937-1103).
 template <class FP>
-__device__ __forceinline__ Refined refine_maximum(const PairView &v, uint8_t *lds_cells, int layer, int px, int py, int threshold)
+__device__ __forceinline__ Refined refine_maximum(const PairView &v, uint8_t *lds_cells, const int (&own_patch)[9], const int (&s58)[9], int layer, int px, int py,
+                                                  int threshold)
 {
     // One walk above, one below, one own patch -- in the reference's order (above, below, patch), each at a single
-    // call site so that everything inlines and no argument goes through the stack.
+    // call site so that everything inlines and no argument goes through the stack.  The windows' cells (lds_cells), the
+    // own patch (first index x: getAgastScore(int, int, 1) on the own layer, :1685-1694) and the 5/8 scores come from the
+    // walker's record (det_window_kernel).
     const float basicSize = 12.0f;
     const FP fp{};
     const DetGeom &g = *v.g;
@@ -1011,34 +1117,12 @@ __device__ __forceinline__ Refined refine_maximum(const PairView &v, uint8_t *ld
     out.ox = out.oy = 0;
     out.escaped = false;
     const bool single = g.n_layers == 1, last = layer == g.n_layers - 1, octave = (layer & 1) == 0;
-    // Everything the refinement reads, requested at once (the walks are chains of data-dependent early exits: fetched
-    // step by step, each would pay a memory latency): the windows of the two neighbouring layers, the candidate's own
-    // 3x3 patch -- its centre is the candidate's score -- and, on layer 0, the 5x5 image block behind the 5/8 scores.
-    // A candidate lies at least 3 pixels inside its layer, so these row segments start inside it (the bytes that run
-    // past a row's end stay inside the padded plane and are not used).
     Window wa, wb;
     wa.cells = lds_cells;
     wb.cells = lds_cells + kWinBytes;
-    WindowRows ra, rb;
-    if (!last) {
-        window_place<true>(wa, layer, px, py);
-        ra = window_fetch(v, wa);
-    }
-    if (layer > 0) {
-        window_place<false>(wb, layer, px, py);
-        rb = window_fetch(v, wb);
-    }
-    unsigned long long own[3], im[5];
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) own[dy + 1] = load8(v.score + L.off + (int64_t)(py + dy) * L.w + px - 1);
-    const bool guess_below = layer == 0 && !single;
-    if (guess_below) {
-#pragma unroll
-        for (int dy = -2; dy <= 2; ++dy) im[dy + 2] = load8(v.img + L.off + (int64_t)(py + dy) * L.w + px - 2);
-    }
-    if (!last) window_store(wa, ra);
-    if (layer > 0) window_store(wb, rb);
-    const int center = (int)((own[1] >> 8) & 0xff);
+    if (!last) window_place<true>(wa, layer, px, py);
+    if (layer > 0) window_place<false>(wb, layer, px, py);
+    const int center = own_patch[4];
     bool ismax = true;
     float max_above = 0.f, max_below = 0.f;
     float delta_x_above = 0.f, delta_y_above = 0.f, delta_x_below = 0.f, delta_y_below = 0.f, delta_x_layer, delta_y_layer;
@@ -1048,6 +1132,7 @@ __device__ __forceinline__ Refined refine_maximum(const PairView &v, uint8_t *ld
         out.ox = wa.ox;
         out.oy = wa.oy;
         out.escaped = wa.escaped;
+        publish_scores(v, wa);
         if (!ismax) return out;
     }
     if (layer > 0) {  // getScoreMaxBelow: the last layer (:651-657), octaves above 0 (:991-996), intra layers (:1049-1053)
@@ -1055,21 +1140,20 @@ __device__ __forceinline__ Refined refine_maximum(const PairView &v, uint8_t *ld
         out.escaped |= wb.escaped;
         if (!ismax) return out;
     } else if (!single) {  // layer 0: guess the missing layer below with the 5/8 mask (:959-989)
-        int s[9];
         int mb = 0;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            s[k] = score_5_8_block(im, k / 3 - 1, k % 3 - 1);
-            mb = max(mb, s[k]);
-        }
-        (void)subpixel2d(fp, s, delta_x_below, delta_y_below);
+        for (int k = 0; k < 9; ++k) mb = max(mb, s58[k]);
+        (void)subpixel2d(fp, s58, delta_x_below, delta_y_below);
         max_below = (float)mb;
     }
-    int own_patch[9];  // s_0_0, s_0_1, s_0_2, s_1_0, ... (first index x): getAgastScore(int, int, 1) on the own layer (:1685-1694)
-#pragma unroll
-    for (int k = 0; k < 9; ++k) own_patch[k] = (int)((own[k % 3] >> (8 * (k / 3))) & 0xff);
     const float max_layer = subpixel2d(fp, own_patch, delta_x_layer, delta_y_layer);
     out.reached = true;
+    // the own 3 x 3 patch is in the reference's cache from here on (status says so once the candidate is a maximum): its scores
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int x = px + k / 3 - 1, y = py + k % 3 - 1;
+        if (x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3) v.score_rw[L.off + (int64_t)y * L.w + x] = (uint8_t)own_patch[k];
+    }
     if (single) {  // :609-638
         out.emit = true;
         out.r = DetResult{(float)fp.add((float)px, delta_x_layer), (float)fp.add((float)py, delta_y_layer), basicSize, max_layer};
@@ -1116,31 +1200,23 @@ __device__ __forceinline__ Refined refine_maximum(const PairView &v, uint8_t *ld
     return out;
 }
 
-__device__ __forceinline__ int layer_of(const int32_t *layer_start, int n_layers, int i)
-{
-    int l = 0;
-    while (l + 1 < n_layers && i >= layer_start[l + 1]) ++l;
-    return l;
-}
 
-// cand_emit bits
-constexpr uint8_t kEmit = 1, kReached = 2;
-
-// Refinement of candidate i.  It reads nothing but the dense score maps, so it does not depend on whether the
-// candidate's tie (if it has one) is already decided: SPECULATIVE runs it ahead of the decision and parks what the
-// decision will publish -- result, "reached its patch", and the cells it asked for in the layer above.
-template <bool SPECULATIVE, class FP>
-__device__ __forceinline__ void finish_candidate(const DetArgs &a, const PairView &v, uint8_t *lds_cells, int p, int i, int layer, int x, int y)
+// Refinement of candidate i.  It reads nothing but its record, so it does not depend on whether the candidate's tie (if it
+// has one) is already decided: SPECULATIVE runs it ahead of the decision and parks what the decision will publish --
+// result, "reached its patch", and the cells it asked for in the layer above.
+template <class FP>
+__device__ __forceinline__ void finish_candidate(const DetArgs &a, const PairView &v, uint8_t *lds_cells, const int (&own_patch)[9], const int (&s58)[9], int p,
+                                                 int i, int layer, int x, int y, bool SPECULATIVE)
 {
-    const Refined r = refine_maximum<FP>(v, lds_cells, layer, x, y, a.threshold);
+    const Refined r = refine_maximum<FP>(v, lds_cells, own_patch, s58, layer, x, y, a.threshold);
     const int64_t ci = (int64_t)p * a.cand_cap + i;
     a.cand_res[ci] = r.r;
     if (r.escaped) atomicOr(a.status_word, 16);
+    a.cand_asked[ci] = r.asked;  // (also what the clean-up behind the emission takes back from the touch map)
+    a.cand_win[ci] = (uint32_t)r.ox | (uint32_t)r.oy << 16;
     if (SPECULATIVE) {
         a.cand_emit[ci] = 0;
-        a.cand_spec[ci] = (uint8_t)((r.emit ? kEmit : 0) | (r.reached ? kReached : 0));
-        a.cand_asked[ci] = r.asked;
-        a.cand_win[ci] = (uint32_t)r.ox | (uint32_t)r.oy << 16;
+        a.cand_spec[ci] = (uint8_t)(kWasTie | (r.emit ? kEmit : 0) | (r.reached ? kReached : 0));
     } else {
         a.cand_emit[ci] = r.emit ? 1 : 0;
         const DetLayer &L = a.dg->L[layer];
@@ -1152,42 +1228,158 @@ __device__ __forceinline__ void finish_candidate(const DetArgs &a, const PairVie
 // maxima without ties: independent of everything else; ties: refined ahead of their decision
 constexpr int kRefineChunk = 512;  // candidates per workgroup
 
-template <bool X87>
-__global__ __launch_bounds__(kDetThreads) void det_refine_kernel(DetArgs a)
+// The cells behind the walks.  A workgroup takes a chunk of candidates, gathers its maxima and ties ("walkers": a quarter
+// or so of the candidates; the list goes to global memory for det_walk_kernel) and hands out (walker, window) items --
+// window 0: the 5 x 5 cells of the layer above, 1: of the layer below, 2: the own 3 x 3 patch and, on layer 0, the 5/8
+// scores that stand in for the layer below (:959-989).  A thread fetches the 11 x 11 image bytes behind its window into
+// registers (eleven 16-byte loads in flight together) and scores the cells from there: no LDS, few registers, many waves.
+__global__ __launch_bounds__(kDetThreads) void det_window_kernel(DetArgs a)
 {
-    __shared__ __attribute__((aligned(4))) uint8_t windows[kDetThreads * kWinStride];
-    __shared__ int todo[kRefineChunk], wave_cnt[4], n_todo;
+    __shared__ int todo[kRefineChunk], wave_cnt[8], n_todo, ls_s[kDetMaxLayers + 1];
     const int p = blockIdx.y, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
-    const int n = ls[a.dg->n_layers], c0 = blockIdx.x * kRefineChunk;
+    const int n_layers = a.dg->n_layers, n = ls[n_layers], c0 = blockIdx.x * kRefineChunk;
     if (c0 >= n) return;
-    // Only a quarter or so of the candidates are maxima or ties: the chunk's ones are gathered first (order does not
-    // matter here), so that the walks below run with full waves.
-    if (threadIdx.x == 0) n_todo = 0;
-    __syncthreads();
-    for (int i0 = c0; i0 < min(n, c0 + kRefineChunk); i0 += kDetThreads) {
-        const int i = i0 + threadIdx.x;
-        const bool take = i < n && a.cand_flag[(int64_t)p * a.cand_cap + i] != kDetNotMax;
-        const unsigned long long m = __ballot(take);
-        if (lane == 0) wave_cnt[wave] = __popcll(m);
+    if (threadIdx.x <= kDetMaxLayers) ls_s[threadIdx.x] = (int)threadIdx.x <= n_layers ? ls[threadIdx.x] : 0x7fffffff;
+    const int64_t cb = (int64_t)p * a.cand_cap;
+    {  // the chunk's walkers, in candidate order: both halves of the chunk in one go
+        static_assert(kRefineChunk == 2 * kDetThreads, "a thread takes two candidates of the chunk");
+        const int i_a = c0 + threadIdx.x, i_b = i_a + kDetThreads;
+        const bool take_a = i_a < n && a.cand_flag[cb + i_a] != kDetNotMax, take_b = i_b < n && a.cand_flag[cb + i_b] != kDetNotMax;
+        const unsigned long long m_a = __ballot(take_a), m_b = __ballot(take_b);
+        if (lane == 0) {
+            wave_cnt[wave] = __popcll(m_a);
+            wave_cnt[4 + wave] = __popcll(m_b);
+        }
         __syncthreads();
-        int before = n_todo;
-        for (int w = 0; w < wave; ++w) before += wave_cnt[w];
-        if (take) todo[before + __popcll(m & ((1ull << lane) - 1))] = i;
-        __syncthreads();
-        if (threadIdx.x == 0) n_todo += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        int before_a = 0, before_b = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        for (int w = 0; w < wave; ++w) {
+            before_a += wave_cnt[w];
+            before_b += wave_cnt[4 + w];
+        }
+        if (take_a) {
+            const int k = before_a + __popcll(m_a & ((1ull << lane) - 1));
+            todo[k] = i_a;
+            a.walk_list[cb + c0 + k] = i_a;
+        }
+        if (take_b) {
+            const int k = before_b + __popcll(m_b & ((1ull << lane) - 1));
+            todo[k] = i_b;
+            a.walk_list[cb + c0 + k] = i_b;
+        }
+        if (threadIdx.x == 0) n_todo = before_b + wave_cnt[4] + wave_cnt[5] + wave_cnt[6] + wave_cnt[7];
         __syncthreads();
     }
+    const int nt = n_todo;
+    if (threadIdx.x == 0) a.walk_count[(int64_t)p * a.walk_chunks + blockIdx.x] = nt;
     const PairView v = pair_view(a, p);
-    for (int k = threadIdx.x; k < n_todo; k += kDetThreads) {
+    const bool single = n_layers == 1;
+    for (int it = threadIdx.x; it < 3 * nt; it += kDetThreads) {
+        const int part = it / nt, k = it - part * nt;  // part-major: a wave's threads mostly share the window kind
         const int i = todo[k];
-        const int64_t ci = (int64_t)p * a.cand_cap + i;
-        const uint32_t xy = a.cand_xy[ci];
-        const int layer = layer_of(ls, a.dg->n_layers, i), x = (int)(xy & 0xffff), y = (int)(xy >> 16);
-        if (a.cand_flag[ci] == kDetMax)
-            finish_candidate<false, Fp<X87>>(a, v, windows + threadIdx.x * kWinStride, p, i, layer, x, y);
+        const uint32_t xy = a.cand_xy[cb + i];
+        int layer = 0;
+#pragma unroll
+        for (int l = 1; l < kDetMaxLayers; ++l) layer += i >= ls_s[l] ? 1 : 0;
+        const int px = (int)(xy & 0xffff), py = (int)(xy >> 16);
+        uint8_t *rec = a.cand_cells + (cb + c0 + k) * kRecBytes;
+        if (part == 2) {
+            // the candidate's own surroundings: 11 x 11 bytes centred on it (a candidate lies >= 3 pixels inside: px - 5 >= -2)
+            const DetLayer &L = v.g->L[layer];
+            const Patch q = patch_fetch(v.img, L, px - 5, py - 5);
+            uint32_t o[3] = {0, 0, 0}, f[3] = {0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const int dx = c / 3 - 1, dy = c % 3 - 1, x = px + dx, y = py + dy;
+                const int sc = (x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3) ? patch_ring_score(q, 5 + dy, 5 + dx) : 0;
+                o[c >> 2] |= (uint32_t)sc << (8 * (c & 3));
+            }
+            if (layer == 0 && !single) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) f[c >> 2] |= (uint32_t)patch_score_5_8(q, 5 + c % 3 - 1, 5 + c / 3 - 1) << (8 * (c & 3));
+            }
+            uint32_t *d = reinterpret_cast<uint32_t *>(rec + kRecOwn);
+            d[0] = o[0];
+            d[1] = o[1];
+            d[2] = o[2];
+            d[(kRec58 - kRecOwn) / 4] = f[0];
+            d[(kRec58 - kRecOwn) / 4 + 1] = f[1];
+            d[(kRec58 - kRecOwn) / 4 + 2] = f[2];
+            continue;
+        }
+        const bool above = part == 0;
+        if (above ? layer == n_layers - 1 : layer == 0) continue;  // no such layer (layer 0's guessed layer below: window 2)
+        Window w;
+        if (above)
+            window_place<true>(w, layer, px, py);
         else
-            finish_candidate<true, Fp<X87>>(a, v, windows + threadIdx.x * kWinStride, p, i, layer, x, y);
+            window_place<false>(w, layer, px, py);
+        const DetLayer &L = v.g->L[w.layer];
+        const Patch q = patch_fetch(v.img, L, w.ox - 3, w.oy - 3);
+        uint32_t *d = reinterpret_cast<uint32_t *>(rec + (above ? kRecAbove : kRecBelow));
+#pragma unroll
+        for (int iy = 0; iy < kWinCells; ++iy) {
+            const int y = w.oy + iy;
+            const bool row_in = y >= 3 && y < L.h - 3;
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int ix = 0; ix < kWinCells; ++ix) {
+                const int x = w.ox + ix;
+                const int sc = (row_in && x >= 3 && x < L.w - 3) ? patch_ring_score(q, iy + 3, ix + 3) : 0;
+                if (ix < 4)
+                    lo |= (uint32_t)sc << (8 * ix);
+                else
+                    hi = (uint32_t)sc;
+            }
+            d[2 * iy] = lo;
+            d[2 * iy + 1] = hi;
+        }
+    }
+}
+
+// The walks: a thread per walker of the chunk, its record's windows copied into its own LDS.
+template <bool X87>
+__global__ __launch_bounds__(kDetThreads) void det_walk_kernel(DetArgs a)
+{
+    __shared__ __attribute__((aligned(4))) uint8_t windows[kDetThreads * kWinStride];
+    __shared__ int ls_s[kDetMaxLayers + 1];
+    const int p = blockIdx.y, c0 = blockIdx.x * kRefineChunk;
+    const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
+    const int n_layers = a.dg->n_layers, n = ls[n_layers];
+    if (c0 >= n) return;
+    if (threadIdx.x <= kDetMaxLayers) ls_s[threadIdx.x] = (int)threadIdx.x <= n_layers ? ls[threadIdx.x] : 0x7fffffff;
+    __syncthreads();
+    const int nt = a.walk_count[(int64_t)p * a.walk_chunks + blockIdx.x];
+    const int64_t cb = (int64_t)p * a.cand_cap;
+    const PairView v = pair_view(a, p);
+    uint8_t *cells = windows + threadIdx.x * kWinStride;
+    for (int k = threadIdx.x; k < nt; k += kDetThreads) {
+        const int i = a.walk_list[cb + c0 + k];
+        const uint32_t xy = a.cand_xy[cb + i];
+        const uint8_t flag = a.cand_flag[cb + i];
+        const uint4 *rec = reinterpret_cast<const uint4 *>(a.cand_cells + (cb + c0 + k) * kRecBytes);
+        uint4 r[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) r[j] = rec[j];  // 112 of the record's 128 bytes: windows, own patch, 5/8 scores
+        int layer = 0;
+#pragma unroll
+        for (int l = 1; l < kDetMaxLayers; ++l) layer += i >= ls_s[l] ? 1 : 0;
+        // record rows of 8 bytes -> window rows of 8 bytes (rows 5 of the windows are never read: a walk that leaves the 5 x 5 cells is reported)
+        uint32_t *cw = reinterpret_cast<uint32_t *>(cells);
+        const uint32_t words[28] = {r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, r[1].z, r[1].w, r[2].x, r[2].y, r[2].z, r[2].w, r[3].x, r[3].y,
+                                    r[3].z, r[3].w, r[4].x, r[4].y, r[4].z, r[4].w, r[5].x, r[5].y, r[5].z, r[5].w, r[6].x, r[6].y, r[6].z, r[6].w};
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            cw[j] = words[j];                       // above: record bytes 0..39 -> window bytes 0..39
+            cw[kWinBytes / 4 + j] = words[10 + j];  // below: record bytes 40..79
+        }
+        int own_patch[9], s58[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            own_patch[c] = (int)((words[20 + (c >> 2)] >> (8 * (c & 3))) & 0xff);
+            s58[c] = (int)((words[24 + (c >> 2)] >> (8 * (c & 3))) & 0xff);
+        }
+        finish_candidate<Fp<X87>>(a, v, cells, own_patch, s58, p, i, layer, (int)(xy & 0xffff), (int)(xy >> 16), flag != kDetMax);
     }
 }
 
@@ -1302,27 +1494,73 @@ __device__ __forceinline__ void tie_apply(const DetArgs &a, const PairView &v, c
     }
 }
 
-// Ties of one layer, all pairs at once.  First sight: every tie looks at its neighbourhood once; the ones that are
-// ready -- the great majority -- decide and publish on the spot (a ready tie depends on no tie that is still pending,
-// so two of them never need each other's outcome, and a status byte changes once, from pending to final: whoever reads
-// the old value merely waits); the others go on the pair's waiting list.
-constexpr int kTieThreads = 512, kTieGroups = 8;
+// The ties of one layer: one workgroup per pair, one launch per layer (a layer reads what the maxima of the layer below
+// asked for in it).  (1) The layer's ties are picked out of its candidates into an LDS list.  (2) First sight: every tie
+// looks at its neighbourhood once; the ones that are ready -- the great majority -- decide and publish on the spot (a
+// ready tie depends on no tie that is still pending, so two of them never need each other's outcome, and a status byte
+// changes once, from pending to final: whoever reads the old value merely waits); the others go on the waiting list.
+// (3) Chains: what first sight left waiting are ties that depend on each other: a thread per link (or several), each
+// spinning until the links before it have published; the earliest pending tie of a layer is always ready, so the
+// spinning ends.  Everything the threads tell each other stays inside the workgroup -- one CU, one vector cache -- so
+// workgroup-scope ordering is all it takes, and all the waves involved are resident.
+constexpr int kTieThreads = 512;
 #ifdef MOFREAK_DEBUG_BOUNDS
-constexpr int kDetWaitCap = 8;  // the debug build overflows the list on every tie-heavy image: the scanning fallback gets tested
+constexpr int kTieListCap = 64, kDetWaitCap = 8;  // the debug build overflows both lists on every tie-heavy image: the scanning fallbacks get tested
 #else
-constexpr int kDetWaitCap = 4096;  // waiting ties per pair and layer the chain kernel takes from a list (more: it scans the layer)
+constexpr int kTieListCap = 6144, kDetWaitCap = 4096;  // ties / waiting ties per pair and layer held in LDS lists (more: the candidates are scanned instead)
 #endif
 
-__global__ __launch_bounds__(kTieThreads) void det_tie_first_kernel(DetArgs a, int layer, int32_t *waiting)
+__global__ __launch_bounds__(kTieThreads) void det_tie_kernel(DetArgs a, int layer)
 {
-    const int p = blockIdx.y;
+    __shared__ int tie_idx[kTieListCap], wait_idx[kDetWaitCap], n_ties_s, n_wait_s;
+    const int p = blockIdx.x, lane = threadIdx.x & 63;
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
     const int lo = ls[layer], hi = ls[layer + 1];
+    if (hi <= lo) return;
     const PairView v = pair_view(a, p);
     const int64_t cb = (int64_t)p * a.cand_cap;
     const DetLayer L = a.dg->L[layer];
-    int32_t *list = a.wait_list + (int64_t)p * kDetWaitCap;
-    for (int i = lo + blockIdx.x * kTieThreads + threadIdx.x; i < hi; i += gridDim.x * kTieThreads) {
+    if (threadIdx.x == 0) {
+        n_ties_s = 0;
+        n_wait_s = 0;
+    }
+    __syncthreads();
+    // (1) sixteen flag bytes per thread and load (one candidate in eight is a tie): the layer's flags in one or two round trips
+    for (int i0 = lo; i0 < hi; i0 += 16 * kTieThreads) {
+        const int i = i0 + 16 * (int)threadIdx.x;
+        uint4 f = make_uint4(0, 0, 0, 0);
+        if (i < hi) __builtin_memcpy(&f, a.cand_flag + cb + i, 16);  // (the flag array is padded: the last load may run past hi)
+        const uint32_t w[4] = {f.x, f.y, f.z, f.w};
+        uint32_t ties = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) ties |= (((w[k >> 2] >> (8 * (k & 3))) & 0xff) == kDetTie && i + k < hi) ? 1u << k : 0u;
+        const int cnt = __popc(ties);
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        const int total = __shfl(incl, 63);
+        if (total) {  // wave-uniform
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&n_ties_s, total);
+            int k = __builtin_amdgcn_readfirstlane(base) + incl - cnt;
+            while (ties) {
+                const int b = __ffs((int)ties) - 1;
+                ties &= ties - 1;
+                if (k < kTieListCap) tie_idx[k] = i + b;
+                ++k;
+            }
+        }
+    }
+    __syncthreads();
+    const int n_ties = n_ties_s;
+    const bool ties_listed = n_ties <= kTieListCap;
+    const int n_first = ties_listed ? n_ties : hi - lo;
+    // (2) first sight
+    for (int k = threadIdx.x; k < n_first; k += kTieThreads) {
+        const int i = ties_listed ? tie_idx[k] : lo + k;
         const TieCand c = tie_cand(a, cb + i);
         if (c.flag != kDetTie) continue;
         const int px = (int)(c.xy & 0xffff), py = (int)(c.xy >> 16);
@@ -1330,45 +1568,21 @@ __global__ __launch_bounds__(kTieThreads) void det_tie_first_kernel(DetArgs a, i
         if (step.ready)
             tie_apply(a, v, L, cb + i, c, layer, px, py, step.is_max);
         else {
-            const int k = atomicAdd(&waiting[p], 1);
-            if (k < kDetWaitCap) list[k] = i;
+            const int w = atomicAdd(&n_wait_s, 1);
+            if (w < kDetWaitCap) wait_idx[w] = i;
         }
     }
-}
-
-// What first sight left waiting: chains of ties that depend on each other.  One workgroup per pair, a thread per link
-// (or several), each spinning until the links before it have published; the earliest pending tie of a layer is
-// always ready, so the spinning ends.  Everything the threads tell each other stays inside the workgroup -- one CU,
-// one vector cache -- so workgroup-scope ordering is all it takes, and all the waves involved are resident.
-__global__ __launch_bounds__(kTieThreads) void det_tie_chain_kernel(DetArgs a, int layer, const int32_t *waiting)
-{
-    const int p = blockIdx.x;
-    const int n_wait = waiting[p];
+    __syncthreads();
+    // (3) chains
+    const int n_wait = n_wait_s;
     if (n_wait == 0) return;
-    const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
-    const int lo = ls[layer], hi = ls[layer + 1];
-    const PairView v = pair_view(a, p);
-    const int64_t cb = (int64_t)p * a.cand_cap;
-    const DetLayer L = a.dg->L[layer];
-    const int32_t *list = a.wait_list + (int64_t)p * kDetWaitCap;
     const bool listed = n_wait <= kDetWaitCap;  // list overflow: every candidate of the layer
     const int n_items = listed ? n_wait : hi - lo;
-    // a thread's first two ties stay in registers between passes (there are rarely more than a few hundred per pair and
+    // a thread's first tie stays in registers between passes (there are rarely more than a few hundred per pair and
     // layer): a pass is then one round of neighbourhood loads, not list entry -> record -> neighbourhood
-    constexpr int kOwn = 2;
-    TieCand own[kOwn];
-    int own_i[kOwn];
-    bool own_waits[kOwn];
-#pragma unroll
-    for (int j = 0; j < kOwn; ++j) {
-        const int k = threadIdx.x + j * kTieThreads;
-        own_i[j] = k < n_items ? (listed ? list[k] : lo + k) : lo;
-    }
-#pragma unroll
-    for (int j = 0; j < kOwn; ++j) {
-        own[j] = tie_cand(a, cb + own_i[j]);
-        own_waits[j] = (int)threadIdx.x + j * kTieThreads < n_items && own[j].flag == kDetTie;
-    }
+    const int own_i = (int)threadIdx.x < n_items ? (listed ? wait_idx[threadIdx.x] : lo + (int)threadIdx.x) : lo;
+    const TieCand own = tie_cand(a, cb + own_i);
+    bool own_waits = (int)threadIdx.x < n_items && own.flag == kDetTie;
     // The earliest pending tie of a layer is always ready, so a pass decides at least one tie and n_items + 1 passes
     // are enough for the longest possible chain.  Should that invariant ever break (a status byte left pending by a
     // candidate nobody lists), the thread gives up and says so (status bit 32 -> MOFREAK_ERR_HIP) instead of hanging
@@ -1376,20 +1590,18 @@ __global__ __launch_bounds__(kTieThreads) void det_tie_chain_kernel(DetArgs a, i
     for (int pass = 0;; ++pass) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // the pass reads what has been published by now
         bool waits = false;
-#pragma unroll
-        for (int j = 0; j < kOwn; ++j) {
-            if (!own_waits[j]) continue;
-            const int px = (int)(own[j].xy & 0xffff), py = (int)(own[j].xy >> 16);
+        if (own_waits) {
+            const int px = (int)(own.xy & 0xffff), py = (int)(own.xy >> 16);
             const TieStep step = tie_step(v, L, a.safe_threshold, px, py);
             if (step.ready) {
-                tie_apply(a, v, L, cb + own_i[j], own[j], layer, px, py, step.is_max);
-                own_waits[j] = false;
+                tie_apply(a, v, L, cb + own_i, own, layer, px, py, step.is_max);
+                own_waits = false;
             } else {
                 waits = true;
             }
         }
-        for (int k = threadIdx.x + kOwn * kTieThreads; k < n_items; k += kTieThreads) {
-            const int i = listed ? list[k] : lo + k;
+        for (int k = threadIdx.x + kTieThreads; k < n_items; k += kTieThreads) {
+            const int i = listed ? wait_idx[k] : lo + k;
             const TieCand c = tie_cand(a, cb + i);
             if (c.flag != kDetTie) continue;  // written by this thread only
             const int px = (int)(c.xy & 0xffff), py = (int)(c.xy >> 16);
@@ -1467,11 +1679,19 @@ __global__ __launch_bounds__(kDetThreads) void det_emit_scan_kernel(DetArgs a, i
 
 __global__ __launch_bounds__(kDetThreads) void det_emit_scatter_kernel(DetArgs a)
 {
-    __shared__ int wave_cnt[4], chunk_base;
+    __shared__ int wave_cnt[4], chunk_base, ls_s[kDetMaxLayers + 1], w_s[kDetMaxLayers];
+    __shared__ long long off_s[kDetMaxLayers];
     const int p = blockIdx.y, c = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
-    const int n = ls[a.dg->n_layers];
+    const int n_layers = a.dg->n_layers, n = ls[n_layers];
     if (c * kEmitChunk >= n) return;
+    if (wave == 1 && lane <= kDetMaxLayers) {  // the pair's layer boundaries and the layers' geometry: one round trip for everybody
+        ls_s[lane] = lane <= n_layers ? ls[lane] : 0x7fffffff;
+        if (lane < kDetMaxLayers) {
+            w_s[lane] = a.dg->L[lane].w;
+            off_s[lane] = a.dg->L[lane].off;
+        }
+    }
     if (wave == 0) {  // emitted candidates in the chunks before this one
         int before = 0;
         for (int k = lane; k < c; k += 64) before += a.emit_chunks[(int64_t)p * a.emit_chunk_cap + k];
@@ -1480,10 +1700,36 @@ __global__ __launch_bounds__(kDetThreads) void det_emit_scatter_kernel(DetArgs a
     }
     __syncthreads();
     long long run = a.emit_offsets[p] + chunk_base;
+    const int64_t plane = (int64_t)p * a.dg->plane_bytes;
     for (int i0 = c * kEmitChunk; i0 < min(n, (c + 1) * kEmitChunk); i0 += kDetThreads) {
         const int i = i0 + threadIdx.x;
         const int64_t ci = (int64_t)p * a.cand_cap + i;
         const bool e = i < n && a.cand_emit[ci];
+        if (i < n) {
+            // Everything that read the two bookkeeping maps of the tie logic is done: take back what this candidate put
+            // there -- its status byte and the touch bytes of the cells it asked for in the layer above -- so that both
+            // maps are all zero again when the next call starts (nobody clears them wholesale).
+            const uint8_t fl = a.cand_flag[ci], sp = a.cand_spec[ci];
+            if (fl == kDetMax || (sp & kWasTie)) {  // maxima and ties own a status byte; only maxima have touched cells of the layer above
+                const uint32_t xy = a.cand_xy[ci];
+                const unsigned long long asked = fl == kDetMax ? a.cand_asked[ci] : 0ull;
+                const uint32_t win = a.cand_win[ci];  // (meaningful only with asked != 0)
+                int layer = 0;
+#pragma unroll
+                for (int l = 1; l < kDetMaxLayers; ++l) layer += i >= ls_s[l] ? 1 : 0;
+                a.status[plane + off_s[layer] + (int64_t)(xy >> 16) * w_s[layer] + (xy & 0xffff)] = kStNone;
+                if (asked) {
+                    // whole window rows at a time (eight bytes: two more than the window is wide -- every byte of the map
+                    // ends up zero anyway, the planes are padded, and nobody reads the map any more in this call)
+                    uint8_t *ub = a.touch + plane + off_s[layer + 1] + (int64_t)(win >> 16) * w_s[layer + 1] + (win & 0xffff);
+                    const int uw = w_s[layer + 1];
+                    const unsigned long long zero = 0ull;
+#pragma unroll
+                    for (int iy = 0; iy < kWinCells; ++iy)
+                        if ((asked >> (iy * kWinSide)) & 0x3f) __builtin_memcpy(ub + iy * uw, &zero, 8);
+                }
+            }
+        }
         const unsigned long long m = __ballot(e);
         if (lane == 0) wave_cnt[wave] = __popcll(m);
         __syncthreads();
@@ -1498,7 +1744,12 @@ __global__ __launch_bounds__(kDetThreads) void det_emit_scatter_kernel(DetArgs a
                 const DetResult r = a.cand_res[ci];
                 a.out_kps[o] = mofreak_keypoint{r.x, r.y, r.size};
                 if (a.out_response) a.out_response[o] = r.response;
-                if (a.out_layer) a.out_layer[o] = layer_of(ls, a.dg->n_layers, i);
+                if (a.out_layer) {
+                    int layer = 0;
+#pragma unroll
+                    for (int l = 1; l < kDetMaxLayers; ++l) layer += i >= ls_s[l] ? 1 : 0;
+                    a.out_layer[o] = layer;
+                }
             }
         }
         run += all;
@@ -1533,8 +1784,16 @@ int launch_det_scores(const DetArgs &a, void *stream)
     for (int l = 0; l < a.g.n_layers; ++l) {
         const dim3 grid((a.g.L[l].w + kScoreTileW - 1) / kScoreTileW, (a.g.L[l].h + kScoreTileH - 1) / kScoreTileH, a.n_pairs);
         if (grid.x == 0 || grid.y == 0) continue;
-        hipLaunchKernelGGL(det_score_kernel, grid, dim3(kDetThreads), 0, s, a, l);
+        hipLaunchKernelGGL(det_dense_score_kernel, grid, dim3(kDetThreads), 0, s, a, l);
     }
+    return (int)hipGetLastError();
+}
+
+int launch_det_corners(const DetArgs &a, void *stream)
+{
+    const int tiles = a.g.tile_start[a.g.n_layers];  // every layer's tiles in one launch
+    if (tiles > 0 && a.n_pairs > 0)
+        hipLaunchKernelGGL(det_corner_kernel, dim3(tiles, a.n_pairs), dim3(kDetThreads), 0, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 
@@ -1543,16 +1802,14 @@ int launch_det_keypoints(const DetArgs &a, int64_t *running, void *stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(det_scan_kernel, dim3(a.n_pairs), dim3(kDetThreads), 0, s, a);
     hipLaunchKernelGGL(det_candidates_kernel, dim3((a.g.total_rows + 3) / 4, a.n_pairs), dim3(kDetThreads), 0, s, a);
+    const dim3 rgrid((a.cand_cap + kRefineChunk - 1) / kRefineChunk, a.n_pairs);
+    hipLaunchKernelGGL(det_window_kernel, rgrid, dim3(kDetThreads), 0, s, a);
     if (a.fp_x87)
-        hipLaunchKernelGGL(det_refine_kernel<true>, dim3((a.cand_cap + kRefineChunk - 1) / kRefineChunk, a.n_pairs), dim3(kDetThreads), 0, s, a);
+        hipLaunchKernelGGL(det_walk_kernel<true>, rgrid, dim3(kDetThreads), 0, s, a);
     else
-        hipLaunchKernelGGL(det_refine_kernel<false>, dim3((a.cand_cap + kRefineChunk - 1) / kRefineChunk, a.n_pairs), dim3(kDetThreads), 0, s, a);
+        hipLaunchKernelGGL(det_walk_kernel<false>, rgrid, dim3(kDetThreads), 0, s, a);
     // ties: layer by layer (a layer's ties read what the maxima of the layer below asked for in it)
-    for (int l = 0; l < a.g.n_layers; ++l) {
-        int32_t *waiting = a.tie_waiting + (int64_t)l * a.n_pairs;
-        hipLaunchKernelGGL(det_tie_first_kernel, dim3(kTieGroups, a.n_pairs), dim3(kTieThreads), 0, s, a, l, waiting);
-        hipLaunchKernelGGL(det_tie_chain_kernel, dim3(a.n_pairs), dim3(kTieThreads), 0, s, a, l, waiting);
-    }
+    for (int l = 0; l < a.g.n_layers; ++l) hipLaunchKernelGGL(det_tie_kernel, dim3(a.n_pairs), dim3(kTieThreads), 0, s, a, l);
     const dim3 egrid((a.cand_cap + kEmitChunk - 1) / kEmitChunk, a.n_pairs);
     hipLaunchKernelGGL(det_emit_count_kernel, egrid, dim3(kDetThreads), 0, s, a);
     hipLaunchKernelGGL(det_emit_scan_kernel, dim3(1), dim3(kDetThreads), 0, s, a, running);

@@ -197,13 +197,13 @@ struct DetGeom {
     int32_t n_layers, total_rows;
     int64_t plane_bytes;  // one pair, all layers
     DetLayer L[kDetMaxLayers];
-    // the corner kernel's 64 x 32-pixel tiles: tiles per row of a layer, first tile of a layer in the pair's tile list
+    // the corner kernel's 64 x 64-pixel tiles: tiles per row of a layer, first tile of a layer in the pair's tile list
     // (tile_start[n_layers] = tiles per pair); the hit masks -- one 64-bit word per tile row and layer row: bit b of word
     // (y, tx) = pixel (64 tx + b, y) is a detected corner -- start at word mask_off[l] of the pair's mask_words words
     int32_t tiles_x[kDetMaxLayers], tile_start[kDetMaxLayers + 1];
     int64_t mask_off[kDetMaxLayers], mask_words;
 };
-constexpr int kDetTileW = 64, kDetTileH = 32;
+constexpr int kDetTileW = 64, kDetTileH = 64;
 // candidate flags
 enum : uint8_t { kDetNotMax = 0, kDetMax = 1, kDetTie = 2 };
 // status-map values (one byte per pixel, written only by the thread that owns that candidate)
@@ -232,15 +232,17 @@ struct DetArgs {
     uint8_t *cand_spec;                     // [n_pairs][cand_cap] ties: emit / reached bits of the refinement run ahead of the decision
     unsigned long long *cand_asked;         // [n_pairs][cand_cap] cells a walk asked for in the layer above (bit mask over a 6 x 6 window; 0: none)
     uint32_t *cand_win;                     // [n_pairs][cand_cap] that window's origin, x | y << 16
-    int32_t *tie_list;                      // [n_pairs][cand_cap]: the ties of layer l at [layer_start[l], layer_start[l] + tie_count[l]) in any order
-    int32_t *tie_count;                     // [n_pairs][kDetMaxLayers], zeroed per batch
+    // refinement: chunk c of 512 candidates has walk_count[c] walkers (maxima and ties); walker k of the chunk is candidate
+    // walk_list[512 c + k] and owns the 128-byte record cand_cells[512 c + k] (the cells its walks can read)
+    int32_t *walk_list;                     // [n_pairs][cand_cap]
+    int32_t *walk_count;                    // [n_pairs][walk_chunks]
+    int32_t walk_chunks;
+    uint8_t *cand_cells;                    // [n_pairs][cand_cap][128]
     DetResult *cand_res;                    // [n_pairs][cand_cap]
     int32_t *layer_start;                   // [n_pairs][kDetMaxLayers + 1]
     int32_t *emit_count;                    // [n_pairs]
     int32_t *emit_chunks;                   // [n_pairs][emit_chunk_cap]: emitted candidates per chunk of 1024
     int32_t emit_chunk_cap;
-    int32_t *wait_list;                     // [n_pairs][4096]: the ties of the current layer that were not ready at first sight
-    int32_t *tie_waiting;                   // [kDetMaxLayers][2][n_pairs], zeroed per batch: ties of a layer left waiting; workgroups that arrived
     int64_t *emit_offsets;                  // [n_pairs + 1], relative to out_base
     mofreak_keypoint *out_kps;              // whole-call outputs
     float *out_response;                    // optional

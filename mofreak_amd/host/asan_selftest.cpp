@@ -27,6 +27,7 @@ int launch_bow_normalize(const unsigned int *, int, float *, int32_t *, void *) 
 int launch_unpack_integral(const int32_t *, int, int, int, int, int32_t *, void *) { STUB; }
 int launch_det_pyramid(const DetArgs &, void *) { STUB; }
 int launch_det_scores(const DetArgs &, void *) { STUB; }
+int launch_det_corners(const DetArgs &, void *) { STUB; }
 int launch_det_keypoints(const DetArgs &, int64_t *, void *) { STUB; }
 }  // namespace mofreak
 

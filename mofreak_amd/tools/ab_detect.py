@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""A/B timing of detector builds (kernel experiments only; the figures that count are bench.py's, on the in-tree library).
+
+  ab_detect.py --build NAME [-DX ...]   compile mofreak_amd/_exp/libdet_NAME.so from the tree's sources with extra flags
+  ab_detect.py --ablate NAME            an ablation build from a patched COPY of detect_kernel.hip (ABLATIONS below); the
+                                        product source has no switch for this; results are wrong by construction, only the
+                                        time is of interest
+  ab_detect.py --run [PAIRS] LIB ...    on the GPU box: every library in a process of its own under
+                                        rocprofv3 --kernel-trace --stats (detector_probe.py PAIRS 6), one line per det_* kernel
+                                        (microseconds per call) and the probe's own line
+"""
+from __future__ import annotations
+
+import csv
+import glob
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+EXP = os.path.join(ROOT, "mofreak_amd", "_exp")
+
+
+def sub1(text, old, new):
+    assert text.count(old) == 1, old
+    return text.replace(old, new)
+
+
+ABLATIONS = {
+    # refinement: the cells of a window taken from the image byte under them instead of scored (17 extractions + 80 operations less per cell)
+    "noscore": lambda t: sub1(sub1(t, "? patch_ring_score(q, iy + 3, ix + 3) : 0;", "? patch_byte(q, iy + 3, ix + 3) : 0;"),
+                              "? patch_ring_score(q, 5 + dy, 5 + dx) : 0;", "? patch_byte(q, 5 + dy, 5 + dx) : 0;"),
+    # refinement: no image patch loads (registers filled from the coordinates)
+    "noload": lambda t: sub1(t, "__builtin_memcpy(&v, img + L.off + (int64_t)yc * L.w + xs, 16);", "v = make_uint4(xs, yc, r, 0);"),
+    # corner kernel: nobody survives the compass test (what is left: tile load, zero fill, write out)
+    "nopass": lambda t: sub1(t, "const bool pass = (nb >= 2 || nd >= 2) &&", "const bool pass = (nb >= 200 || nd >= 200) &&"),
+    # corner kernel: survivors are listed but not scored
+    "nophase2": lambda t: sub1(t, "for (int i = threadIdx.x; i < n; i += kDetThreads) {\n        const int e = list[i]", "for (int i = threadIdx.x; i < 0; i += kDetThreads) {\n        const int e = list[i]"),
+}
+
+
+def build(name, flags, patch=None):
+    sys.path.insert(0, ROOT)
+    from mofreak_amd import build as B
+    os.makedirs(EXP, exist_ok=True)
+    out = os.path.join(EXP, f"libdet_{name}.so")
+    srcs = [os.path.join(B.CSRC, s) for s in B.SOURCES]
+    if patch:
+        d = os.path.join(EXP, f"src_{name}")
+        os.makedirs(d, exist_ok=True)
+        i = [os.path.basename(s) for s in srcs].index("detect_kernel.hip")
+        with open(srcs[i]) as f:
+            text = patch(f.read())
+        srcs[i] = os.path.join(d, "detect_kernel.hip")
+        with open(srcs[i], "w") as f:
+            f.write(text)
+        flags = [*flags, "-I", B.CSRC]
+    subprocess.check_call([B.hipcc(), *B.FLAGS, *flags, "-o", out, *srcs])
+    print(out)
+
+
+def run(libs, pairs):
+    os.chdir(ROOT)
+    env0 = dict(os.environ, TMPDIR="/tmp")
+    for lib in libs:
+        name = os.path.basename(lib)
+        out = os.path.join(ROOT, "gpurun_out", "ab_detect", name)
+        subprocess.call(["rm", "-rf", out])
+        os.makedirs(out, exist_ok=True)
+        env = dict(env0, MOFREAK_HIP_LIBRARY=os.path.abspath(lib))
+        log = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "--", "python3",
+                              "mofreak_amd/tools/detector_probe.py", str(pairs), "6"], env=env, capture_output=True, text=True, timeout=300)
+        probe = [ln for ln in log.stdout.splitlines() if ln.startswith("pairs=")]
+        stats = glob.glob(os.path.join(out, "**", "*kernel_stats.csv"), recursive=True)
+        per = {}
+        if stats:
+            for r in csv.DictReader(open(stats[0])):
+                m = re.search(r"(det_\w+)", r["Name"])
+                if m:
+                    per[m.group(1)] = per.get(m.group(1), 0.0) + float(r["TotalDurationNs"]) / 7e3  # 1 warm-up + 6 calls; microseconds per call
+        total = sum(per.values())
+        print(f"{name}: {' '.join(probe) or log.stderr[-300:]}")
+        print("   " + "  ".join(f"{k[4:].replace('_kernel', '')} {v:.0f}" for k, v in sorted(per.items(), key=lambda kv: -kv[1])) + f"  | sum {total:.0f} us/call", flush=True)
+        subprocess.call(["rm", "-rf", out])
+
+
+if __name__ == "__main__":
+    a = sys.argv[1:]
+    if a[:1] == ["--build"]:
+        build(a[1], a[2:])
+    elif a[:1] == ["--ablate"]:
+        build(a[1], [], ABLATIONS[a[1]])
+    elif a[:1] == ["--run"]:
+        pairs = 32
+        if len(a) > 1 and a[1].isdigit():
+            pairs = int(a[1])
+            a = a[1:]
+        run(a[1:], pairs)
+    else:
+        raise SystemExit(__doc__)
