@@ -1654,6 +1654,13 @@ int det_geometry(const mofreak_ctx *ctx, int W, int H, int octaves, DetGeom &g)
     if (tiles >= ((int64_t)1 << 31)) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "frame too large for the detector's tile list");
     for (int i = g.n_layers; i <= kDetMaxLayers; ++i) g.tile_start[i] = (int32_t)tiles;
     g.mask_words = words;
+    int groups = 0;
+    for (int i = 0; i < g.n_layers; ++i) {
+        g.cand_rows_per_wave[i] = std::max(1, 64 / std::max(1, g.tiles_x[i]));
+        g.cand_group_start[i] = groups;
+        groups += (g.L[i].h + g.cand_rows_per_wave[i] - 1) / g.cand_rows_per_wave[i];
+    }
+    for (int i = g.n_layers; i <= kDetMaxLayers; ++i) g.cand_group_start[i] = groups;
     return MOFREAK_OK;
 }
 

@@ -222,6 +222,165 @@ __global__ __launch_bounds__(kDetThreads) void det_twothird_kernel(DetArgs a, in
     __builtin_memcpy(dst + 8, &hi16, 2);
 }
 
+// ---- the whole pyramid in one launch
+// A workgroup takes a band of 12 rows of the frame pair and produces that band of every layer: |cur - prev| (12 rows),
+// the 2/3 layer (8 rows), the halves (6, 4, 3, 2 rows).  Every resampler works inside a row (pairs / triples of rows), so
+// full-width bands need no halo and every column quirk of the SIMD loops stays where it is; the lower layers of a band
+// are read from LDS instead of from memory: the frames are read once and each layer is written once (8.1 MB per full-HD
+// pair instead of 13.9 MB and one launch instead of six).  Used when the width is a multiple of 16 and the band fits 64 KB
+// of LDS (frames up to 2800 pixels wide) and there are at most six layers; other shapes take the kernels above.
+constexpr int kPyrBand = 12, kPyrLayers = 6;
+struct PyrBand {
+    int rows[kPyrLayers], pitch[kPyrLayers], base[kPyrLayers];  // rows of a band, LDS row pitch and offset per layer
+    int bytes;
+};
+__host__ __device__ inline PyrBand pyr_band(const DetGeom &g)
+{
+    constexpr int r[kPyrLayers] = {12, 8, 6, 4, 3, 2};
+    PyrBand b;
+    int at = 0;
+    for (int l = 0; l < kPyrLayers; ++l) {
+        b.rows[l] = r[l];
+        b.pitch[l] = l < g.n_layers ? ((g.L[l].w + 15) & ~15) + 16 : 0;  // 16 bytes behind a row: block loads may run past its end
+        b.base[l] = at;
+        if (l + 2 < g.n_layers || (l == 0 && g.n_layers > 1)) at += r[l] * b.pitch[l];  // kept in LDS only if a later layer reads it
+    }
+    b.bytes = at;
+    return b;
+}
+
+// one block of the 2/3 resampler from two rows in LDS: 15 columns in, 10 bytes out (det_twothird_kernel's arithmetic)
+__device__ __forceinline__ void twothird_block(const uint8_t *outer, const uint8_t *mid, uint8_t *dst_lds, uint8_t *dst)
+{
+    unsigned long long o[2], m[2];
+    o[0] = load8(outer);
+    o[1] = load8(outer + 8);
+    m[0] = load8(mid);
+    m[1] = load8(mid + 8);
+    int v[15];  // _mm_avg_epu8(_mm_avg_epu8(outer, mid), outer) per column
+#pragma unroll
+    for (int x = 0; x < 15; ++x) {
+        const int ov = (int)((o[x >> 3] >> (8 * (x & 7))) & 0xff), mv = (int)((m[x >> 3] >> (8 * (x & 7))) & 0xff);
+        v[x] = avg_u8(avg_u8(ov, mv), ov);
+    }
+    constexpr int t2[10] = {0, 2, 3, 5, 6, 8, 9, 11, 12, 14}, t1[10] = {1, 1, 4, 4, 7, 7, 10, 10, 12, 12};  // the shuffle masks of :1982-1984
+    unsigned long long lo = 0;
+    uint32_t hi = 0;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const unsigned long long b = (unsigned long long)avg_u8(avg_u8(v[t2[k]], v[t1[k]]), v[t2[k]]);
+        if (k < 8)
+            lo |= b << (8 * k);
+        else
+            hi |= (uint32_t)b << (8 * (k - 8));
+    }
+    const uint16_t hi16 = (uint16_t)hi;
+    __builtin_memcpy(dst, &lo, 8);
+    __builtin_memcpy(dst + 8, &hi16, 2);
+    if (dst_lds) {
+        __builtin_memcpy(dst_lds, &lo, 8);
+        __builtin_memcpy(dst_lds + 8, &hi16, 2);
+    }
+}
+
+// a layer's band rows halved: four output pixels per item where the SIMD loop's blocks produced them, else pixel by pixel
+__device__ __forceinline__ void half_band(const uint8_t *src, int src_pitch, int src_w, uint8_t *dst_lds, int dst_pitch, uint8_t *dst, int dst_w, int n_rows)
+{
+    const int hsize = src_w / 16, end = hsize / 2, per_row = (dst_w + 3) / 4;
+    for (int it = threadIdx.x; it < n_rows * per_row; it += kDetThreads) {
+        const int r = it / per_row, c = 4 * (it - r * per_row);
+        const uint8_t *u = src + (2 * r) * src_pitch, *l = u + src_pitch;
+        uint8_t o[4];
+        if (c + 4 <= 8 * hsize && c + 4 <= dst_w) {
+            const bool main_blocks = c < 16 * end;
+            const unsigned long long qu = *reinterpret_cast<const unsigned long long *>(u + 2 * c), ql = *reinterpret_cast<const unsigned long long *>(l + 2 * c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int v0 = avg_u8((int)((qu >> (16 * k)) & 0xff), (int)((ql >> (16 * k)) & 0xff));
+                const int v1 = avg_u8((int)((qu >> (16 * k + 8)) & 0xff), (int)((ql >> (16 * k + 8)) & 0xff));
+                o[k] = (uint8_t)(main_blocks ? avg_u8(v0, v1) : (v0 + v1) / 2);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = c + k < dst_w ? (uint8_t)half_pixel(u, l, c + k, hsize, end) : 0;
+        }
+        const uint32_t packed = (uint32_t)o[0] | (uint32_t)o[1] << 8 | (uint32_t)o[2] << 16 | (uint32_t)o[3] << 24;
+        if (dst_lds) *reinterpret_cast<uint32_t *>(dst_lds + r * dst_pitch + c) = packed;  // (the pitch covers whole dwords)
+        uint8_t *dg = dst + (int64_t)r * dst_w + c;
+        if (c + 4 <= dst_w)
+            __builtin_memcpy(dg, &packed, 4);
+        else
+            for (int k = 0; c + k < dst_w; ++k) dg[k] = o[k];
+    }
+}
+
+__global__ __launch_bounds__(kDetThreads) void det_pyramid_fused_kernel(DetArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t band_lds[];
+    const int p = blockIdx.y, band = blockIdx.x, n_layers = a.g.n_layers;
+    const PyrBand B = pyr_band(a.g);  // from the argument block: scalar arithmetic
+    uint8_t *plane = a.img + (int64_t)p * a.g.plane_bytes;
+    // rows of this band that exist, per layer
+    int nr[kPyrLayers];
+#pragma unroll
+    for (int l = 0; l < kPyrLayers; ++l) nr[l] = l < n_layers ? max(0, min(B.rows[l], a.g.L[l].h - band * B.rows[l])) : 0;
+    const int W = a.g.L[0].w;
+    {  // layer 0: cv::absdiff (MoFREAKUtilities.cpp:413-414), sixteen pixels per item
+        const uint8_t *cur = a.f.cur + (int64_t)p * a.f.pair_stride, *prev = a.f.prev ? a.f.prev + (int64_t)p * a.f.pair_stride : nullptr;
+        const int per_row = W / 16;
+        uint8_t *l0 = plane + a.g.L[0].off + (int64_t)band * kPyrBand * W;
+        for (int it = threadIdx.x; it < nr[0] * per_row; it += kDetThreads) {
+            const int r = it / per_row, k = it - r * per_row;
+            const int64_t src = (int64_t)(band * kPyrBand + r) * a.f.row_stride + 16 * k;
+            uint4 u, v = make_uint4(0, 0, 0, 0);
+            __builtin_memcpy(&u, cur + src, 16);
+            if (prev) __builtin_memcpy(&v, prev + src, 16);
+            auto word = [](uint32_t s, uint32_t t) {
+                uint32_t d = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) d |= (uint32_t)absdiff_u8(s, t, q) << (8 * q);
+                return d;
+            };
+            const uint4 d = make_uint4(word(u.x, v.x), word(u.y, v.y), word(u.z, v.z), word(u.w, v.w));
+            if (n_layers > 1) *reinterpret_cast<uint4 *>(band_lds + B.base[0] + r * B.pitch[0] + 16 * k) = d;
+            *reinterpret_cast<uint4 *>(l0 + (int64_t)r * W + 16 * k) = d;
+        }
+    }
+    if (n_layers == 1) return;
+    __syncthreads();
+    {  // layer 1 = 2/3 of layer 0 (BriskLayer::twothirdsample, brisk.cpp:1974-2065): a block of 15 -> 10 columns or a remainder pixel per item
+        const int w1 = a.g.L[1].w, hsize = W / 15, rest = w1 - 10 * hsize, per_row = hsize + rest;
+        const bool keep = 3 < n_layers;  // layer 3 reads it
+        uint8_t *l1 = plane + a.g.L[1].off + (int64_t)band * B.rows[1] * w1;
+        for (int it = threadIdx.x; it < nr[1] * per_row; it += kDetThreads) {
+            const int r2 = it / per_row, t = it - r2 * per_row, r = r2 >> 1;
+            const uint8_t *mid = band_lds + B.base[0] + (3 * r + 1) * B.pitch[0];
+            const uint8_t *outer = (r2 & 1) ? mid + B.pitch[0] : mid - B.pitch[0];  // third row for the lower output row, first for the upper
+            uint8_t *dl = keep ? band_lds + B.base[1] + r2 * B.pitch[1] : nullptr, *dg = l1 + (int64_t)r2 * w1;
+            if (t < hsize) {
+                twothird_block(outer + 15 * t, mid + 15 * t, dl ? dl + 10 * t : nullptr, dg + 10 * t);
+            } else {
+                const int c = 10 * hsize + (t - hsize);
+                const uint8_t b = (uint8_t)twothird_pixel(outer, mid, c, hsize);
+                if (dl) dl[c] = b;
+                dg[c] = b;
+            }
+        }
+    }
+    if (n_layers > 2)  // layer 2 = half of layer 0 (BriskLayer::halfsample, brisk.cpp:1840-1972)
+        half_band(band_lds + B.base[0], B.pitch[0], W, 4 < n_layers ? band_lds + B.base[2] : nullptr, B.pitch[2],
+                  plane + a.g.L[2].off + (int64_t)band * B.rows[2] * a.g.L[2].w, a.g.L[2].w, nr[2]);
+    if (n_layers <= 3) return;
+    __syncthreads();
+    half_band(band_lds + B.base[1], B.pitch[1], a.g.L[1].w, 5 < n_layers ? band_lds + B.base[3] : nullptr, B.pitch[3],
+              plane + a.g.L[3].off + (int64_t)band * B.rows[3] * a.g.L[3].w, a.g.L[3].w, nr[3]);
+    if (n_layers > 4)
+        half_band(band_lds + B.base[2], B.pitch[2], a.g.L[2].w, nullptr, 0, plane + a.g.L[4].off + (int64_t)band * B.rows[4] * a.g.L[4].w, a.g.L[4].w, nr[4]);
+    if (n_layers <= 5) return;
+    __syncthreads();
+    half_band(band_lds + B.base[3], B.pitch[3], a.g.L[3].w, nullptr, 0, plane + a.g.L[5].off + (int64_t)band * B.rows[5] * a.g.L[5].w, a.g.L[5].w, nr[5]);
+}
+
 // ------------------------------------------------------------------ dense corner scores
 // score = largest b in [1, 254] for which 9 contiguous ring pixels are all > c + b or all < c - b, 0 if none:
 // what OastDetector9_16::cornerScore's bisection converges to (oast9_16_nms.cc:42-2116), for any start value <= it.
@@ -504,34 +663,38 @@ __global__ __launch_bounds__(kDetThreads) void det_scan_kernel(DetArgs a)
     }
 }
 
-// One wave per layer row: the row's corners in x order (the order of OastDetector9_16::detect), read off the row's hit
-// masks -- a lane per 64-pixel word, a prefix sum over the words' populations, then every lane walks the few bits of
-// its own word -- each classified by the strict part of isMax2D (brisk.cpp:838-872) on the 3 x 3 scores around it.
-// A neighbour that is no corner holds 0 or a true score below the threshold in the score plane: never >= a corner's.
+// The corners of a layer in raster order (the order of OastDetector9_16::detect), read off the hit masks.  A wave takes as
+// many whole rows as fit its 64 lanes (a lane per 64-pixel word; the words of consecutive rows are consecutive in memory),
+// or one row in stretches of 64 words; a prefix sum over the words' populations places every corner, then a lane per
+// corner (the corners of a row cluster in few words: a lane per word would walk them one latency at a time) classifies
+// it by the strict part of isMax2D (brisk.cpp:838-872) on the 3 x 3 scores around it.  A neighbour that is no corner
+// holds 0 or a true score below the threshold in the score plane: never >= a corner's.
 __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
 {
-    // the wave's row is the same in every lane: kept in a scalar register, and so is everything that follows from it alone
-    const int p = blockIdx.y, row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= a.g.total_rows) return;
-    // which layer the row belongs to: from the argument block's copy of the geometry with constant indices (scalar
-    // registers, no memory) -- the same search on the device copy is a chain of dependent loads
+    // the wave's row group is the same in every lane: kept in scalar registers, and so is everything that follows from it alone
+    const int p = blockIdx.y, grp = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (grp >= a.g.cand_group_start[a.g.n_layers]) return;
+    // which layer: from the argument block's copy of the geometry with constant indices (scalar registers, no memory)
     int layer = 0;
 #pragma unroll
-    for (int k = 1; k < kDetMaxLayers; ++k) layer += (k < a.g.n_layers && row >= a.g.L[k].row_base) ? 1 : 0;
+    for (int k = 1; k < kDetMaxLayers; ++k) layer += (k < a.g.n_layers && grp >= a.g.cand_group_start[k]) ? 1 : 0;
     const DetLayer L = a.dg->L[layer];
-    const int y = row - L.row_base;
-    if (y < 3 || y >= L.h - 3) return;
-    const int32_t *rc = a.row_count + (int64_t)p * (a.dg->total_rows + 1);
-    int base = rc[row];
-    if (rc[row + 1] == base) return;
+    const int tiles_x = a.dg->tiles_x[layer], rpw = a.dg->cand_rows_per_wave[layer];
+    const int y0 = (grp - a.dg->cand_group_start[layer]) * rpw;
+    const int n_rows = min(rpw, L.h - y0), n_words = n_rows * tiles_x;  // rpw > 1: n_words <= 64
+    const int32_t *rc = a.row_count + (int64_t)p * (a.dg->total_rows + 1) + L.row_base;
+    if (rc[y0] == rc[y0 + n_rows]) return;  // no corner in these rows
     const int64_t plane = (int64_t)p * a.dg->plane_bytes + L.off;
-    const uint8_t *srow = a.score + plane + (int64_t)y * L.w;
+    const uint8_t *sc = a.score + plane;
     const int64_t cbase = (int64_t)p * a.cand_cap;
-    const int tiles_x = a.dg->tiles_x[layer];
-    const unsigned long long *mrow = a.hit_mask + (int64_t)p * a.dg->mask_words + a.dg->mask_off[layer] + (int64_t)y * tiles_x;
-    for (int w0 = 0; w0 < tiles_x; w0 += 64) {
-        const int wi = w0 + lane;
-        const unsigned long long m = wi < tiles_x ? mrow[wi] : 0ull;
+    const unsigned long long *mrow = a.hit_mask + (int64_t)p * a.dg->mask_words + a.dg->mask_off[layer] + (int64_t)y0 * tiles_x;
+    int carried = 0;  // one row in several stretches: its corners in the stretches before this one
+    for (int w0 = 0; w0 < n_words; w0 += 64) {
+        const int gw = w0 + lane;
+        const bool in = gw < n_words;
+        const int r = in ? gw / tiles_x : 0, wi = gw - r * tiles_x;  // the lane's word: row y0 + r, pixels 64 wi ..
+        const unsigned long long m = in ? mrow[gw] : 0ull;
+        const int row_first = rc[y0 + r];
         const int cnt = __popcll(m);
         int incl = cnt;
 #pragma unroll
@@ -540,8 +703,10 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
             if (lane >= o) incl += t;
         }
         const int total = __shfl(incl, 63);
-        // a lane per corner (the corners of a row cluster in few words: a lane per word would walk them one latency at
-        // a time): corner j of this stretch sits in the first word whose running count exceeds j ...
+        // corner j of the stretch (wave order = raster order) is candidate j + delta of the lane whose word holds it
+        const int row_lane0 = rpw > 1 ? r * tiles_x : 0;  // the lane that holds the first word of this lane's row
+        const int delta = row_first + carried - (__shfl(incl, row_lane0) - __shfl(cnt, row_lane0));
+        const int where = (y0 + r) << 16 | wi;
         for (int j0 = 0; j0 < total; j0 += 64) {  // (wave-uniform trip count: the shuffles below read every lane)
             const int j = j0 + lane;
             int w = 0;
@@ -553,6 +718,7 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
             w = min(w, 63);
             const int before = __shfl(incl - cnt, w);
             const uint32_t mlo = (uint32_t)__shfl((int)(uint32_t)m, w), mhi = (uint32_t)__shfl((int)(uint32_t)(m >> 32), w);
+            const int idx = j + __shfl(delta, w), wh = __shfl(where, w);
             // ... and is that word's (j - before)-th set bit, found by halving
             int k = j - before, pos = 0;
             uint32_t part = mlo;
@@ -575,8 +741,9 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
                 }
                 part &= lowmask;
             }
-            const int x = 64 * (w0 + w) + pos, idx = base + j;
+            const int x = 64 * (wh & 0xffff) + pos, y = wh >> 16;
             if (j < total && idx < a.cand_cap) {
+                const uint8_t *srow = sc + (int64_t)y * L.w;
                 uint32_t r0, r1, r2;  // scores x - 1 .. x + 2 of the three rows (a corner lies >= 3 pixels inside the layer)
                 __builtin_memcpy(&r0, srow + x - 1 - L.w, 4);
                 __builtin_memcpy(&r1, srow + x - 1, 4);
@@ -601,7 +768,7 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
                 if (flag == kDetTie) a.status[plane + (int64_t)y * L.w + x] = kStPending;
             }
         }
-        base += total;
+        carried += total;
     }
 }
 
@@ -622,7 +789,7 @@ constexpr int kWinStride = 2 * kWinBytes + 4;               // 100 bytes = 25 dw
 constexpr int kRecBytes = 128, kRecAbove = 0, kRecBelow = 40, kRecOwn = 80, kRec58 = 96;
 struct Window {
     uint8_t *cells;
-    int ox, oy, layer;
+    int ox, oy, layer, side;  // side: cells per row and column that are filled (4 above, 5 below: window_place)
     unsigned long long asked;  // bit iy * kWinSide + ix: the walk asked for this cell (and the cell is inside the scored region)
     bool escaped;              // the walk left the window (cannot happen by construction; reported if it does)
 };
@@ -706,7 +873,7 @@ template <bool MARK>
 __device__ __forceinline__ int window_at(const PairView &v, Window &w, int x, int y)
 {
     const int ix = x - w.ox, iy = y - w.oy;
-    if ((unsigned)ix >= (unsigned)kWinCells || (unsigned)iy >= (unsigned)kWinCells) {
+    if ((unsigned)ix >= (unsigned)w.side || (unsigned)iy >= (unsigned)w.side) {
         w.escaped = true;
         return 0;
     }
@@ -933,7 +1100,8 @@ __device__ __forceinline__ void walk_square(int layer, int x_layer, int y_layer,
 }
 
 // where the walk's window sits: it reaches from (int)x_1 - 1 (patch around max_x = (int)x1 when that equals (int)x_1)
-// to (int)x1 + 1 <= (int)x_1 + 3: five cells; the window holds six
+// to (int)x1 + 1.  The sampling square is 2/3 or 3/4 of a cell wide in the layer above ((int)x1 <= (int)x_1 + 1: four
+// cells) and 4/3 or 3/2 cells wide in the layer below ((int)x1 <= (int)x_1 + 2: five cells); the window holds six
 template <bool ABOVE>
 __device__ __forceinline__ void window_place(Window &win, int layer, int x_layer, int y_layer)
 {
@@ -942,6 +1110,7 @@ __device__ __forceinline__ void window_place(Window &win, int layer, int x_layer
     win.ox = (int)x_1 - 1;
     win.oy = (int)y_1 - 1;
     win.layer = ABOVE ? layer + 1 : layer - 1;
+    win.side = ABOVE ? kWinCells - 1 : kWinCells;
     win.asked = 0;
     win.escaped = false;
 }
@@ -1228,6 +1397,28 @@ __device__ __forceinline__ void finish_candidate(const DetArgs &a, const PairVie
 // maxima without ties: independent of everything else; ties: refined ahead of their decision
 constexpr int kRefineChunk = 512;  // candidates per workgroup
 
+// the SIDE x SIDE cells of window w from the image bytes behind it, a row of eight bytes at a time into the walker's record
+template <int SIDE>
+__device__ __forceinline__ void window_scores(const Patch &q, const DetLayer &L, const Window &w, uint2 *d)
+{
+#pragma unroll
+    for (int iy = 0; iy < SIDE; ++iy) {
+        const int y = w.oy + iy;
+        const bool row_in = y >= 3 && y < L.h - 3;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int ix = 0; ix < SIDE; ++ix) {
+            const int x = w.ox + ix;
+            const int sc = (row_in && x >= 3 && x < L.w - 3) ? patch_ring_score(q, iy + 3, ix + 3) : 0;
+            if (ix < 4)
+                lo |= (uint32_t)sc << (8 * ix);
+            else
+                hi = (uint32_t)sc;
+        }
+        d[iy] = make_uint2(lo, hi);
+    }
+}
+
 // The cells behind the walks.  A workgroup takes a chunk of candidates, gathers its maxima and ties ("walkers": a quarter
 // or so of the candidates; the list goes to global memory for det_walk_kernel) and hands out (walker, window) items --
 // window 0: the 5 x 5 cells of the layer above, 1: of the layer below, 2: the own 3 x 3 patch and, on layer 0, the 5/8
@@ -1316,24 +1507,11 @@ __global__ __launch_bounds__(kDetThreads) void det_window_kernel(DetArgs a)
             window_place<false>(w, layer, px, py);
         const DetLayer &L = v.g->L[w.layer];
         const Patch q = patch_fetch(v.img, L, w.ox - 3, w.oy - 3);
-        uint32_t *d = reinterpret_cast<uint32_t *>(rec + (above ? kRecAbove : kRecBelow));
-#pragma unroll
-        for (int iy = 0; iy < kWinCells; ++iy) {
-            const int y = w.oy + iy;
-            const bool row_in = y >= 3 && y < L.h - 3;
-            uint32_t lo = 0, hi = 0;
-#pragma unroll
-            for (int ix = 0; ix < kWinCells; ++ix) {
-                const int x = w.ox + ix;
-                const int sc = (row_in && x >= 3 && x < L.w - 3) ? patch_ring_score(q, iy + 3, ix + 3) : 0;
-                if (ix < 4)
-                    lo |= (uint32_t)sc << (8 * ix);
-                else
-                    hi = (uint32_t)sc;
-            }
-            d[2 * iy] = lo;
-            d[2 * iy + 1] = hi;
-        }
+        uint2 *d = reinterpret_cast<uint2 *>(rec + (above ? kRecAbove : kRecBelow));
+        if (above)
+            window_scores<kWinCells - 1>(q, L, w, d);
+        else
+            window_scores<kWinCells>(q, L, w, d);
     }
 }
 
@@ -1763,6 +1941,13 @@ int launch_det_pyramid(const DetArgs &a, void *stream)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const DetGeom &g = a.g;
+    if (g.n_layers <= kPyrLayers && g.L[0].w > 0 && g.L[0].h > 0 && (g.L[0].w & 15) == 0) {
+        const PyrBand B = pyr_band(g);
+        if (B.bytes <= 64 * 1024) {  // the whole pyramid band by band in one launch
+            hipLaunchKernelGGL(det_pyramid_fused_kernel, dim3((g.L[0].h + kPyrBand - 1) / kPyrBand, a.n_pairs), dim3(kDetThreads), (size_t)B.bytes, s, a);
+            return (int)hipGetLastError();
+        }
+    }
     if (g.L[0].w > 0 && g.L[0].h > 0)
         hipLaunchKernelGGL(det_diff_kernel, dim3((unsigned)(((int64_t)((g.L[0].w + 15) / 16) * g.L[0].h + kDetThreads - 1) / kDetThreads), a.n_pairs), dim3(kDetThreads), 0, s, a);
     // BriskScaleSpace::constructPyramid (brisk.cpp:572-588): layer 1 = 2/3 of layer 0, layer i >= 2 = half of layer i-2
@@ -1801,7 +1986,7 @@ int launch_det_keypoints(const DetArgs &a, int64_t *running, void *stream)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(det_scan_kernel, dim3(a.n_pairs), dim3(kDetThreads), 0, s, a);
-    hipLaunchKernelGGL(det_candidates_kernel, dim3((a.g.total_rows + 3) / 4, a.n_pairs), dim3(kDetThreads), 0, s, a);
+    hipLaunchKernelGGL(det_candidates_kernel, dim3((a.g.cand_group_start[a.g.n_layers] + 3) / 4, a.n_pairs), dim3(kDetThreads), 0, s, a);
     const dim3 rgrid((a.cand_cap + kRefineChunk - 1) / kRefineChunk, a.n_pairs);
     hipLaunchKernelGGL(det_window_kernel, rgrid, dim3(kDetThreads), 0, s, a);
     if (a.fp_x87)

@@ -202,6 +202,9 @@ struct DetGeom {
     // (y, tx) = pixel (64 tx + b, y) is a detected corner -- start at word mask_off[l] of the pair's mask_words words
     int32_t tiles_x[kDetMaxLayers], tile_start[kDetMaxLayers + 1];
     int64_t mask_off[kDetMaxLayers], mask_words;
+    // the candidate kernel: a wave takes cand_rows_per_wave[l] whole rows of layer l (as many as give it <= 64 mask words; 1
+    // for wider layers); cand_group_start[l] = first such group of layer l, [n_layers] = groups per pair
+    int32_t cand_rows_per_wave[kDetMaxLayers], cand_group_start[kDetMaxLayers + 1];
 };
 constexpr int kDetTileW = 64, kDetTileH = 64;
 // candidate flags
