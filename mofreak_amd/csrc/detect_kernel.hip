@@ -532,10 +532,13 @@ __device__ __forceinline__ uint32_t compass_test4(uint32_t C, uint32_t L4, uint3
     return res;
 }
 
+// the corner kernel's image tile in LDS: rows of 96 bytes from image column x0 - 16 (whole 16-byte pieces: six per row)
+constexpr int kCornerLdsW = 96, kCornerLdsX = 16;
+
 __global__ __launch_bounds__(kDetThreads) void det_corner_kernel(DetArgs a)
 {
     constexpr int kPasses = kDetTileH / 16;  // 16 rows of 16 four-pixel groups per pass of the 256 threads
-    __shared__ __attribute__((aligned(16))) uint8_t tile[(kDetTileH + 6) * kScoreLdsW];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[(kDetTileH + 6) * kCornerLdsW];
     __shared__ __attribute__((aligned(16))) uint8_t out[kDetTileH * kDetTileW];
     __shared__ uint16_t list[kDetTileH * kDetTileW];
     __shared__ unsigned long long row_mask[kDetTileH];
@@ -548,7 +551,27 @@ __global__ __launch_bounds__(kDetThreads) void det_corner_kernel(DetArgs a)
     const int tiles_x = a.dg->tiles_x[layer], tl = t - a.dg->tile_start[layer];
     const int ty = tl / tiles_x, tx = tl - ty * tiles_x, x0 = tx * kDetTileW, y0 = ty * kDetTileH;
     const int64_t plane = (int64_t)p * a.dg->plane_bytes + L.off;
-    score_tile_load<kDetTileH>(tile, a.img + plane, L, x0, y0);
+    {  // tile + 3-pixel halo -> LDS, sixteen bytes per item (positions outside the image read as zero and are never scored)
+        const uint8_t *img = a.img + plane;
+        constexpr int kPieces = kCornerLdsW / 16;
+        for (int it = threadIdx.x; it < (kDetTileH + 6) * kPieces; it += kDetThreads) {
+            const int r = it / kPieces, k = it - r * kPieces;
+            const int gx = x0 - kCornerLdsX + 16 * k, gy = y0 - 3 + r;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gy >= 0 && gy < L.h) {
+                const uint8_t *src = img + (int64_t)gy * L.w + gx;
+                if (gx >= 0 && gx + 16 <= L.w) {
+                    __builtin_memcpy(&v, src, 16);
+                } else if (gx + 16 > 0 && gx < L.w) {  // a piece that straddles the image's edge: byte by byte
+                    uint8_t b[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) b[q] = (gx + q >= 0 && gx + q < L.w) ? src[q] : (uint8_t)0;
+                    __builtin_memcpy(&v, b, 16);
+                }
+            }
+            *reinterpret_cast<uint4 *>(tile + r * kCornerLdsW + 16 * k) = v;
+        }
+    }
     static_assert(kDetTileH * kDetTileW == 16 * kDetThreads, "a thread clears 16 bytes of the tile's scores");
     reinterpret_cast<uint4 *>(out)[threadIdx.x] = make_uint4(0, 0, 0, 0);
     if (threadIdx.x < kDetTileH) row_mask[threadIdx.x] = 0ull;
@@ -556,46 +579,48 @@ __global__ __launch_bounds__(kDetThreads) void det_corner_kernel(DetArgs a)
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int thr = a.safe_threshold;
-    // (1) the compass test: thread = (row r0 of a pass, group g of four pixels); survivors per pass and pixel as ballots,
-    // then ONE reservation in the tile's list for all of the wave's survivors
+    // (1) the compass test: thread = (row r0 of a pass, group g of four pixels): a 16-bit mask of survivors per thread (four
+    // passes of four pixels), one prefix sum over the wave and ONE reservation in the tile's list for all of them
     const int g = threadIdx.x & 15, r0 = threadIdx.x >> 4;
     uint32_t colmask = 0;  // which of the group's four columns lie inside the scored region
 #pragma unroll
     for (int i = 0; i < 4; ++i) colmask |= (x0 + 4 * g + i >= 3 && x0 + 4 * g + i < L.w - 3) ? 1u << i : 0u;
-    unsigned long long pm[kPasses][4];
-    int n_wave = 0;
+    uint32_t m16 = 0;
 #pragma unroll
     for (int j = 0; j < kPasses; ++j) {
         const int ry = r0 + 16 * j, y = y0 + ry;
-        const uint32_t *q = reinterpret_cast<const uint32_t *>(tile + (ry + 3) * kScoreLdsW) + g + 1;  // the dword of columns 4g .. 4g + 3
-        const uint32_t C = q[0], Cp = q[-1], Cn = q[1], U = q[-3 * (kScoreLdsW / 4)], D = q[3 * (kScoreLdsW / 4)];
-        uint32_t m4 = compass_test4(C, __builtin_amdgcn_alignbyte(C, Cp, 1), __builtin_amdgcn_alignbyte(Cn, C, 3), U, D, thr);
-        m4 = (y >= 3 && y < L.h - 3) ? (m4 & colmask) : 0u;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            pm[j][i] = __ballot((m4 >> i) & 1u);
-            n_wave += __popcll(pm[j][i]);
-        }
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(tile + (ry + 3) * kCornerLdsW + kCornerLdsX) + g;  // the dword of columns 4g .. 4g + 3
+        const uint32_t C = q[0], Cp = q[-1], Cn = q[1], U = q[-3 * (kCornerLdsW / 4)], D = q[3 * (kCornerLdsW / 4)];
+        const uint32_t m4 = compass_test4(C, __builtin_amdgcn_alignbyte(C, Cp, 1), __builtin_amdgcn_alignbyte(Cn, C, 3), U, D, thr);
+        m16 |= ((y >= 3 && y < L.h - 3) ? (m4 & colmask) : 0u) << (4 * j);
     }
-    if (n_wave) {  // wave-uniform
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&n_list, n_wave);
-        base = __builtin_amdgcn_readfirstlane(base);
+    {
+        const int cnt = __popc(m16);
+        int incl = cnt;
 #pragma unroll
-        for (int j = 0; j < kPasses; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned long long m = pm[j][i];
-                if ((m >> lane) & 1) list[base + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)((r0 + 16 * j) << 6 | (4 * g + i));
-                base += __popcll(m);
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        const int total = __shfl(incl, 63);
+        if (total) {  // wave-uniform
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&n_list, total);
+            int k = __builtin_amdgcn_readfirstlane(base) + incl - cnt;
+            uint32_t m = m16;
+            while (m) {  // a few bits per lane at most
+                const int b = __ffs((int)m) - 1;
+                m &= m - 1;
+                list[k++] = (uint16_t)((r0 + 16 * (b >> 2)) << 6 | (4 * g + (b & 3)));
             }
+        }
     }
     __syncthreads();
     // (2) the survivors' scores
     const int n = n_list;
     for (int i = threadIdx.x; i < n; i += kDetThreads) {
         const int e = list[i], ry = e >> 6, lx = e & 63;
-        const int s = ring_score<kScoreLdsW>(tile + (ry + 3) * kScoreLdsW + lx + 4);
+        const int s = ring_score<kCornerLdsW>(tile + (ry + 3) * kCornerLdsW + lx + kCornerLdsX);
         if (s >= thr) {
             out[ry * kDetTileW + lx] = (uint8_t)s;
             atomicOr(&row_mask[ry], 1ull << lx);

@@ -33,10 +33,6 @@ ABLATIONS = {
                               "? patch_ring_score(q, 5 + dy, 5 + dx) : 0;", "? patch_byte(q, 5 + dy, 5 + dx) : 0;"),
     # refinement: no image patch loads (registers filled from the coordinates)
     "noload": lambda t: sub1(t, "__builtin_memcpy(&v, img + L.off + (int64_t)yc * L.w + xs, 16);", "v = make_uint4(xs, yc, r, 0);"),
-    # corner kernel: nobody survives the compass test (what is left: tile load, zero fill, write out)
-    "nopass": lambda t: sub1(t, "const bool pass = (nb >= 2 || nd >= 2) &&", "const bool pass = (nb >= 200 || nd >= 200) &&"),
-    # corner kernel: survivors are listed but not scored
-    "nophase2": lambda t: sub1(t, "for (int i = threadIdx.x; i < n; i += kDetThreads) {\n        const int e = list[i]", "for (int i = threadIdx.x; i < 0; i += kDetThreads) {\n        const int e = list[i]"),
 }
 
 
