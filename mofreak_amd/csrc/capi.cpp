@@ -299,7 +299,11 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
         if (rc) return rc;
     } else {
         const int tiles_x = (g.W + kTileW - 1) / kTileW, tiles_y = (g.H + kTileH - 1) / kTileH;
-        const int64_t n_keys = (int64_t)tiles_x * tiles_y * (d_offsets ? n_pairs : 1);
+        // A list per pair with few keypoints per tile (a detector's output: some thousand keypoints on a frame of 255 tiles)
+        // would be handed to the gather path tile by tile in the binning pass: it goes there as a whole instead -- no tile
+        // keys to count, scan and scatter, no tile kernel launch.  (A tile pays from about 48 keypoints up, tile_kernel.hip.)
+        const bool all_gather = d_offsets != nullptr && n_kp < (int64_t)n_pairs * tiles_x * tiles_y * 24;
+        const int64_t n_keys = all_gather ? 0 : (int64_t)tiles_x * tiles_y * (d_offsets ? n_pairs : 1);
         const int64_t n_bkeys = (int64_t)tiles_y * (d_offsets ? n_pairs : 1);  // the gather path's keypoints are binned too: by band of rows
         if (n_keys + n_bkeys >= ((int64_t)1 << 31)) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "too many (pair, tile) bins in one call");
         const size_t bin_blocks = ((size_t)n_kp + 255) / 256;
@@ -323,7 +327,7 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
         b.H = g.H;
         b.tiles_x = tiles_x;
         b.tiles_y = tiles_y;
-        b.force_slow = 0;
+        b.force_slow = all_gather ? 1 : 0;
         b.small = ctx->d_small;
         b.kp_key = static_cast<int32_t *>(ctx->kp_key.ptr);
         b.kp_scale = static_cast<uint8_t *>(ctx->kp_key.ptr) + (size_t)n_kp * 4;
@@ -350,7 +354,7 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
         if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(span.ev[1], ctx->stream));
 
         const int kMaxGridY = 32768;  // pairs per tile_kernel launch (keeps the 1-D grid well inside 2^28 work items)
-        for (int p0 = 0; p0 < n_pairs; p0 += kMaxGridY) {
+        for (int p0 = 0; p0 < n_pairs && !all_gather; p0 += kMaxGridY) {
             const int np = std::min(kMaxGridY, n_pairs - p0);
             TileArgs t;
             t.f.cur = cur + (int64_t)p0 * g.pair_stride;

@@ -56,7 +56,7 @@ def build(name, flags, patch=None):
     print(out)
 
 
-def run(libs, pairs):
+def run(libs, pairs, describe=False):
     os.chdir(ROOT)
     env0 = dict(os.environ, TMPDIR="/tmp")
     for lib in libs:
@@ -66,13 +66,14 @@ def run(libs, pairs):
         os.makedirs(out, exist_ok=True)
         env = dict(env0, MOFREAK_HIP_LIBRARY=os.path.abspath(lib))
         log = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "--", "python3",
-                              "mofreak_amd/tools/detector_probe.py", str(pairs), "6"], env=env, capture_output=True, text=True, timeout=300)
+                              "mofreak_amd/tools/detector_probe.py", str(pairs), "6", *(["describe"] if describe else [])], env=env, capture_output=True,
+                             text=True, timeout=300)
         probe = [ln for ln in log.stdout.splitlines() if ln.startswith("pairs=")]
         stats = glob.glob(os.path.join(out, "**", "*kernel_stats.csv"), recursive=True)
         per = {}
         if stats:
             for r in csv.DictReader(open(stats[0])):
-                m = re.search(r"(det_\w+)", r["Name"])
+                m = re.search(r"(det_\w+|describe_kernel|tile_kernel|band_\w+|bin_\w+|compact_\w+)", r["Name"])
                 if m:
                     per[m.group(1)] = per.get(m.group(1), 0.0) + float(r["TotalDurationNs"]) / 7e3  # 1 warm-up + 6 calls; microseconds per call
         total = sum(per.values())
@@ -92,6 +93,7 @@ if __name__ == "__main__":
         if len(a) > 1 and a[1].isdigit():
             pairs = int(a[1])
             a = a[1:]
-        run(a[1:], pairs)
+        describe = len(a) > 1 and a[1] == "describe"  # the descriptors of the detector's keypoints behind it
+        run(a[2 if describe else 1:], pairs, describe)
     else:
         raise SystemExit(__doc__)

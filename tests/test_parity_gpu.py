@@ -262,11 +262,13 @@ def test_orientation_and_scale_normalisation_flags(native_lib, oracle):
         assert np.array_equal(valid, want_v) and np.array_equal(desc, want_d), (on, sn)
 
 
-def test_csr_ragged_keypoint_lists(ctx_path, oracle):
+@pytest.mark.parametrize("counts", [[0, 37, 1, 0, 250, 64], [0, 900, 1, 0, 1500, 700]])
+def test_csr_ragged_keypoint_lists(ctx_path, oracle, counts):
+    """One keypoint list per pair.  The first set is sparse (fewer than 24 keypoints per tile on average: the whole call goes
+    to the gather path, as a detector's output does), the second dense enough for the tile kernel."""
     W, H = 320, 240
     fr = synth.synth_stack(11, W, H)
     rng = np.random.default_rng(12)
-    counts = [0, 37, 1, 0, 250, 64]
     offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     kps = synth.random_keypoints(rng, int(offs[-1]), W, H, sizes=(7.0, 8.4, 12.0))
     cur, prev = fr[5:], fr[:6]
