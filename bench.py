@@ -13,8 +13,9 @@ Other workloads of BASELINE.json (each prints its own single JSON line; the metr
   --config C2                 640x480, 16-px grid, 1000 resident pairs (the bit-exactness configuration), same line shape
   --config C4 [--gpus N]      HMDB51-shaped batch: clips of uneven length, one video per GPU at a time, rows gathered to
                               rank 0 (harness.run_dataset): clips/s, descriptors/s, gather_ms
-  --config C5 --stream        TRECVID-shaped 720x576 stream from page-locked host memory through the pipelined frame
-                              loop: sustained descriptors/s INCLUDING the host-to-device copies and the rows' way back
+  --config C5 [--frames N]    TRECVID-shaped 720x576 stream from page-locked host memory through the pipelined frame
+                              loop: sustained descriptors/s INCLUDING the host-to-device copies and the rows' way back;
+                              --frames 90000 (the hour-long stream): pushed in chunks of 2048 frames, bounded memory
 """
 from __future__ import annotations
 
@@ -524,7 +525,8 @@ def bench_dataset(args):
                            "every rank's clips in ONE pipelined mofreak_extract_clips call, rows gathered device to device" if res["batched"]
                            else f"{args.workers} host thread(s) with a context each per rank, one synchronous C-ABI call per clip")},
             "frames_in_GBs": float(lengths.sum() * W * H * steps / elapsed / 1e9),
-            "gather_ms": gather_s * 1e3, "ranks_seen": ranks_seen(dist, world), **dist_info(dist, args), "rounds": res["rounds"], "frames_in_MB_per_step": float(lengths.sum() * W * H / 1e6),
+            "gather_ms": gather_s * 1e3, "ranks_seen": ranks_seen(dist, world), **dist_info(dist, args), "rounds": res["rounds"],
+            "rank0_seconds_last_step": {"extract": res["compute_s"], "exchange_and_copy_to_host": res["gather_s"]}, "frames_in_MB_per_step": float(lengths.sum() * W * H / 1e6),
             "note": f"host frames in ({'pageable' if args.pageable else 'page-locked'} memory) -> rows on rank 0's host; "
                     "compute, gather and the root's device-to-host copy are all inside the timed region"}))
     mo.close()
@@ -535,7 +537,13 @@ def bench_dataset(args):
 
 # ------------------------------------------------------------------------------------------------ C5: a long stream
 def bench_stream(args):
+    """BASELINE config 5: an hour-long 720x576 stream (90 000 frames at 25 fps) through mofreak_stream_push_frames in bounded
+    memory: two page-locked chunk buffers of --push-frames frames, refilled by host threads (the decoder's stand-in) while the
+    other one is being pushed; the device keeps the stream's last gap frames, the rows of a chunk come back into a page-locked
+    buffer per slot.  --frames below 2 * --push-frames: the whole stack in one mofreak_extract_stream_pipelined call."""
     torch, dist, rank, local_rank, world, on_device = dist_setup(args)
+    import queue
+
     import mofreak_amd as M
     from mofreak_amd import synth
 
@@ -547,12 +555,6 @@ def bench_stream(args):
     distinct = min(T, 256)  # distinct synthetic frames, repeated to the stream's length (host generation is not the subject)
     base = make_stack(distinct, W, H, t0=5000 * rank, workers=max(1, min(16, ncpu // max(1, world))))
     ctx = M.Context(local_rank)
-    frames = ctx.host_alloc((T, H, W))  # the decoder's output buffer: page-locked
-    for t0 in range(0, T, distinct):
-        n = min(distinct, T - t0)
-        frames[t0:t0 + n] = base[:n]
-    n_rows_max = (T - 5) * len(kps)
-    rows = ctx.host_alloc((n_rows_max,), M.api.ROW_DTYPE)
     # resident rate of the same shape for reference (frames already in HBM, no rows back)
     d_fr = torch.from_numpy(base).cuda()
     d_kps = torch.from_numpy(kps).cuda()
@@ -567,17 +569,99 @@ def bench_stream(args):
         ctx.extract_pairs(d_fr[5:], d_fr[:np_res], W, H, np_res, d_kps, desc, valid)
     ctx.synchronize()
     resident = 5 * np_res * len(kps) / (time.perf_counter() - t0)
+    del d_fr, desc, valid
+    steps = args.steps or (1 if T > 20000 else 3)
+    chunk = args.push_frames
+    pushed = T >= 2 * chunk
+    n_rows_max = (T - 5) * len(kps)
+    extra = {}
+    if not pushed:
+        frames = ctx.host_alloc((T, H, W))  # the decoder's output buffer: page-locked
+        for t0 in range(0, T, distinct):
+            n = min(distinct, T - t0)
+            frames[t0:t0 + n] = base[:n]
+        rows = ctx.host_alloc((n_rows_max,), M.api.ROW_DTYPE)
+        got = ctx.extract_stream_pipelined_host(frames[: min(T, 600)], kps, chunk_frames=args.chunk, rows_out=rows)  # warm-up
+        assert len(got) == (min(T, 600) - 5) * len(kps)
+        fence(torch, dist, world)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            got = ctx.extract_stream_pipelined_host(frames, kps, chunk_frames=args.chunk, rows_out=rows)
+        fence(torch, dist, world)
+        elapsed = max_over_ranks(torch, dist, world, on_device, time.perf_counter() - t0)
+        assert len(got) == n_rows_max
+        pinned_bytes = frames.nbytes + rows.nbytes
+        ctx.host_free(frames)
+        ctx.host_free(rows)
+        how = f"one {W}x{H} stream of {T} frames per GPU, whole stack in page-locked host memory, one pipelined call, windows of {args.chunk} frames"
+    else:
+        bufs = [ctx.host_alloc((chunk, H, W)) for _ in range(2)]
+        rows = [ctx.host_alloc((chunk * len(kps),), M.api.ROW_DTYPE) for _ in range(2)]
+        pinned_bytes = sum(b.nbytes for b in bufs) + sum(r.nbytes for r in rows)
+        fillers = max(1, min(args.fill_threads, ncpu // max(1, world)))
+        pool = ThreadPoolExecutor(fillers)
 
-    got = ctx.extract_stream_pipelined_host(frames[: min(T, 600)], kps, chunk_frames=args.chunk, rows_out=rows)  # warm-up
-    assert len(got) == (min(T, 600) - 5) * len(kps)
-    steps = args.steps or 3
-    fence(torch, dist, world)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        got = ctx.extract_stream_pipelined_host(frames, kps, chunk_frames=args.chunk, rows_out=rows)
-    fence(torch, dist, world)
-    elapsed = max_over_ranks(torch, dist, world, on_device, time.perf_counter() - t0)
-    assert len(got) == n_rows_max
+        def fill(buf, t0, n):
+            """The decoder's stand-in: frames t0 .. t0 + n of the stream into the chunk buffer, on `fillers` host threads."""
+            def part(lo, hi):
+                for t in range(lo, hi):  # (frame by frame: the stream repeats its `distinct` frames)
+                    buf[t - t0] = base[t % distinct]
+            step = (n + fillers - 1) // fillers
+            return [pool.submit(part, t0 + i * step, min(t0 + n, t0 + (i + 1) * step)) for i in range(fillers) if i * step < n]
+
+        def one_pass():
+            filled = queue.Queue()
+            free = queue.Queue()
+            for b in range(2):
+                free.put(b)
+
+            def producer():
+                for t0 in range(0, T, chunk):
+                    b = free.get()
+                    n = min(chunk, T - t0)
+                    for f in fill(bufs[b], t0, n):
+                        f.result()
+                    filled.put((b, n))
+                filled.put(None)
+
+            th = threading.Thread(target=producer)
+            th.start()
+            total = waited = 0
+            checks = []
+            with ctx.open_stream(W, H, use_detector=False) as st:
+                while True:
+                    tw = time.perf_counter()
+                    item = filled.get()
+                    waited += time.perf_counter() - tw
+                    if item is None:
+                        break
+                    b, n = item
+                    got = st.push_frames(bufs[b][:n], kps, chunk_frames=args.chunk, rows_out=rows[b])
+                    total += len(got)
+                    if len(got):
+                        checks.append((int(got["frame_number"][0]), int(got["frame_number"][-1])))
+                    free.put(b)
+            th.join()
+            return total, waited, checks
+
+        warm_T, T_keep = min(T, 2 * chunk + 7), T
+        T = warm_T
+        total, _, _ = one_pass()  # warm-up on the first chunks
+        assert total == (warm_T - 5) * len(kps)
+        T = T_keep
+        fence(torch, dist, world)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            total, waited, checks = one_pass()
+        fence(torch, dist, world)
+        elapsed = max_over_ranks(torch, dist, world, on_device, time.perf_counter() - t0)
+        assert total == n_rows_max and checks[0][0] == 4 and checks[-1][1] == T - 2, (total, checks[:1], checks[-1:])
+        pool.shutdown()
+        for b in bufs + rows:
+            ctx.host_free(b)
+        extra = {"push_frames_per_chunk": chunk, "fill_threads": fillers, "seconds_waiting_for_the_filler_last_step": waited}
+        how = (f"one {W}x{H} stream of {T} frames per GPU through mofreak_stream_push_frames: two page-locked buffers of {chunk} frames refilled by "
+               f"{fillers} host threads, windows of {args.chunk} frames inside a push")
     if rank == 0:
         n_desc = n_rows_max
         value = world * n_desc * steps / elapsed
@@ -588,14 +672,12 @@ def bench_stream(args):
             "value": value, "unit": "descriptors/s", "n_gpus": world, "steps": steps, "warmup": 1,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": f"synthetic ({distinct} distinct frames repeated)",
-            "config": {"workload": f"C5: one {W}x{H} stream of {T} frames per GPU from page-locked host memory, dense {cfg['step']}-px grid, "
-                                   f"{len(kps)} keypoints/frame, chunks of {args.chunk} frames", "descriptors_per_step_per_gpu": n_desc,
+            "config": {"workload": f"C5: {how}, dense {cfg['step']}-px grid, {len(kps)} keypoints/frame", "descriptors_per_step_per_gpu": n_desc,
                        "parallelism": f"one stream per GPU x{world}"},
             "ranks_seen": ranks_seen(dist, world), **dist_info(dist, args), "frames_per_s": world * (T - 5) * steps / elapsed, "resident_descriptors_per_s": resident,
             "pcie_bound_descriptors_per_s": pcie_bound, "frac_of_min_bound": value / world / min(pcie_bound, resident),
-            "h2d_GBs": (T * W * H * steps / elapsed) / 1e9, "d2h_GBs": (n_desc * 32 * steps / elapsed) / 1e9}))
-    ctx.host_free(frames)
-    ctx.host_free(rows)
+            "h2d_GBs": (T * W * H * steps / elapsed) / 1e9, "d2h_GBs": (n_desc * 32 * steps / elapsed) / 1e9,
+            "peak_page_locked_MB": pinned_bytes / 1e6, **extra}))
     ctx.close()
     if grouped(dist):
         dist.barrier()
@@ -611,7 +693,10 @@ def main():
     ap.add_argument("--config", default="C3", help="C3 = the metric's (1080p, 8-px grid); C2, C4, C5: see the module text")
     ap.add_argument("--stream", action="store_true", help="with --config C5: the pipelined host-to-device stream (its only mode)")
     ap.add_argument("--frames", type=int, default=2005, help="C5: frames in the stream")
-    ap.add_argument("--chunk", type=int, default=256, help="C5: frames per pipelined chunk")
+    ap.add_argument("--chunk", type=int, default=256, help="C5: frames per window of the copy/compute pipeline")
+    ap.add_argument("--push-frames", type=int, default=2048, help="C5: frames per page-locked chunk buffer (streams of at least two such chunks are pushed "
+                    "chunk by chunk in bounded memory; BASELINE's hour-long stream: --frames 90000)")
+    ap.add_argument("--fill-threads", type=int, default=12, help="C5: host threads that refill a chunk buffer (the decoder's stand-in)")
     ap.add_argument("--clips", type=int, default=512, help="C4: clips in the batch (HMDB51 has 6766)")
     ap.add_argument("--workers", type=int, default=4, help="C4: host threads per rank, each with a context of its own, taking the rank's clips in turn")
     ap.add_argument("--per-clip-calls", action="store_true", help="C4: one synchronous mofreak_extract_stream call per clip (round 2's path) instead of "

@@ -290,6 +290,22 @@ int mofreak_stream_open(mofreak_ctx *ctx, int W, int H, int use_detector, int th
 int mofreak_stream_push(mofreak_stream *s, const uint8_t *frame, int channels, int64_t row_stride,
                         const mofreak_keypoint *kps, int64_t n_kp, mofreak_row *rows_out, int64_t rows_capacity,
                         int64_t *n_rows_out, unsigned flags);
+/*
+ * Many frames at once, bounded memory: the continuation of the same stream by n_frames contiguous W x H gray frames in HOST
+ * memory (page-locked memory from mofreak_host_alloc goes down by DMA in place).  The gap frames before the chunk are
+ * still in the device ring, so pairs run on across pushes and frame numbers keep counting (MoFREAKUtilities.cpp:391-401,
+ * 485-488 is O(1) in the length of the video, and so is this: nothing but the ring survives a push).  Inside the call the
+ * chunk goes through the three-stream pipeline of mofreak_extract_stream_pipelined in windows of chunk_frames frames
+ * (<= gap: a default of about 96 MiB): the next window's copy under this window's kernels, the previous one's rows on
+ * their way back.  kps: ONE keypoint list (host) for every frame of the chunk (streams opened with use_detector = 0).
+ * rows_out (host; page-locked: DMA in place) receives the chunk's rows -- those of mofreak_extract_stream on the whole
+ * stream, piece by piece.  A caller with two chunk buffers refills one while the other is being pushed.  On
+ * MOFREAK_ERR_CAPACITY the frames are consumed all the same and *n_rows_out holds the number of rows the chunk has.
+ * Frame-at-a-time pushes and chunk pushes may be mixed on one stream.
+ */
+int mofreak_stream_push_frames(mofreak_stream *s, const uint8_t *frames, int n_frames, int chunk_frames,
+                               const mofreak_keypoint *kps, int64_t n_kp, mofreak_row *rows_out, int64_t rows_capacity,
+                               int64_t *n_rows_out);
 int64_t mofreak_stream_frames(const mofreak_stream *s); /* frames pushed so far */
 void mofreak_stream_close(mofreak_stream *s);
 

@@ -39,7 +39,7 @@ EXPORTS = [
     "mofreak_parse_rows", "mofreak_diff_integral", "mofreak_mip19", "mofreak_roi19", "mofreak_freak_info",
     "mofreak_theta_index", "mofreak_pattern_sizes", "mofreak_scale_index", "mofreak_table_pattern",
     "mofreak_table_orientation", "mofreak_table_bit_pairs", "mofreak_table_resize", "mofreak_table_mip_positions",
-    "mofreak_detect_pairs", "mofreak_detect_set_capacity", "mofreak_brisk_pyramid", "mofreak_compute_stream", "mofreak_stream_open", "mofreak_stream_push", "mofreak_stream_frames", "mofreak_stream_close",
+    "mofreak_detect_pairs", "mofreak_detect_set_capacity", "mofreak_brisk_pyramid", "mofreak_compute_stream", "mofreak_stream_open", "mofreak_stream_push", "mofreak_stream_push_frames", "mofreak_stream_frames", "mofreak_stream_close",
 ]
 
 
@@ -110,6 +110,7 @@ def load() -> C.CDLL:
     L.mofreak_detect_set_capacity.argtypes = [vp, i32]
     L.mofreak_stream_open.argtypes = [vp, i32, i32, i32, i32, i32, C.POINTER(vp)]
     L.mofreak_stream_push.argtypes = [vp, vp, i32, i64, vp, i64, vp, i64, C.POINTER(i64), C.c_uint]
+    L.mofreak_stream_push_frames.argtypes = [vp, vp, i32, i32, vp, i64, vp, i64, C.POINTER(i64)]
     L.mofreak_stream_frames.argtypes = [vp]
     L.mofreak_stream_frames.restype = i64
     L.mofreak_stream_close.argtypes = [vp]
@@ -674,6 +675,20 @@ class FrameStream:
         self._ctx._check(self._ctx._lib.mofreak_stream_push(self._h, _ptr(frame), channels, channels * self.W, _ptr(k),
                                                             0 if k is None else len(k), _ptr(rows), capacity, C.byref(n), MEM_HOST))
         return rows[:n.value].copy()
+
+    def push_frames(self, frames: np.ndarray, kps: np.ndarray, chunk_frames: int = 0, rows_out: np.ndarray | None = None) -> np.ndarray:
+        """A chunk of (n, H, W) gray frames at once (mofreak_stream_push_frames): the rows of the pairs it completes.  frames
+        and rows_out from Context.host_alloc() move by DMA in place; rows_out None: a new array sized for the chunk."""
+        assert frames.dtype == np.uint8 and frames.ndim == 3 and frames.flags.c_contiguous and frames.shape[1:] == (self.H, self.W)
+        if not self._h:
+            raise MoFREAKError(ERR_BAD_ARG, "stream is closed")
+        k = np.ascontiguousarray(kps, np.float32).reshape(-1, 3)
+        rows = rows_out if rows_out is not None else np.zeros(max(frames.shape[0] * len(k), 1), ROW_DTYPE)
+        assert rows.dtype == ROW_DTYPE and rows.flags.c_contiguous
+        n = C.c_int64(0)
+        self._ctx._check(self._ctx._lib.mofreak_stream_push_frames(self._h, _ptr(frames), frames.shape[0], chunk_frames, _ptr(k), len(k), _ptr(rows),
+                                                                   rows.shape[0], C.byref(n)))
+        return rows[:n.value] if rows_out is not None else rows[:n.value].copy()
 
     @property
     def frames(self) -> int:

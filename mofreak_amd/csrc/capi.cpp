@@ -965,6 +965,16 @@ int mofreak_extract_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W
     return MOFREAK_OK;
 }
 
+static bool is_device_memory(const void *p)
+{
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice;
+}
+
 static bool is_pinned_host(const void *p)
 {
     hipPointerAttribute_t at{};
@@ -1068,9 +1078,20 @@ int pipe_host_pair(mofreak_ctx *ctx, void *(&slot)[2], size_t &have, size_t want
 // and the compaction drops the pairs whose two frames belong to different clips (label < 0) and numbers the others
 // gap - 1, gap, ... inside their clip (:401, :488).  Window k + 1's copies run under window k's kernels while window
 // k - 1's rows travel back.
+// A clip may come in several pieces (joined[c] != 0: piece c continues the clip of piece c - 1 -- a stream's frames still on
+// the device in front of the chunk that was just pushed) and may start at a frame number of its own (label_base[c], read
+// at a clip's first piece: the frames of the stream before it); a piece may be device memory (copied device to device).
+struct ClipPieces {
+    const uint8_t *joined = nullptr;
+    const int64_t *label_base = nullptr;
+    int last_window_slot = -1;       // out: which of the pipeline's two frame buffers holds the sequence's last window ...
+    int64_t last_window_first = 0;   // ... and which frame of the sequence is its first
+};
+
 int extract_clips_impl(mofreak_ctx *ctx, const uint8_t *const *clip_frames, const int32_t *clip_n_frames, int n_clips, int W,
                        int H, int chunk_frames, const mofreak_keypoint *kps, int64_t n_kp, mofreak_row *rows_out,
-                       int64_t rows_capacity, int64_t *clip_row_offsets_out, int64_t *n_rows_out, bool rows_on_device)
+                       int64_t rows_capacity, int64_t *clip_row_offsets_out, int64_t *n_rows_out, bool rows_on_device,
+                       ClipPieces *pieces = nullptr)
 {
     const int gap = ctx->params.gap_for_frame_difference;
     const int64_t fsz = (int64_t)W * H;
@@ -1098,15 +1119,20 @@ int extract_clips_impl(mofreak_ctx *ctx, const uint8_t *const *clip_frames, cons
     int rc = validate_frames(ctx, some_frame, some_frame, W, H, W, fsz, chunk_pairs);
     if (rc) return rc;
 
-    // frame labels per pair, and which clip a frame belongs to (for the segment copies)
+    // frame labels per pair (a clip = a run of joined pieces), and which piece a frame belongs to (for the segment copies)
     std::vector<int32_t> label((size_t)n_pairs_all);
-    for (int c = 0; c < n_clips; ++c)
-        for (int64_t q = start[c]; q < start[c + 1] && q < n_pairs_all; ++q)
-            label[(size_t)q] = q + gap < start[c + 1] ? (int32_t)(q - start[c]) + gap - 1 : -1;
-    std::vector<char> clip_pinned((size_t)n_clips);
+    for (int c = 0; c < n_clips;) {
+        int c1 = c + 1;
+        while (c1 < n_clips && pieces && pieces->joined && pieces->joined[c1]) ++c1;
+        const int64_t base = pieces && pieces->label_base ? pieces->label_base[c] : 0;
+        for (int64_t q = start[c]; q < start[c1] && q < n_pairs_all; ++q)
+            label[(size_t)q] = q + gap < start[c1] ? (int32_t)(q - start[c] + base) + gap - 1 : -1;
+        c = c1;
+    }
+    std::vector<char> clip_pinned((size_t)n_clips);  // 1: page-locked or device memory (copied in place), 0: through the staging buffers
     bool all_pinned = true;
     for (int c = 0; c < n_clips; ++c) {
-        clip_pinned[c] = clip_n_frames[c] == 0 || is_pinned_host(clip_frames[c]);
+        clip_pinned[c] = clip_n_frames[c] == 0 || is_pinned_host(clip_frames[c]) || is_device_memory(clip_frames[c]);
         all_pinned = all_pinned && clip_pinned[c];
     }
     const bool rows_pinned = rows_on_device || is_pinned_host(rows_out);
@@ -1193,7 +1219,7 @@ int extract_clips_impl(mofreak_ctx *ctx, const uint8_t *const *clip_frames, cons
                 std::memcpy(stage, src, (size_t)(hi - lo) * fsz);
                 src = stage;
             }
-            HIP_TRY(ctx, hipMemcpyAsync(dst, src, (size_t)(hi - lo) * fsz, hipMemcpyHostToDevice, P.s_in));
+            HIP_TRY(ctx, hipMemcpyAsync(dst, src, (size_t)(hi - lo) * fsz, hipMemcpyDefault, P.s_in));  // (host or device piece)
         }
         HIP_TRY(ctx, hipEventRecord(P.ev_in[b], P.s_in));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, P.ev_in[b], 0));
@@ -1230,6 +1256,10 @@ int extract_clips_impl(mofreak_ctx *ctx, const uint8_t *const *clip_frames, cons
         state[b] = 1;
         chunk_q0[b] = f0;
         chunk_np[b] = np;
+        if (pieces) {
+            pieces->last_window_slot = b;
+            pieces->last_window_first = f0;
+        }
         if ((rc = advance(b ^ 1, false))) return rc;  // window k-1: its count is in (or we wait for it) -> rows start travelling
     }
     for (int k = n_chunks; k < n_chunks + 2; ++k)
@@ -2041,6 +2071,65 @@ int mofreak_stream_push(mofreak_stream *s, const uint8_t *frame, int channels, i
     if (rc) return rc;
     if (host && total) HIP_TRY(ctx, hipMemcpy(rows_out, d_rows, (size_t)total * sizeof(mofreak_row), hipMemcpyDeviceToHost));
     return MOFREAK_OK;
+}
+
+int mofreak_stream_push_frames(mofreak_stream *s, const uint8_t *frames, int n_frames, int chunk_frames, const mofreak_keypoint *kps, int64_t n_kp,
+                               mofreak_row *rows_out, int64_t rows_capacity, int64_t *n_rows_out)
+{
+    if (!s || !s->ctx) return MOFREAK_ERR_BAD_ARG;
+    mofreak_ctx *ctx = s->ctx;
+    if (n_rows_out) *n_rows_out = 0;
+    if (n_frames < 0 || n_kp < 0 || rows_capacity < 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "negative count");
+    if (n_frames == 0) return MOFREAK_OK;
+    if (!frames) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null frames");
+    if (s->use_detector) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "mofreak_stream_push_frames takes a shared keypoint list; a detector stream is pushed frame by frame or handed to mofreak_compute_stream");
+    if (n_kp > 0 && !kps) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null keypoint pointer");
+    if (rows_capacity > 0 && !rows_out) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null rows_out");
+    NEED_DEVICE(ctx);
+    const int W = s->W, H = s->H, gap = ctx->params.gap_for_frame_difference, slots = gap + 1;
+    const int64_t fsz = (int64_t)W * H;
+    uint8_t *ring = static_cast<uint8_t *>(s->ring.ptr);
+    const int tail = (int)std::min<int64_t>(s->n_seen, gap);  // frames of the stream still in the device ring that new pairs look back to
+    const int64_t first_new = s->n_seen;
+    int rc = MOFREAK_OK;
+    ClipPieces pc;
+    if ((int64_t)tail + n_frames > gap && n_kp > 0) {
+        // one clip in tail + 1 pieces: the ring's frames (one slot each, oldest first), then the caller's chunk
+        std::vector<const uint8_t *> ptr;
+        std::vector<int32_t> len;
+        std::vector<uint8_t> joined;
+        std::vector<int64_t> base;
+        for (int j = 0; j < tail; ++j) {
+            ptr.push_back(ring + ((first_new - tail + j) % slots) * fsz);
+            len.push_back(1);
+        }
+        ptr.push_back(frames);
+        len.push_back(n_frames);
+        joined.assign(ptr.size(), 1);
+        joined[0] = 0;
+        base.assign(ptr.size(), first_new - tail);  // the clip's first frame is frame number first_new - tail of the stream (:401, :488)
+        pc.joined = joined.data();
+        pc.label_base = base.data();
+        rc = extract_clips_impl(ctx, ptr.data(), len.data(), (int)ptr.size(), W, H, chunk_frames, kps, n_kp, rows_out, rows_capacity, nullptr, n_rows_out, false, &pc);
+        if (rc != MOFREAK_OK && rc != MOFREAK_ERR_CAPACITY) return rc;  // (rows that do not fit: the frames are consumed all the same, like mofreak_stream_push)
+    }
+    // the stream's last gap frames into their ring slots: from the pipeline's last window where they already are on the
+    // device, else (a chunk too short for a pair, or no keypoints) from the caller's memory
+    const int keep = std::min(gap, n_frames);
+    for (int j = 0; j < keep; ++j) {
+        const int64_t idx = first_new + n_frames - keep + j;
+        uint8_t *dst = ring + (idx % slots) * fsz;
+        if (pc.last_window_slot >= 0) {
+            const int64_t q = tail + (idx - first_new);  // its place in the clip
+            const uint8_t *src = static_cast<const uint8_t *>(ctx->pipe.d_frames[pc.last_window_slot].ptr) + (q - pc.last_window_first) * fsz;
+            HIP_TRY(ctx, hipMemcpyAsync(dst, src, (size_t)fsz, hipMemcpyDeviceToDevice, ctx->stream));
+        } else {
+            HIP_TRY(ctx, hipMemcpyAsync(dst, frames + (idx - first_new) * fsz, (size_t)fsz, hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the caller may reuse its frame buffer
+    s->n_seen += n_frames;
+    return rc;
 }
 
 int mofreak_brisk_pyramid(mofreak_ctx *ctx, const uint8_t *img, int W, int H, int64_t row_stride, int octaves, uint8_t *layers_out,

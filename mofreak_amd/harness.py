@@ -301,10 +301,12 @@ def plan_batches(shard: Sequence[int], nbytes: Sequence[int], batch_bytes: int) 
     return out
 
 
-def _extract_batch(mofreak, stacks, use_batched: bool, to_device, workers: int):
+def _extract_batch(mofreak, stacks, use_batched: bool, to_device, workers: int, dest=None):
     """Rows of one batch of clips, clip after clip.  Returns (rows, n_rows, per-clip counts): rows is a uint8 CUDA tensor
-    when to_device is a device (batched mode only), else a ROW_DTYPE array.  Clips of different frame sizes are handed to
-    mofreak_extract_clips size by size (it takes one W x H per call) and their rows put back in the batch's clip order."""
+    when to_device is a device (batched mode only), else a ROW_DTYPE array -- a view of `dest` (a page-locked ROW_DTYPE
+    array with room for the batch: the rows are written where the caller keeps them) when one is given.  Clips of different
+    frame sizes are handed to mofreak_extract_clips size by size (it takes one W x H per call) and their rows put back in
+    the batch's clip order."""
     import torch
 
     if not stacks:
@@ -348,8 +350,8 @@ def _extract_batch(mofreak, stacks, use_batched: bool, to_device, workers: int):
             n_rows, offs = mofreak._ctx.extract_clips(group, kps, rows_out=buf)
         elif len(sizes) == 1:
             # the rows are wanted on this host: they travel back window by window under the pipeline's kernels, into
-            # page-locked memory kept across calls
-            buf, offs = mofreak._ctx.extract_clips(group, kps, rows_out=_pinned_rows(mofreak, cap))
+            # page-locked memory (the caller's, or a buffer kept across calls)
+            buf, offs = mofreak._ctx.extract_clips(group, kps, rows_out=dest if dest is not None else _pinned_rows(mofreak, cap))
         else:
             buf, offs = mofreak._ctx.extract_clips(group, kps)
         for k, j in enumerate(members):
@@ -365,6 +367,9 @@ def _extract_batch(mofreak, stacks, use_batched: bool, to_device, workers: int):
     ordered = [seg[j] for j in range(len(stacks))]
     if to_device is not None:
         return (torch.cat(ordered) if total else torch.empty(0, dtype=torch.uint8, device=to_device)), total, counts
+    if dest is not None:
+        np.concatenate(ordered, out=dest[:total])
+        return dest[:total], total, counts
     return np.concatenate(ordered), total, counts
 
 
@@ -388,9 +393,9 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
        bytes a 1-rank run writes; the files of a finished round are on disk before the next round starts (out_dir None:
        nothing is written).  keep_rows=False: rows are not kept after their round (with out_dir they are still
        written); without out_dir and without keep_rows nothing but the counts comes to the host.
-    Returns timings and, on rank 0 with keep_rows, `rows_per_video`: in a one-round run views into a page-locked buffer
-    that belongs to `mofreak` and is reused by its next run_dataset call (copy what has to outlive that), otherwise
-    copies.
+    Returns timings and, on rank 0 with keep_rows, `rows_per_video`: views into a page-locked buffer that belongs to
+    `mofreak` and is reused by its next run_dataset call (copy what has to outlive that); with per-frame keypoint sources
+    (no capacity known up front) and several rounds: copies.
     """
     import time
 
@@ -421,12 +426,19 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
     rows_per_video: dict[int, np.ndarray] = {}
     t_compute = t_gather = t_write = 0.0
     rows_here = total_rows = 0
+    # Rows that are kept are written where they stay: one page-locked buffer for the whole run (its size is known up front
+    # for a shared keypoint list: pairs x keypoints), filled round after round -- no copy per video.
+    keep_buf, keep_at = None, 0
+    if rank == 0 and keep_rows and use_batched:
+        gap = mofreak._ctx.params.gap_for_frame_difference
+        keep_buf = _pinned_rows(mofreak, int(sum(max(sh[0] - gap, 0) * len(prov(gap, sh[2], sh[1])) for sh in shapes)))
     for r in range(n_rounds):
         mine = plans[rank][r] if r < len(plans[rank]) else []
         round_ids = [i for p in plans if r < len(p) for i in p[r]]  # rank order, ascending inside a rank: the gathered order
         t0 = time.perf_counter()
         stacks = [np.ascontiguousarray(stack_of(videos[i])) for i in mine]
-        local, n_local, local_counts = _extract_batch(mofreak, stacks, use_batched, rows_dev, workers)
+        dest = keep_buf[keep_at:] if (keep_buf is not None and not distributed) else None
+        local, n_local, local_counts = _extract_batch(mofreak, stacks, use_batched, rows_dev, workers, dest)
         del stacks
         rows_here += n_local
         t_compute += time.perf_counter() - t0
@@ -450,7 +462,12 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
             if on_device:
                 torch.cuda.synchronize()
             if rank == 0 and want_rows:
-                if gathered.is_cuda:  # the root's one device-to-host copy, into page-locked memory kept across calls
+                if keep_buf is not None:  # the root's one copy of the round's rows, to where they stay
+                    all_rows = keep_buf[keep_at: keep_at + gathered.numel() // 32]
+                    torch.from_numpy(all_rows.view(np.uint8).reshape(-1)).copy_(gathered, non_blocking=True)
+                    if gathered.is_cuda:
+                        torch.cuda.synchronize()
+                elif gathered.is_cuda:  # ... or into page-locked memory kept across calls
                     host = _pinned_bytes(mofreak, gathered.numel())
                     host.copy_(gathered, non_blocking=True)
                     torch.cuda.synchronize()
@@ -479,7 +496,8 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
                 if out_dir is not None:
                     write_atomic(os.path.join(out_dir, names[i] + ".mofreak"), [api.format_rows(seg)])
                 if keep_rows:
-                    rows_per_video[i] = seg if n_rounds == 1 else seg.copy()
+                    rows_per_video[i] = seg if (n_rounds == 1 or keep_buf is not None) else seg.copy()
+            keep_at += len(all_rows) if keep_buf is not None else 0
             t_write += time.perf_counter() - t2
 
     out = {"compute_s": t_compute, "gather_s": t_gather, "videos_here": len(shards[rank]), "rows_here": int(rows_here),

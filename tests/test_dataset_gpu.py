@@ -69,6 +69,7 @@ def test_mixed_frame_sizes_and_bounded_rounds(oracle, tmp_path):
         one = harness.run_dataset(clips, names, str(tmp_path / "one"), mo)
         rows_one = {i: r.copy() for i, r in one["rows_per_video"].items()}
         many = harness.run_dataset(clips, names, str(tmp_path / "many"), mo, batch_bytes=12 << 20)
+        many["rows_per_video"] = {i: r.copy() for i, r in many["rows_per_video"].items()}  # (views into a buffer the next call reuses)
         quiet = harness.run_dataset(clips, names, str(tmp_path / "quiet"), mo, batch_bytes=12 << 20, keep_rows=False)
     finally:
         mo.close()

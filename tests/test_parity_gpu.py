@@ -594,6 +594,41 @@ def _clip_set(rng, W, H, lengths):
     return [np.ascontiguousarray(pool[(3 * i) % 7: (3 * i) % 7 + t]) for i, t in enumerate(lengths)]
 
 
+@pytest.mark.parametrize("pinned", [False, True])
+def test_chunk_pushes_into_a_stream_equal_the_whole_stack_call(gpu_ctx, pinned):
+    """mofreak_stream_push_frames: a stream fed in chunks of any length (shorter than the gap, one frame, hundreds; windows
+    inside a chunk that cut it in the middle; single-frame pushes in between) keeps only its last gap frames on the device
+    and yields, piece by piece, the rows of mofreak_extract_stream over the whole stack -- frame numbers running on."""
+    W, H, T = 320, 240, 131
+    frames = synth.synth_stack(T, W, H)
+    kps = synth.dense_grid(W, H, 16, 12.0, 38)
+    want = gpu_ctx.extract_stream_host(frames, kps)
+    assert len(want) == (T - 5) * len(kps)
+    src = frames
+    if pinned:
+        src = gpu_ctx.host_alloc(frames.shape)
+        src[:] = frames
+    rows_buf = gpu_ctx.host_alloc((60 * len(kps),), M.api.ROW_DTYPE) if pinned else None
+    got = []
+    with gpu_ctx.open_stream(W, H, use_detector=False) as st:
+        t = 0
+        for n, window in [(3, 0), (1, 0), (4, 0), (40, 0), (1, -1), (57, 11), (2, 0), (1, -1), (22, 7)]:
+            if window < 0:  # a frame-at-a-time push in between
+                got.append(st.push(frames[t], kps))
+            else:
+                got.append(st.push_frames(src[t:t + n], kps, chunk_frames=window, rows_out=rows_buf).copy())
+            t += n
+            assert st.frames == t
+        assert t == T
+        # a rows buffer that is too small: reported, the frames consumed all the same
+        with pytest.raises(M.MoFREAKError) as e:
+            st.push_frames(np.ascontiguousarray(frames[:9]), kps, rows_out=np.zeros(5, M.api.ROW_DTYPE))
+        assert e.value.code == M.api.ERR_CAPACITY and st.frames == T + 9
+    got = np.concatenate(got)
+    assert got.tobytes() == want.tobytes()
+    assert [len(g) for g in (got[got["frame_number"] == 4], got[got["frame_number"] == T - 2])] == [len(kps), len(kps)]
+
+
 @pytest.mark.parametrize("chunk", [0, 9, 23, 64])
 def test_clips_in_one_call_equal_one_call_per_clip(gpu_ctx, chunk):
     """mofreak_extract_clips: the dataset loop's body (main.cpp:862-921) for many videos at once.  Rows and per-clip
