@@ -230,6 +230,11 @@ int mofreak_extract_stream_pipelined(mofreak_ctx *ctx, const uint8_t *frames, in
 int mofreak_extract_clips(mofreak_ctx *ctx, const uint8_t *const *clip_frames, const int32_t *clip_n_frames, int n_clips,
                           int W, int H, int chunk_frames, const mofreak_keypoint *kps, int64_t n_kp, mofreak_row *rows_out,
                           int64_t rows_capacity, int64_t *clip_row_offsets_out, int64_t *n_rows_out, unsigned flags);
+/* Device memory for rows that stay in HBM (MOFREAK_ROWS_DEVICE; the RCCL gather of include/mofreak_dist.h) for callers that do
+ * not link the HIP runtime themselves: hipMalloc / hipFree on the context's device, and a synchronous device-to-host copy. */
+int mofreak_device_alloc(mofreak_ctx *ctx, size_t bytes, void **out);
+int mofreak_device_free(mofreak_ctx *ctx, void *ptr);
+int mofreak_copy_to_host(mofreak_ctx *ctx, void *host_dst, const void *device_src, size_t bytes);
 /* Page-locked host memory for frames decoded by the caller and for rows (hipHostMalloc / hipHostFree). */
 int mofreak_host_alloc(mofreak_ctx *ctx, size_t bytes, void **out);
 int mofreak_host_free(mofreak_ctx *ctx, void *ptr); /* ctx may be NULL: the memory may outlive its context */

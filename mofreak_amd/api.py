@@ -36,6 +36,7 @@ EXPORTS = [
     "mofreak_set_profiling", "mofreak_get_profile", "mofreak_set_path", "mofreak_get_tile_stamps", "mofreak_bgr_to_gray", "mofreak_bow_assign", "mofreak_bow_histogram",
     "mofreak_extract_pairs", "mofreak_compact_rows", "mofreak_extract_stream", "mofreak_format_rows",
     "mofreak_extract_stream_pipelined", "mofreak_extract_clips", "mofreak_host_alloc", "mofreak_host_free",
+    "mofreak_device_alloc", "mofreak_device_free", "mofreak_copy_to_host",
     "mofreak_parse_rows", "mofreak_diff_integral", "mofreak_mip19", "mofreak_roi19", "mofreak_freak_info",
     "mofreak_theta_index", "mofreak_pattern_sizes", "mofreak_scale_index", "mofreak_table_pattern",
     "mofreak_table_orientation", "mofreak_table_bit_pairs", "mofreak_table_resize", "mofreak_table_mip_positions",

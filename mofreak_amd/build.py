@@ -51,5 +51,27 @@ def build_native(force: bool = False, verbose: bool = False, debug: bool = False
     return LIB_PATH
 
 
+DIST_LIB_PATH = os.path.join(PKG_DIR, "libmofreak_dist.so")  # include/mofreak_dist.h over RCCL (host code only: no kernels of its own)
+DIST_SOURCES = ["dist_rccl.cpp"]
+DIST_HEADERS = ["dist_gather.h", os.path.join("..", "..", "include", "mofreak_dist.h"), os.path.join("..", "..", "include", "mofreak_hip.h")]
+
+
+def build_dist(force: bool = False, verbose: bool = False) -> str:
+    """libmofreak_dist.so: the N-GPU exchange step over rccl.h (links /opt/rocm's librccl and HIP runtime: it is loaded by the
+    C++ host side, never into a Python process that has torch's own copies of those libraries)."""
+    if not force and os.path.exists(DIST_LIB_PATH):
+        t = os.path.getmtime(DIST_LIB_PATH)
+        if not any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in DIST_SOURCES + DIST_HEADERS):
+            return DIST_LIB_PATH
+    rocm = os.path.dirname(os.path.dirname(hipcc()))
+    cmd = [hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-x", "c++", "-D__HIP_PLATFORM_AMD__", f"-I{rocm}/include",
+           *[os.path.join(CSRC, s) for s in DIST_SOURCES], "-o", DIST_LIB_PATH, f"-L{rocm}/lib", "-lrccl", "-lamdhip64", f"-Wl,-rpath,{rocm}/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return DIST_LIB_PATH
+
+
 if __name__ == "__main__":
     print(build_native(force=True, verbose=True))
+    print(build_dist(force=True, verbose=True))

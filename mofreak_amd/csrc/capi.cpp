@@ -985,6 +985,31 @@ static bool is_pinned_host(const void *p)
     return at.type == hipMemoryTypeHost;
 }
 
+int mofreak_device_alloc(mofreak_ctx *ctx, size_t bytes, void **out)
+{
+    if (!ctx || !out) return MOFREAK_ERR_BAD_ARG;
+    NEED_DEVICE(ctx);
+    *out = nullptr;
+    HIP_TRY(ctx, hipMalloc(out, std::max<size_t>(bytes, 256)));
+    return MOFREAK_OK;
+}
+
+int mofreak_device_free(mofreak_ctx *ctx, void *ptr)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    NEED_DEVICE(ctx);
+    if (ptr) HIP_TRY(ctx, hipFree(ptr));
+    return MOFREAK_OK;
+}
+
+int mofreak_copy_to_host(mofreak_ctx *ctx, void *host_dst, const void *device_src, size_t bytes)
+{
+    if (!ctx || (bytes > 0 && (!host_dst || !device_src))) return MOFREAK_ERR_BAD_ARG;
+    NEED_DEVICE(ctx);
+    if (bytes) HIP_TRY(ctx, hipMemcpy(host_dst, device_src, bytes, hipMemcpyDeviceToHost));
+    return MOFREAK_OK;
+}
+
 int mofreak_host_alloc(mofreak_ctx *ctx, size_t bytes, void **out)
 {
     if (!ctx || !out) return MOFREAK_ERR_BAD_ARG;

@@ -2,7 +2,10 @@
 // Reference lines cited are src/MoFREAK/MoFREAKUtilities.cpp of ChrisWhiten/MoFREAK.
 #include "MoFREAKUtilities.h"
 
+#include <sys/stat.h>
 #include <unistd.h>
+
+#include "mofreak_dist.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -238,6 +241,133 @@ void MoFREAKUtilities::computeMoFREAKFromFiles(const std::vector<std::string> &v
         batch.push_back(std::move(c));
     }
     flush();
+}
+
+void MoFREAKUtilities::computeMoFREAKFromFilesSharded(const std::vector<std::string> &video_filenames, const std::vector<std::string> &mofreak_filenames,
+                                                      mofreak_comm *comm)
+{
+    if (video_filenames.size() != mofreak_filenames.size()) throw std::runtime_error("computeMoFREAKFromFilesSharded: one output name per video");
+    if (!comm) throw std::runtime_error("computeMoFREAKFromFilesSharded: no communicator");
+    if (use_brisk_ || !provider_shared_) throw std::runtime_error("computeMoFREAKFromFilesSharded: a shared keypoint list (dense grid) is required");
+    auto dist_check = [](int rc, const char *what) {
+        if (rc != MOFREAK_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + mofreak_dist_last_error());
+    };
+    const int rank = mofreak_comm_rank(comm), world = mofreak_comm_world(comm), n = (int)video_filenames.size();
+    // the same plan on every rank: costs = file sizes, LPT shard, a rank's share cut into rounds of batch_bytes_
+    std::vector<int64_t> cost((size_t)n, 0);
+    for (int i = 0; i < n; ++i) {
+        struct stat st;
+        if (stat(video_filenames[i].c_str(), &st) == 0) cost[i] = (int64_t)st.st_size;
+    }
+    std::vector<int32_t> rank_of((size_t)n, 0);
+    dist_check(mofreak_shard_lpt(cost.data(), n, world, rank_of.data()), "mofreak_shard_lpt");
+    std::vector<std::vector<std::vector<int>>> plan((size_t)world);  // rank -> round -> videos (ascending)
+    for (int r = 0; r < world; ++r) {
+        std::vector<int> cur;
+        int64_t acc = 0;
+        for (int i = 0; i < n; ++i) {
+            if (rank_of[i] != r) continue;
+            if (!cur.empty() && acc + cost[i] > (int64_t)batch_bytes_) {
+                plan[r].push_back(cur);
+                cur.clear();
+                acc = 0;
+            }
+            cur.push_back(i);
+            acc += cost[i];
+        }
+        if (!cur.empty()) plan[r].push_back(cur);
+    }
+    size_t n_rounds = 0;
+    for (auto &p : plan) n_rounds = std::max(n_rounds, p.size());
+    mofreak_ctx *ctx = context();
+    const int gap = params_.gap_for_frame_difference;
+    struct DeviceRows {  // hipMalloc'd through the C ABI, freed on every way out
+        mofreak_ctx *ctx;
+        void *p = nullptr;
+        ~DeviceRows()
+        {
+            if (p) (void)mofreak_device_free(ctx, p);
+        }
+    };
+    for (size_t round = 0; round < n_rounds; ++round) {
+        std::vector<int> ids;  // the round's videos in gathered order: rank after rank, ascending inside a rank
+        for (int r = 0; r < world; ++r)
+            if (round < plan[r].size()) ids.insert(ids.end(), plan[r][round].begin(), plan[r][round].end());
+        const std::vector<int> mine = round < plan[rank].size() ? plan[rank][round] : std::vector<int>();
+        // my clips of the round: loaded, then run by run of one frame size through mofreak_extract_clips, rows left in HBM
+        struct Clip {
+            std::vector<uint8_t> frames;
+            int T = 0, H = 0, W = 0;
+            bool ok = false;
+        };
+        std::vector<Clip> clips(mine.size());
+        int64_t capacity = 0;
+        for (size_t k = 0; k < mine.size(); ++k) {
+            Clip &c = clips[k];
+            c.ok = load_npy_u8_3d(video_filenames[mine[k]], c.frames, c.T, c.H, c.W);
+            if (!c.ok) {
+                cout << "Could not open file: " << video_filenames[mine[k]] << endl;  // :383-386
+                continue;
+            }
+            capacity += (int64_t)std::max(c.T - gap, 0) * (int64_t)provider_(gap, c.W, c.H).size();
+        }
+        DeviceRows mine_rows{ctx}, all_rows{ctx};
+        check(ctx, mofreak_device_alloc(ctx, (size_t)std::max<int64_t>(capacity, 1) * sizeof(mofreak_row), &mine_rows.p), "mofreak_device_alloc");
+        std::vector<int64_t> count_of((size_t)mine.size(), 0);
+        int64_t n_mine = 0;
+        for (size_t k0 = 0; k0 < clips.size();) {
+            if (!clips[k0].ok) {
+                count_of[k0++] = -1;  // (no file is written for it: the sum over the ranks stays negative)
+                continue;
+            }
+            size_t k1 = k0 + 1;
+            while (k1 < clips.size() && clips[k1].ok && clips[k1].W == clips[k0].W && clips[k1].H == clips[k0].H) ++k1;
+            std::vector<const uint8_t *> ptr;
+            std::vector<int32_t> len;
+            for (size_t k = k0; k < k1; ++k) {
+                ptr.push_back(clips[k].frames.data());
+                len.push_back(clips[k].T);
+            }
+            const std::vector<mofreak_keypoint> kps = provider_(gap, clips[k0].W, clips[k0].H);
+            std::vector<int64_t> offs(ptr.size() + 1, 0);
+            int64_t got = 0;
+            check(ctx,
+                  mofreak_extract_clips(ctx, ptr.data(), len.data(), (int)ptr.size(), clips[k0].W, clips[k0].H, /*chunk_frames*/ 0, kps.data(), (int64_t)kps.size(),
+                                        static_cast<mofreak_row *>(mine_rows.p) + n_mine, capacity - n_mine, offs.data(), &got, MOFREAK_ROWS_DEVICE),
+                  "mofreak_extract_clips");
+            for (size_t k = k0; k < k1; ++k) count_of[k] = offs[k - k0 + 1] - offs[k - k0];
+            n_mine += got;
+            k0 = k1;
+        }
+        clips.clear();
+        // the exchange: per-video counts (every video belongs to one rank: the sum is its count), per-rank counts, rows
+        std::vector<int64_t> video_count(ids.size(), 0);
+        for (size_t j = 0; j < ids.size(); ++j)
+            for (size_t k = 0; k < mine.size(); ++k)
+                if (ids[j] == mine[k]) video_count[j] = count_of[k];
+        dist_check(mofreak_allreduce_sum_i64(comm, video_count.data(), (int)video_count.size()), "mofreak_allreduce_sum_i64");
+        std::vector<int64_t> rank_count((size_t)world, 0);
+        dist_check(mofreak_gather_counts(comm, n_mine, rank_count.data()), "mofreak_gather_counts");
+        int64_t total = 0;
+        for (int64_t c : rank_count) total += c;
+        if (rank == 0) check(ctx, mofreak_device_alloc(ctx, (size_t)std::max<int64_t>(total, 1) * sizeof(mofreak_row), &all_rows.p), "mofreak_device_alloc");
+        check(ctx, mofreak_synchronize(ctx), "mofreak_synchronize");  // my rows are in place before the exchange stream reads them
+        dist_check(mofreak_gather_rows(comm, static_cast<const mofreak_row *>(mine_rows.p), rank_count.data(), 0, static_cast<mofreak_row *>(all_rows.p)),
+                   "mofreak_gather_rows");
+        if (rank != 0) continue;
+        std::vector<mofreak_row> rows((size_t)std::max<int64_t>(total, 1));
+        check(ctx, mofreak_copy_to_host(ctx, rows.data(), all_rows.p, (size_t)total * sizeof(mofreak_row)), "mofreak_copy_to_host");  // the root's one copy to the host
+        int64_t at = 0;
+        for (size_t j = 0; j < ids.size(); ++j) {
+            if (video_count[j] < 0) continue;  // could not be opened on its rank
+            appendRows(rows.data() + at, video_count[j], video_filenames[ids[j]]);
+            at += video_count[j];
+            cout << "Writing this mofreak file: " << mofreak_filenames[ids[j]] << endl;
+            writeMoFREAKFeaturesToFile(mofreak_filenames[ids[j]]);
+            features.clear();
+        }
+        if (at != total) throw std::runtime_error("computeMoFREAKFromFilesSharded: gathered rows and per-video counts disagree");
+    }
 }
 
 void MoFREAKUtilities::computeMoFREAKFromFrames(const uint8_t *frames, int T, int W, int H,

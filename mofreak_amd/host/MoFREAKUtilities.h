@@ -100,6 +100,14 @@ public:
     // crash loses are bounded by the batch.  Files come out byte-identical to the loop's.
     void computeMoFREAKFromFiles(const std::vector<std::string> &video_filenames, const std::vector<std::string> &mofreak_filenames);
     void setBatchBytes(size_t bytes) { batch_bytes_ = bytes > 0 ? bytes : 1; }  // default 2 GiB of frames per batch
+    // The same over N GPUs, one process per GPU (the reference's loop is sequential): every rank calls this
+    // with the same lists and its communicator (include/mofreak_dist.h).  Videos go to ranks longest-processing-time
+    // first (file sizes); the ranks walk their shares in rounds of at most setBatchBytes() of frames: a rank's clips of a
+    // round through mofreak_extract_clips with the rows left in HBM, the per-video row counts summed over the ranks, the
+    // rows gathered to rank 0 over RCCL (ncclAllGather of the counts, grouped ncclSend / ncclRecv peer -> root), and rank 0
+    // writes the round's files -- the bytes computeMoFREAKFromFiles writes.  Dense-grid keypoints only.
+    void computeMoFREAKFromFilesSharded(const std::vector<std::string> &video_filenames, const std::vector<std::string> &mofreak_filenames,
+                                        struct mofreak_comm *comm);
 
 private:
     void readMetadata(const std::string &filename, int &action, int &video_number, int &person);

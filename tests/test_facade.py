@@ -16,6 +16,8 @@ EXE = os.path.join(HOST, "facade_main")
 
 @pytest.fixture(scope="module")
 def facade(native_lib):
+    from mofreak_amd import build
+    build.build_dist()  # facade_main links the row gather over RCCL (include/mofreak_dist.h)
     subprocess.check_call(["make", "-C", HOST, "-s"])
     return EXE
 
@@ -105,6 +107,49 @@ def test_cpp_compute_mofreak_files_layout(facade, oracle, tmp_path):
         want = oracle.Freak().extract_stream(fr, np.tile(grid, (n_pairs, 1)), offs)
         assert out.read_bytes() == oracle.format_rows(want), name
     assert (mdir / "run" / "short.npy.mofreak").read_bytes() == b""  # T <= gap: the reference writes an empty file
+
+
+@pytest.mark.gpu
+def test_cpp_ranks_over_rccl_write_the_files_of_the_plain_walk(facade, tmp_path):
+    """facade_ranks 1: the C++ route to the N-GPU run -- a launcher that loads no GPU library starts the rank process(es);
+    a rank = MoFREAKUtilities::computeMoFREAKFromFilesSharded over include/mofreak_dist.h: LPT shard, rows left in HBM,
+    ncclAllReduce of the per-video counts, ncclAllGather of the ranks' counts, grouped ncclSend / ncclRecv to rank 0 (at one
+    rank: a self exchange of 1 MiB in their place), rank 0 writes.  Rounds of a few hundred KiB; mixed frame sizes; an empty
+    clip.  The files are those of `facade_main files`, byte for byte."""
+    vdir, one, many = tmp_path / "videos", tmp_path / "one", tmp_path / "ranks"
+    (vdir / "walk").mkdir(parents=True)
+    (vdir / "run").mkdir()
+    clips = {"top.npy": synth.synth_stack(8, 160, 120, t0=1), "walk/w1.npy": synth.synth_stack(17, 160, 120, t0=20), "walk/w2.npy": synth.synth_stack(9, 208, 144, t0=5),
+             "run/r1.npy": synth.synth_stack(29, 160, 120, t0=50), "run/short.npy": synth.synth_stack(4, 160, 120, t0=70), "run/r2.npy": synth.synth_stack(12, 160, 120, t0=90)}
+    for name, fr in clips.items():
+        np.save(vdir / name, fr)
+    one.mkdir()
+    subprocess.check_call([facade, "files", str(vdir), str(one)])
+    launcher = os.path.join(os.path.dirname(facade), "facade_ranks")
+    env = dict(os.environ, MOFREAK_BATCH_BYTES=str(400_000), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    msg = subprocess.run([launcher, "1", str(vdir), str(many)], env=env, text=True, capture_output=True, timeout=300)
+    assert msg.returncode == 0, msg.stdout[-2000:] + msg.stderr[-2000:]
+    assert "ranks 1 videos 6" in msg.stdout
+    for name in clips:
+        a, b = (one / (name + ".mofreak")).read_bytes(), (many / (name + ".mofreak")).read_bytes()
+        assert a == b and (len(a) > 0 or name.endswith("short.npy")), name
+    assert not [f for f in os.listdir(many) if f.startswith(".mofreak_rccl_id")]
+
+
+def test_dist_library_exports_its_header_and_the_exchange_logic_runs_on_the_cpu():
+    """include/mofreak_dist.h: every declared function is exported by libmofreak_dist.so (looked up with nm: the library links
+    /opt/rocm's RCCL and HIP runtime and is not loaded into this Python process), and csrc/dist_gather.h -- the LPT shard and
+    the peer-to-root gather that run over RCCL on the GPUs -- passes its self-test over an in-process communicator."""
+    import re
+    from mofreak_amd import build
+    lib = build.build_dist()
+    declared = set(re.findall(r"\b(mofreak_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "mofreak_dist.h")).read()))
+    declared -= {"mofreak_amd"}
+    exported = {line.split()[-1] for line in subprocess.check_output(["nm", "-D", "--defined-only", lib], text=True).splitlines() if " T " in line}
+    assert declared and declared <= exported, sorted(declared - exported)
+    host = os.path.join(ROOT, "mofreak_amd", "host")
+    subprocess.check_call(["make", "-C", host, "-s", "dist_selftest"])
+    assert subprocess.check_output([os.path.join(host, "dist_selftest")], text=True).strip() == "ok"
 
 
 @pytest.mark.gpu
