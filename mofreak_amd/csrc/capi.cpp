@@ -302,7 +302,7 @@ int extract_device(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, co
         // A list per pair with few keypoints per tile (a detector's output: some thousand keypoints on a frame of 255 tiles)
         // would be handed to the gather path tile by tile in the binning pass: it goes there as a whole instead -- no tile
         // keys to count, scan and scatter, no tile kernel launch.  (A tile pays from about 48 keypoints up, tile_kernel.hip.)
-        const bool all_gather = d_offsets != nullptr && n_kp < (int64_t)n_pairs * tiles_x * tiles_y * 24;
+        const bool all_gather = d_offsets != nullptr && n_kp < (int64_t)n_pairs * tiles_x * tiles_y * 32;
         const int64_t n_keys = all_gather ? 0 : (int64_t)tiles_x * tiles_y * (d_offsets ? n_pairs : 1);
         const int64_t n_bkeys = (int64_t)tiles_y * (d_offsets ? n_pairs : 1);  // the gather path's keypoints are binned too: by band of rows
         if (n_keys + n_bkeys >= ((int64_t)1 << 31)) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "too many (pair, tile) bins in one call");

@@ -543,7 +543,12 @@ __global__ __launch_bounds__(kDetThreads) void det_corner_kernel(DetArgs a)
     __shared__ uint16_t list[kDetTileH * kDetTileW];
     __shared__ unsigned long long row_mask[kDetTileH];
     __shared__ int n_list;
-    const int p = blockIdx.y, t = blockIdx.x;
+    // Workgroups go to the eight XCDs in turn (each with an L2 of its own): an XCD takes a contiguous eighth of the pair's
+    // tile list, so that neighbouring tiles -- which share their halo's cache lines -- meet in one L2 (the grid's x extent
+    // is a multiple of 8: launch_det_corners).
+    const int p = blockIdx.y, n_tiles = a.g.tile_start[a.g.n_layers], per_xcd = (n_tiles + 7) / 8;
+    const int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (t >= min(n_tiles, (int)((blockIdx.x & 7) + 1) * per_xcd)) return;
     int layer = 0;  // from the argument block's copy of the geometry with constant indices: scalar compares, no memory
 #pragma unroll
     for (int k = 1; k < kDetMaxLayers; ++k) layer += (k < a.g.n_layers && t >= a.g.tile_start[k]) ? 1 : 0;
@@ -911,16 +916,17 @@ __device__ __forceinline__ int window_at(const PairView &v, Window &w, int x, in
 
 // The cells a walk asked for in the layer above: their true scores go into that layer's score plane right away (a
 // cell's score is what it is, whoever computes it and whenever; nobody reads a cell below the threshold unless a touch or
-// status byte says the reference would have cached it) ...
+// status byte says the reference would have cached it).  The window's rows go out whole -- four scores per row, one
+// unaligned 4-byte store -- for every row the walk asked a cell of: the cells beside the asked ones get their true scores
+// too, which nobody minds (cells outside the scored region hold 0 in the window and in the plane).
 __device__ __forceinline__ void publish_scores(const PairView &v, const Window &w)
 {
     const DetLayer &L = v.g->L[w.layer];
-    unsigned long long asked = w.asked;
-    while (asked) {
-        const int k = __ffsll((long long)asked) - 1;
-        asked &= asked - 1;
-        const int iy = k / kWinSide, ix = k % kWinSide;
-        v.score_rw[L.off + (int64_t)(w.oy + iy) * L.w + w.ox + ix] = w.cells[iy * kWinRow + ix];
+#pragma unroll
+    for (int iy = 0; iy < kWinCells - 1; ++iy) {  // (windows above are 4 x 4)
+        if (!((w.asked >> (iy * kWinSide)) & 0x3f)) continue;
+        const uint32_t row = *reinterpret_cast<const uint32_t *>(w.cells + iy * kWinRow);
+        __builtin_memcpy(v.score_rw + L.off + (int64_t)(w.oy + iy) * L.w + w.ox, &row, 4);
     }
 }
 
@@ -2001,9 +2007,9 @@ int launch_det_scores(const DetArgs &a, void *stream)
 
 int launch_det_corners(const DetArgs &a, void *stream)
 {
-    const int tiles = a.g.tile_start[a.g.n_layers];  // every layer's tiles in one launch
+    const int tiles = a.g.tile_start[a.g.n_layers];  // every layer's tiles in one launch, an eighth of the list per XCD
     if (tiles > 0 && a.n_pairs > 0)
-        hipLaunchKernelGGL(det_corner_kernel, dim3(tiles, a.n_pairs), dim3(kDetThreads), 0, static_cast<hipStream_t>(stream), a);
+        hipLaunchKernelGGL(det_corner_kernel, dim3(((tiles + 7) / 8) * 8, a.n_pairs), dim3(kDetThreads), 0, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 
