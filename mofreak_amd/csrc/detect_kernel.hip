@@ -75,6 +75,13 @@ __device__ __forceinline__ PairView pair_view(const DetArgs &a, int p)
     return v;
 }
 
+// the batch's geometry into LDS (a per-thread layer index into the device copy is a memory round trip per field)
+__device__ __forceinline__ void geom_to_lds(DetGeom *dst, const DetGeom *src)
+{
+    static_assert(sizeof(DetGeom) % 4 == 0, "copied as dwords");
+    for (int i = threadIdx.x; i < (int)(sizeof(DetGeom) / 4); i += blockDim.x) reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
+}
+
 __device__ __forceinline__ int avg_u8(int a, int b) { return (a + b + 1) >> 1; }  // _mm_avg_epu8
 
 __device__ __forceinline__ unsigned long long load8(const uint8_t *p)
@@ -1419,7 +1426,7 @@ __device__ __forceinline__ void finish_candidate(const DetArgs &a, const PairVie
         a.cand_spec[ci] = (uint8_t)(kWasTie | (r.emit ? kEmit : 0) | (r.reached ? kReached : 0));
     } else {
         a.cand_emit[ci] = r.emit ? 1 : 0;
-        const DetLayer &L = a.dg->L[layer];
+        const DetLayer &L = v.g->L[layer];
         v.status[L.off + (int64_t)y * L.w + x] = r.reached ? kStReached : kStDone;
         if (r.asked) apply_asked(v, layer + 1, r.ox, r.oy, r.asked);
     }
@@ -1458,11 +1465,13 @@ __device__ __forceinline__ void window_scores(const Patch &q, const DetLayer &L,
 __global__ __launch_bounds__(kDetThreads) void det_window_kernel(DetArgs a)
 {
     __shared__ int todo[kRefineChunk], wave_cnt[8], n_todo, ls_s[kDetMaxLayers + 1];
+    __shared__ DetGeom geom_s;
     const int p = blockIdx.y, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
     const int n_layers = a.dg->n_layers, n = ls[n_layers], c0 = blockIdx.x * kRefineChunk;
     if (c0 >= n) return;
     if (threadIdx.x <= kDetMaxLayers) ls_s[threadIdx.x] = (int)threadIdx.x <= n_layers ? ls[threadIdx.x] : 0x7fffffff;
+    geom_to_lds(&geom_s, a.dg);
     const int64_t cb = (int64_t)p * a.cand_cap;
     {  // the chunk's walkers, in candidate order: both halves of the chunk in one go
         static_assert(kRefineChunk == 2 * kDetThreads, "a thread takes two candidates of the chunk");
@@ -1494,7 +1503,8 @@ __global__ __launch_bounds__(kDetThreads) void det_window_kernel(DetArgs a)
     }
     const int nt = n_todo;
     if (threadIdx.x == 0) a.walk_count[(int64_t)p * a.walk_chunks + blockIdx.x] = nt;
-    const PairView v = pair_view(a, p);
+    PairView v = pair_view(a, p);
+    v.g = &geom_s;
     const bool single = n_layers == 1;
     for (int it = threadIdx.x; it < 3 * nt; it += kDetThreads) {
         const int part = it / nt, k = it - part * nt;  // part-major: a wave's threads mostly share the window kind
@@ -1552,15 +1562,18 @@ __global__ __launch_bounds__(kDetThreads) void det_walk_kernel(DetArgs a)
 {
     __shared__ __attribute__((aligned(4))) uint8_t windows[kDetThreads * kWinStride];
     __shared__ int ls_s[kDetMaxLayers + 1];
+    __shared__ DetGeom geom_s;
     const int p = blockIdx.y, c0 = blockIdx.x * kRefineChunk;
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
     const int n_layers = a.dg->n_layers, n = ls[n_layers];
     if (c0 >= n) return;
     if (threadIdx.x <= kDetMaxLayers) ls_s[threadIdx.x] = (int)threadIdx.x <= n_layers ? ls[threadIdx.x] : 0x7fffffff;
+    geom_to_lds(&geom_s, a.dg);
     __syncthreads();
     const int nt = a.walk_count[(int64_t)p * a.walk_chunks + blockIdx.x];
     const int64_t cb = (int64_t)p * a.cand_cap;
-    const PairView v = pair_view(a, p);
+    PairView v = pair_view(a, p);
+    v.g = &geom_s;
     uint8_t *cells = windows + threadIdx.x * kWinStride;
     for (int k = threadIdx.x; k < nt; k += kDetThreads) {
         const int i = a.walk_list[cb + c0 + k];
