@@ -45,6 +45,15 @@ struct mofreak_ctx {
     DeviceBuffer det_img, det_score, det_touch, det_status, det_rows, det_cand_xy, det_cand_flag, det_cand_emit, det_cand_spec, det_cand_asked, det_cand_win, det_cand_res, det_layer_start,
         det_emit_count, det_emit_chunks, det_geom, det_emit_offsets, det_out_kps, det_out_offsets, det_out_resp, det_out_layer, det_planes_out, det_hit_mask, det_walk_list, det_walk_count, det_cand_cells;
     bool det_maps_dirty = false;  // a detector call stopped half way: its touch / status bytes may still be set
+    // |cur - prev| of the pairs of the last mofreak_detect_pairs call, as the detector left it (layer 0 of its planes) --
+    // valid while that call had ONE batch; mofreak_compute_stream lets the gather path's integral read it instead of
+    // both frames (use_det_diff, for the extract that follows the detector on the same pairs)
+    struct DetDiff {
+        const uint8_t *base = nullptr;
+        int64_t pair_stride = 0;
+        int W = 0, H = 0, pairs = 0;
+    } det_diff;
+    bool use_det_diff = false;
     int det_cand_cap = 131072;
     size_t det_counter_bytes = 0;  // row counts + tie counters behind the running total in det_rows
     int64_t det_kp_capacity = 0;
@@ -188,6 +197,13 @@ int run_integral(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *prev, cons
     a.f.H = g.H;
     a.f.row_stride = g.row_stride;
     a.f.pair_stride = g.pair_stride;
+    if (ctx->use_det_diff && ctx->det_diff.base && ctx->det_diff.W == g.W && ctx->det_diff.H == g.H && p0 + np <= ctx->det_diff.pairs) {
+        // the frame loop: the detector has left |cur - prev| of these very pairs in HBM: one byte per pixel to read instead of two
+        a.f.cur = ctx->det_diff.base + (int64_t)p0 * ctx->det_diff.pair_stride;
+        a.f.prev = nullptr;
+        a.f.row_stride = g.W;
+        a.f.pair_stride = ctx->det_diff.pair_stride;
+    }
     a.integral = static_cast<int32_t *>(ctx->integral.ptr);
     a.band_totals = static_cast<int32_t *>(ctx->band_totals.ptr);
     a.pitch = pitch;
@@ -1870,6 +1886,8 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
     a.out_capacity = capacity;
     a.out_offsets = d_off;
     ctx->det_maps_dirty = true;  // until the call has run to its end (every early return below leaves it set)
+    ctx->det_diff = mofreak_ctx::DetDiff{};
+    if (d_prev && n_pairs <= batch) ctx->det_diff = mofreak_ctx::DetDiff{a.img + g.L[0].off, g.plane_bytes, W, H, n_pairs};
     for (int p0 = 0; p0 < n_pairs; p0 += batch) {
         const int np = std::min(batch, n_pairs - p0);
         a.n_pairs = np;
@@ -1938,30 +1956,69 @@ int mofreak_compute_stream(mofreak_ctx *ctx, const uint8_t *frames, int T, int W
         if ((rc = ensure(ctx, ctx->stage[5], (size_t)std::max<int64_t>(rows_capacity, 1) * sizeof(mofreak_row)))) return rc;
         d_rows = static_cast<mofreak_row *>(ctx->stage[5].ptr);
     }
-    // keypoints: room for what the last call needed (at least 4096 per pair), grown once if this stream has more
-    int64_t n_kp = 0;
-    for (int attempt = 0;; ++attempt) {
-        const int64_t cap = std::max<int64_t>(ctx->det_kp_capacity, (int64_t)4096 * n_pairs);
-        if ((rc = ensure(ctx, ctx->det_out_kps, (size_t)cap * sizeof(mofreak_keypoint)))) return rc;
-        if ((rc = ensure(ctx, ctx->det_out_offsets, (size_t)(n_pairs + 1) * sizeof(int64_t)))) return rc;
-        rc = mofreak_detect_pairs(ctx, d_frames + (int64_t)gap * fsz, d_frames, W, H, W, fsz, n_pairs, threshold, octaves,
-                                  static_cast<mofreak_keypoint *>(ctx->det_out_kps.ptr), cap, static_cast<int64_t *>(ctx->det_out_offsets.ptr),
-                                  nullptr, nullptr, &n_kp, MOFREAK_MEM_DEVICE);
-        if (rc == MOFREAK_ERR_CAPACITY && n_kp > cap && attempt == 0) {
-            ctx->det_kp_capacity = n_kp + n_kp / 8;
+    // The stack in detector batches (as many pairs as its workspace takes at once: a few hundred full-HD pairs): detector,
+    // then the descriptors of the batch's keypoints -- their integral images read |cur - prev| where the detector has just
+    // left it -- then the batch's rows behind those of the batches before.
+    DetGeom g;
+    if ((rc = det_geometry(ctx, W, H, octaves, g))) return rc;
+    const int batch = det_batch(ctx, g, n_pairs);
+    const Geometry geo{W, H, W, fsz};
+    int64_t total_rows = 0, total_kp = 0;
+    bool rows_overflow = false;
+    struct DiffScope {  // the planes are this call's: no later extract may take them for its own pairs' difference images
+        mofreak_ctx *c;
+        ~DiffScope()
+        {
+            c->use_det_diff = false;
+            c->det_diff = mofreak_ctx::DetDiff{};
+        }
+    } scope{ctx};
+    for (int p0 = 0; p0 < n_pairs; p0 += batch) {
+        const int np = std::min(batch, n_pairs - p0);
+        const uint8_t *cur = d_frames + (int64_t)(gap + p0) * fsz, *prev = d_frames + (int64_t)p0 * fsz;
+        // keypoints: room for what the last call needed (at least 4096 per pair), grown once if this stream has more
+        int64_t n_kp = 0;
+        for (int attempt = 0;; ++attempt) {
+            const int64_t cap = std::max<int64_t>(ctx->det_kp_capacity, (int64_t)4096 * np);
+            if ((rc = ensure(ctx, ctx->det_out_kps, (size_t)cap * sizeof(mofreak_keypoint)))) return rc;
+            if ((rc = ensure(ctx, ctx->det_out_offsets, (size_t)(np + 1) * sizeof(int64_t)))) return rc;
+            rc = mofreak_detect_pairs(ctx, cur, prev, W, H, W, fsz, np, threshold, octaves, static_cast<mofreak_keypoint *>(ctx->det_out_kps.ptr), cap,
+                                      static_cast<int64_t *>(ctx->det_out_offsets.ptr), nullptr, nullptr, &n_kp, MOFREAK_MEM_DEVICE);
+            if (rc == MOFREAK_ERR_CAPACITY && n_kp > cap && attempt == 0) {
+                ctx->det_kp_capacity = n_kp + n_kp / 8;
+                continue;
+            }
+            if (rc) return rc;
+            break;
+        }
+        total_kp += n_kp;
+        if (n_keypoints_out) *n_keypoints_out = total_kp;
+        if (n_kp == 0) continue;
+        const mofreak_keypoint *kps = static_cast<const mofreak_keypoint *>(ctx->det_out_kps.ptr);
+        const int64_t *d_off = static_cast<const int64_t *>(ctx->det_out_offsets.ptr);
+        std::vector<int64_t> h_off;
+        if ((rc = fetch_offsets(ctx, d_off, np, false, h_off))) return rc;
+        if ((rc = ensure(ctx, ctx->scratch_desc, (size_t)n_kp * 16))) return rc;
+        if ((rc = ensure(ctx, ctx->scratch_valid, (size_t)n_kp))) return rc;
+        uint8_t *desc = static_cast<uint8_t *>(ctx->scratch_desc.ptr), *valid = static_cast<uint8_t *>(ctx->scratch_valid.ptr);
+        ctx->use_det_diff = true;
+        rc = extract_device(ctx, cur, prev, geo, np, kps, d_off, h_off.data(), n_kp, desc, valid, nullptr, nullptr);
+        ctx->use_det_diff = false;
+        if (rc) return rc;
+        int64_t got = 0;
+        const int64_t room = rows_overflow ? 0 : rows_capacity - total_rows;
+        // pair p of the batch is frame gap + p0 + p of the stack: labelled gap - 1 + p0 + p (:401, :488)
+        rc = compact_device(ctx, kps, d_off, n_kp, np, n_kp, gap - 1 + p0, desc, valid, d_rows + (rows_overflow ? 0 : total_rows), room, &got);
+        total_rows += got;
+        if (n_rows_out) *n_rows_out = total_rows;
+        if (rc == MOFREAK_ERR_CAPACITY) {
+            rows_overflow = true;  // no further row leaves the kernels; the counting goes on: the caller learns the size a retry needs
             continue;
         }
         if (rc) return rc;
-        break;
     }
-    if (n_keypoints_out) *n_keypoints_out = n_kp;
-    if (n_kp == 0) return MOFREAK_OK;
-    int64_t total = 0;
-    rc = mofreak_extract_stream(ctx, d_frames, T, W, H, static_cast<const mofreak_keypoint *>(ctx->det_out_kps.ptr),
-                                static_cast<const int64_t *>(ctx->det_out_offsets.ptr), n_kp, d_rows, rows_capacity, &total, MOFREAK_MEM_DEVICE);
-    if (n_rows_out) *n_rows_out = total;
-    if (rc) return rc;
-    if (host && total) HIP_TRY(ctx, hipMemcpy(rows_out, d_rows, (size_t)total * sizeof(mofreak_row), hipMemcpyDeviceToHost));
+    if (rows_overflow) return fail(ctx, MOFREAK_ERR_CAPACITY, "rows_out too small: need " + std::to_string(total_rows));
+    if (host && total_rows) HIP_TRY(ctx, hipMemcpy(rows_out, d_rows, (size_t)total_rows * sizeof(mofreak_row), hipMemcpyDeviceToHost));
     return MOFREAK_OK;
 }
 

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void band_kernel(IntegralArgs a)
     const int W = a.f.W, pitch = a.pitch;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();  // the wave index: the same in every lane, a scalar
     const uint8_t *cur = a.f.cur + (int64_t)pair * a.f.pair_stride;
-    const uint8_t *prev = a.f.prev + (int64_t)pair * a.f.pair_stride;
+    const uint8_t *prev = a.f.prev ? a.f.prev + (int64_t)pair * a.f.pair_stride : nullptr;  // null: `cur` already is the difference image
     const int64_t bt = ((int64_t)pair * a.n_bands + band) * pitch;
     int32_t *integ = a.integral + (int64_t)pair * (a.f.H + 1) * pitch;
     // a band = kBandGroup slabs of kBandRows rows, one after the other through the same LDS buffer, the running column
@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void band_kernel(IntegralArgs a)
 
     for (int r = wave; r < rows; r += 4) {
         const uint8_t *c = cur + (int64_t)(y0 + r) * a.f.row_stride;
-        const uint8_t *p = prev + (int64_t)(y0 + r) * a.f.row_stride;
+        const uint8_t *p = prev ? prev + (int64_t)(y0 + r) * a.f.row_stride : c;  // (without a previous frame: an address that is there; its bytes are not used)
+        const bool diff_given = prev == nullptr;
         int32_t *out = rp + r * pitch;
         if (lane < 4) out[lane] = 0;  // physical columns 0..3; column 3 is logical column 0
         const bool aligned = (((uintptr_t)c | (uintptr_t)p) & 3) == 0;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void band_kernel(IntegralArgs a)
                 const bool fast = aligned && x + 3 < W;
                 const int xs = fast ? x : 0;  // an address that is always there; the slow lanes fill in below
                 uint32_t cv = aligned ? *reinterpret_cast<const uint32_t *>(c + xs) : 0u;
-                uint32_t pv = aligned ? *reinterpret_cast<const uint32_t *>(p + xs) : 0u;
+                uint32_t pv = aligned && !diff_given ? *reinterpret_cast<const uint32_t *>(p + xs) : 0u;
                 if (!fast) {
                     cv = 0;
                     pv = 0;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void band_kernel(IntegralArgs a)
                         }
                 }
                 cvv[u] = cv;
-                pvv[u] = pv;
+                pvv[u] = diff_given ? 0u : pv;
             }
 #pragma unroll
             for (int u = 0; u < kPre; ++u) {

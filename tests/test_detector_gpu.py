@@ -161,6 +161,26 @@ def test_frame_loop_grows_its_keypoint_buffers(ctx):
     assert len(got) > 17 * 8192 and got.tobytes() == plain.tobytes()
 
 
+def test_frame_loop_in_several_detector_batches(ctx):
+    """mofreak_compute_stream walks a stack in detector batches (as many pairs as the detector's workspace takes at once);
+    with 4 M candidates reserved per pair a batch is a dozen pairs: four batches here, frame numbers and rows running on,
+    each batch's integral images read from the difference planes the detector has just left.  Same rows as the three calls."""
+    T, W, H = 40, 160, 120
+    fr = synth.moving_objects_stack(T, W, H, seed=9)
+    kps_d, offs_d, _, _ = ctx.detect_pairs_host(fr[5:], fr[:-5])
+    plain = ctx.extract_stream_host(fr, kps_d, kp_offsets=offs_d)
+    ctx.set_detect_capacity(1 << 22)
+    try:
+        got = ctx.compute_stream_host(fr)
+        with pytest.raises(M.MoFREAKError) as e:  # a rows buffer that is too small: the size a retry needs comes back
+            n_rows, n_kp = ctx.compute_stream(fr, T, W, H, np.zeros(10, M.api.ROW_DTYPE), capacity=10)
+        assert e.value.code == M.api.ERR_CAPACITY and str(len(plain)) in str(e.value)
+    finally:
+        ctx.set_detect_capacity(131072)
+    assert len(got) > 200 and got.tobytes() == plain.tobytes()
+    assert len(set(got["frame_number"].tolist())) > 20  # rows from every batch
+
+
 def test_rows_wider_than_one_chunk(ctx):
     """Layer rows longer than the 2048 pixels the candidate kernel takes per chunk (and than one pyramid block row):
     keypoints next to the chunk boundary see their neighbours across it."""
