@@ -1716,8 +1716,8 @@ __device__ __forceinline__ void tie_apply(const DetArgs &a, const PairView &v, c
     }
 }
 
-// The ties of one layer: one workgroup per pair, one launch per layer (a layer reads what the maxima of the layer below
-// asked for in it).  (1) The layer's ties are picked out of its candidates into an LDS list.  (2) First sight: every tie
+// The ties of a pair: one workgroup per pair, layer after layer (a layer reads what the maxima of the layer below asked for
+// in it), for each layer:  (1) The layer's ties are picked out of its candidates into an LDS list.  (2) First sight: every tie
 // looks at its neighbourhood once; the ones that are ready -- the great majority -- decide and publish on the spot (a
 // ready tie depends on no tie that is still pending, so two of them never need each other's outcome, and a status byte
 // changes once, from pending to final: whoever reads the old value merely waits); the others go on the waiting list.
@@ -1732,15 +1732,21 @@ constexpr int kTieListCap = 64, kDetWaitCap = 8;  // the debug build overflows b
 constexpr int kTieListCap = 6144, kDetWaitCap = 4096;  // ties / waiting ties per pair and layer held in LDS lists (more: the candidates are scanned instead)
 #endif
 
-__global__ __launch_bounds__(kTieThreads) void det_tie_kernel(DetArgs a, int layer)
+__global__ __launch_bounds__(kTieThreads) void det_tie_kernel(DetArgs a)
 {
-    __shared__ int tie_idx[kTieListCap], wait_idx[kDetWaitCap], n_ties_s, n_wait_s;
+    __shared__ int tie_idx[kTieListCap], wait_idx[kDetWaitCap], n_ties_s, n_wait_s, ls_s[kDetMaxLayers + 1];
     const int p = blockIdx.x, lane = threadIdx.x & 63;
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
-    const int lo = ls[layer], hi = ls[layer + 1];
-    if (hi <= lo) return;
+    const int n_layers = a.dg->n_layers;
+    if (threadIdx.x <= kDetMaxLayers) ls_s[threadIdx.x] = (int)threadIdx.x <= n_layers ? ls[threadIdx.x] : 0;
     const PairView v = pair_view(a, p);
     const int64_t cb = (int64_t)p * a.cand_cap;
+    // layer after layer in one launch: a layer reads what the maxima of the layer below -- its ties included -- asked for in
+    // it, and this workgroup is the only one that works on the pair
+    for (int layer = 0; layer < n_layers; ++layer) {
+    __syncthreads();  // the layer below is through (its threads' last decisions included); the lists are free again
+    const int lo = ls_s[layer], hi = ls_s[layer + 1];
+    if (hi <= lo) continue;
     const DetLayer L = a.dg->L[layer];
     if (threadIdx.x == 0) {
         n_ties_s = 0;
@@ -1797,7 +1803,7 @@ __global__ __launch_bounds__(kTieThreads) void det_tie_kernel(DetArgs a, int lay
     __syncthreads();
     // (3) chains
     const int n_wait = n_wait_s;
-    if (n_wait == 0) return;
+    if (n_wait == 0) continue;
     const bool listed = n_wait <= kDetWaitCap;  // list overflow: every candidate of the layer
     const int n_items = listed ? n_wait : hi - lo;
     // a thread's first tie stays in registers between passes (there are rarely more than a few hundred per pair and
@@ -1838,6 +1844,7 @@ __global__ __launch_bounds__(kTieThreads) void det_tie_kernel(DetArgs a, int lay
             atomicOr(a.status_word, 32);
             break;
         }
+    }
     }
 }
 
@@ -2038,7 +2045,7 @@ int launch_det_keypoints(const DetArgs &a, int64_t *running, void *stream)
     else
         hipLaunchKernelGGL(det_walk_kernel<false>, rgrid, dim3(kDetThreads), 0, s, a);
     // ties: layer by layer (a layer's ties read what the maxima of the layer below asked for in it)
-    for (int l = 0; l < a.g.n_layers; ++l) hipLaunchKernelGGL(det_tie_kernel, dim3(a.n_pairs), dim3(kTieThreads), 0, s, a, l);
+    hipLaunchKernelGGL(det_tie_kernel, dim3(a.n_pairs), dim3(kTieThreads), 0, s, a);  // every layer's ties, layer after layer
     const dim3 egrid((a.cand_cap + kEmitChunk - 1) / kEmitChunk, a.n_pairs);
     hipLaunchKernelGGL(det_emit_count_kernel, egrid, dim3(kDetThreads), 0, s, a);
     hipLaunchKernelGGL(det_emit_scan_kernel, dim3(1), dim3(kDetThreads), 0, s, a, running);
