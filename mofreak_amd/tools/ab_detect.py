@@ -56,7 +56,7 @@ def build(name, flags, patch=None):
     print(out)
 
 
-def run(libs, pairs, describe=False):
+def run(libs, pairs, describe=""):
     os.chdir(ROOT)
     env0 = dict(os.environ, TMPDIR="/tmp")
     for lib in libs:
@@ -66,7 +66,7 @@ def run(libs, pairs, describe=False):
         os.makedirs(out, exist_ok=True)
         env = dict(env0, MOFREAK_HIP_LIBRARY=os.path.abspath(lib))
         log = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "--", "python3",
-                              "mofreak_amd/tools/detector_probe.py", str(pairs), "6", *(["describe"] if describe else [])], env=env, capture_output=True,
+                              "mofreak_amd/tools/detector_probe.py", str(pairs), "6", *([describe] if describe else [])], env=env, capture_output=True,
                              text=True, timeout=300)
         probe = [ln for ln in log.stdout.splitlines() if ln.startswith("pairs=")]
         stats = glob.glob(os.path.join(out, "**", "*kernel_stats.csv"), recursive=True)
@@ -78,7 +78,7 @@ def run(libs, pairs, describe=False):
                     per[m.group(1)] = per.get(m.group(1), 0.0) + float(r["TotalDurationNs"]) / 7e3  # 1 warm-up + 6 calls; microseconds per call
         total = sum(per.values())
         print(f"{name}: {' '.join(probe) or log.stderr[-300:]}")
-        print("   " + "  ".join(f"{k[4:].replace('_kernel', '')} {v:.0f}" for k, v in sorted(per.items(), key=lambda kv: -kv[1])) + f"  | sum {total:.0f} us/call", flush=True)
+        print("   " + "  ".join(f"{k.replace('det_', '').replace('_kernel', '')} {v:.0f}" for k, v in sorted(per.items(), key=lambda kv: -kv[1])) + f"  | sum {total:.0f} us/call", flush=True)
         subprocess.call(["rm", "-rf", out])
 
 
@@ -93,7 +93,7 @@ if __name__ == "__main__":
         if len(a) > 1 and a[1].isdigit():
             pairs = int(a[1])
             a = a[1:]
-        describe = len(a) > 1 and a[1] == "describe"  # the descriptors of the detector's keypoints behind it
+        describe = a[1] if len(a) > 1 and a[1] in ("describe", "loop") else ""  # the descriptors behind the detector / the whole frame loop
         run(a[2 if describe else 1:], pairs, describe)
     else:
         raise SystemExit(__doc__)
