@@ -1,17 +1,33 @@
-#!/bin/bash
-# One GPU-box session: the -m gpu tests, then the bench lines of every BASELINE workload (each line into gpurun_out/r3/).
-# Steps are joined so that nothing runs after a step that timed out or failed.
 set -x
 cd "${GRAFT_REPO_ROOT:-.}"
-mkdir -p gpurun_out/r3
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r3/gpu_tests.log 2>&1; rc=$?
-tail -5 gpurun_out/r3/gpu_tests.log
-[ $rc -eq 0 ] || exit $rc
-timeout -k 10 300 python bench.py > gpurun_out/r3/bench_n1.json 2> gpurun_out/r3/bench_n1.err &&
-timeout -k 10 300 python bench.py --gpus 2 --backend gloo --share-device --pairs 64 > gpurun_out/r3/bench_n2.json 2> gpurun_out/r3/bench_n2.err &&
-timeout -k 10 300 python bench.py --config C2 --no-detector > gpurun_out/r3/bench_c2.json 2> gpurun_out/r3/bench_c2.err &&
-timeout -k 10 300 python bench.py --config C4 --steps 3 > gpurun_out/r3/bench_c4.json 2> gpurun_out/r3/bench_c4.err &&
-timeout -k 10 300 python bench.py --config C4 --steps 3 --per-clip-calls > gpurun_out/r3/bench_c4_perclip.json 2> gpurun_out/r3/bench_c4_perclip.err &&
-timeout -k 10 300 python bench.py --config C4 --gpus 2 --backend gloo --share-device > gpurun_out/r3/bench_c4_n2.json 2> gpurun_out/r3/bench_c4_n2.err &&
-timeout -k 10 300 python bench.py --config C5 --stream > gpurun_out/r3/bench_c5.json 2> gpurun_out/r3/bench_c5.err
-echo "benches rc=$?"
+mkdir -p gpurun_out/r4
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout -k 10 600 bash mofreak_amd/tools/profile_detector.sh r04 > gpurun_out/r4/final_profile_detector.log 2>&1; echo det prof rc=$?
+timeout -k 10 250 python bench.py --no-detector --no-cpu-baseline --steps 50 > gpurun_out/r4/final_bench_counters.json 2> /dev/null; echo rc=$?
+timeout -k 10 250 python bench.py --gpus 1 --backend nccl --force-dist --steps 20 > gpurun_out/r4/final_bench_nccl_n1.json 2> gpurun_out/r4/final_bench_nccl_n1.err; echo rc=$?
+timeout -k 10 250 python bench.py --gpus 2 --backend gloo --share-device --pairs 64 > gpurun_out/r4/final_bench_n2.json 2> gpurun_out/r4/final_bench_n2.err; echo rc=$?
+timeout -k 10 250 python bench.py --config C2 --no-detector > gpurun_out/r4/final_bench_c2.json 2> /dev/null; echo rc=$?
+timeout -k 10 250 python bench.py --config C4 --steps 3 > gpurun_out/r4/final_bench_c4.json 2> /dev/null; echo rc=$?
+timeout -k 10 250 python bench.py --config C4 --clips 6766 --steps 1 > gpurun_out/r4/final_bench_c4_6766.json 2> /dev/null; echo rc=$?
+timeout -k 10 250 python bench.py --config C4 --gpus 2 --backend gloo --share-device > gpurun_out/r4/final_bench_c4_n2.json 2> /dev/null; echo rc=$?
+timeout -k 10 250 python bench.py --config C4 --gpus 1 --backend nccl --force-dist --steps 3 > gpurun_out/r4/final_bench_c4_nccl_n1.json 2> /dev/null; echo rc=$?
+timeout -k 10 250 python bench.py --config C5 > gpurun_out/r4/final_bench_c5.json 2> /dev/null; echo rc=$?
+timeout -k 10 300 python bench.py --config C5 --frames 90000 > gpurun_out/r4/final_bench_c5_90000.json 2> /dev/null; echo rc=$?
+for set in FETCH_SIZE WRITE_SIZE; do timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/r4/c2pmc_$set -- python3 bench.py --config C2 --steps 2 --warmup 1 --no-cpu-baseline --no-detector > /dev/null 2>&1; done
+python3 - <<'PY'
+import csv, glob, collections
+tot = collections.defaultdict(list)
+for f in glob.glob('gpurun_out/r4/c2pmc_*/*/*counter_collection.csv'):
+    per = collections.defaultdict(float)
+    for r in csv.DictReader(open(f)):
+        if 'tile_kernel' in r['Kernel_Name']:
+            per[(r['Dispatch_Id'], r['Counter_Name'])] += float(r['Counter_Value'])
+    for (d, c), v in per.items():
+        tot[c].append(v)
+avg = {k: sum(v) / len(v) for k, v in tot.items()}
+b_alg = (2 * 640 * 480 + 28 * 875) * 1000
+traffic = (2 * avg.get('FETCH_SIZE', 0) + avg.get('WRITE_SIZE', 0)) * 1024
+open('gpurun_out/r4/final_c2_traffic.txt', 'w').write(f"C2 (1000 pairs 640x480, 875 keypoints): tile_kernel FETCH_SIZE {avg.get('FETCH_SIZE', 0):.0f} KB, WRITE_SIZE {avg.get('WRITE_SIZE', 0):.0f} KB per launch -> (2 F + W) * 1024 = {traffic / 1e6:.1f} MB = {traffic / b_alg:.3f} x the algorithmic {b_alg / 1e6:.1f} MB\n")
+print(open('gpurun_out/r4/final_c2_traffic.txt').read())
+PY
+rm -rf gpurun_out/r4/c2pmc_*
