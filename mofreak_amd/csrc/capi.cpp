@@ -43,8 +43,10 @@ struct mofreak_ctx {
     DeviceBuffer bow_counts, bow_expanded, pair_label;
     // keypoint detector workspace
     DeviceBuffer det_img, det_score, det_touch, det_status, det_rows, det_cand_xy, det_cand_flag, det_cand_emit, det_cand_spec, det_cand_asked, det_cand_win, det_cand_res, det_layer_start,
-        det_emit_count, det_emit_chunks, det_geom, det_emit_offsets, det_out_kps, det_out_offsets, det_out_resp, det_out_layer, det_planes_out, det_hit_mask, det_walk_list, det_walk_count, det_cand_cells;
+        det_emit_count, det_emit_chunks, det_geom, det_emit_offsets, det_out_kps, det_out_offsets, det_out_resp, det_out_layer, det_planes_out, det_hit_mask, det_walk_list, det_walk_count, det_cand_cells, det_tie_list, det_tie_count;
     bool det_maps_dirty = false;  // a detector call stopped half way: its touch / status bytes may still be set
+    DetGeom det_geom_sent{};      // what det_geom (the device copy) holds
+    bool det_geom_sent_valid = false;
     // |cur - prev| of the pairs of the last mofreak_detect_pairs call, as the detector left it (layer 0 of its planes) --
     // valid while that call had ONE batch; mofreak_compute_stream lets the gather path's integral read it instead of
     // both frames (use_det_diff, for the extract that follows the detector on the same pairs)
@@ -714,7 +716,7 @@ void mofreak_destroy(mofreak_ctx *ctx)
     release(ctx->bow_expanded);
     for (DeviceBuffer *b : {&ctx->det_img, &ctx->det_score, &ctx->det_touch, &ctx->det_status, &ctx->det_rows, &ctx->det_cand_xy, &ctx->det_cand_flag,
                             &ctx->det_cand_emit, &ctx->det_cand_spec, &ctx->det_cand_asked, &ctx->det_cand_win, &ctx->det_cand_res, &ctx->det_layer_start, &ctx->det_emit_count, &ctx->det_emit_chunks, &ctx->det_geom, &ctx->det_emit_offsets,
-                            &ctx->det_out_kps, &ctx->det_out_offsets, &ctx->det_out_resp, &ctx->det_out_layer, &ctx->det_planes_out, &ctx->det_hit_mask, &ctx->det_walk_list, &ctx->det_walk_count, &ctx->det_cand_cells})
+                            &ctx->det_out_kps, &ctx->det_out_offsets, &ctx->det_out_resp, &ctx->det_out_layer, &ctx->det_planes_out, &ctx->det_hit_mask, &ctx->det_walk_list, &ctx->det_walk_count, &ctx->det_cand_cells, &ctx->det_tie_list, &ctx->det_tie_count})
         release(*b);
     release(ctx->integral);
     release(ctx->band_totals);
@@ -1760,6 +1762,8 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     if ((rc = ensure(ctx, ctx->det_walk_list, cands * sizeof(int32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_walk_count, (size_t)batch * a.walk_chunks * sizeof(int32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_cand_cells, cands * 128))) return rc;
+    if ((rc = ensure(ctx, ctx->det_tie_list, cands * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->det_tie_count, (size_t)batch * a.walk_chunks * sizeof(int32_t)))) return rc;
     // one buffer, one fill: the call's running keypoint total (16 bytes) and the per-row counts
     const size_t n_row_counts = (size_t)batch * (g.total_rows + 1);
     if ((rc = ensure(ctx, ctx->det_rows, 16 + n_row_counts * sizeof(int32_t)))) return rc;
@@ -1776,7 +1780,13 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     a.emit_chunk_cap = (ctx->det_cand_cap + 1023) / 1024;
     if ((rc = ensure(ctx, ctx->det_emit_chunks, (size_t)batch * a.emit_chunk_cap * sizeof(int32_t)))) return rc;
     a.g = g;
-    if ((rc = upload(ctx, ctx->det_geom, &a.g, sizeof(DetGeom)))) return rc;  // a.g lives in the caller's frame until it synchronises
+    // the device copy of the geometry: sent when it changes (a stream of equal-sized frames: once)
+    if (!ctx->det_geom.ptr || !ctx->det_geom_sent_valid || std::memcmp(&ctx->det_geom_sent, &g, sizeof(DetGeom)) != 0) {
+        ctx->det_geom_sent_valid = false;
+        ctx->det_geom_sent = g;  // (a member: the copy below may still be reading it when this function returns)
+        if ((rc = upload(ctx, ctx->det_geom, &ctx->det_geom_sent, sizeof(DetGeom)))) return rc;
+        ctx->det_geom_sent_valid = true;
+    }
     a.dg = static_cast<const DetGeom *>(ctx->det_geom.ptr);
     a.img = static_cast<uint8_t *>(ctx->det_img.ptr);
     a.score = static_cast<uint8_t *>(ctx->det_score.ptr);
@@ -1787,6 +1797,8 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     a.walk_list = static_cast<int32_t *>(ctx->det_walk_list.ptr);
     a.walk_count = static_cast<int32_t *>(ctx->det_walk_count.ptr);
     a.cand_cells = static_cast<uint8_t *>(ctx->det_cand_cells.ptr);
+    a.tie_list = static_cast<DetTie *>(ctx->det_tie_list.ptr);
+    a.tie_count = static_cast<int32_t *>(ctx->det_tie_count.ptr);
     ctx->det_counter_bytes = n_row_counts * sizeof(int32_t);
     a.cand_cap = ctx->det_cand_cap;
     a.cand_xy = static_cast<uint32_t *>(ctx->det_cand_xy.ptr);
@@ -1800,7 +1812,8 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     a.emit_count = static_cast<int32_t *>(ctx->det_emit_count.ptr);
     a.emit_offsets = static_cast<int64_t *>(ctx->det_emit_offsets.ptr);
     a.emit_chunks = static_cast<int32_t *>(ctx->det_emit_chunks.ptr);
-    a.status_word = ctx->d_status + 1;  // the detector's own word: clearing it leaves the describe kernels' flags alone
+    // the detector's own status word sits behind the call's running total: one fill clears both, one copy fetches both
+    a.status_word = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(ctx->det_rows.ptr) + 8);
     a.fp_x87 = ctx->params.brisk_fp_model == MOFREAK_FP_X87 ? 1 : 0;
     return MOFREAK_OK;
 }
@@ -1874,9 +1887,8 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
     const int batch = det_batch(ctx, g, n_pairs);
     DetArgs a{};
     if ((rc = det_workspace(ctx, g, batch, a))) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_status + 1, 0, sizeof(int32_t), ctx->stream));
     int64_t *running = static_cast<int64_t *>(ctx->det_rows.ptr);
-    if (n_pairs == 0) HIP_TRY(ctx, hipMemsetAsync(running, 0, sizeof(int64_t), ctx->stream));
+    if (n_pairs == 0) HIP_TRY(ctx, hipMemsetAsync(running, 0, 16, ctx->stream));
     if (n_pairs == 0) HIP_TRY(ctx, hipMemsetAsync(d_off, 0, sizeof(int64_t), ctx->stream));
     a.threshold = threshold;
     a.safe_threshold = (int)(uint8_t)((float)threshold * 1.0f);  // safeThreshold_ = threshold_ * safetyFactor_ (brisk.cpp:58, 597)
@@ -1904,11 +1916,11 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
         if (!e) e = launch_det_keypoints(a, running, ctx->stream);
         if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("detector launch: ") + hipGetErrorString((hipError_t)e));
     }
-    int64_t total = 0;
-    int32_t st = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&total, running, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(&st, ctx->d_status + 1, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    int64_t head[2] = {0, 0};  // the running total and, behind it, the status word
+    HIP_TRY(ctx, hipMemcpyAsync(head, running, sizeof(head), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t total = head[0];
+    const int32_t st = (int32_t)(uint32_t)(uint64_t)head[1];
     if (n_out) *n_out = total;
     ctx->det_maps_dirty = (st & (16 | 32)) != 0;  // the emission of every batch has taken its bytes back
     if (st & 16) return fail(ctx, MOFREAK_ERR_HIP, "detector: a refinement walk left its staged window (internal error)");

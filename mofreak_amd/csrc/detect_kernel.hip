@@ -1464,7 +1464,7 @@ __device__ __forceinline__ void window_scores(const Patch &q, const DetLayer &L,
 // registers (eleven 16-byte loads in flight together) and scores the cells from there: no LDS, few registers, many waves.
 __global__ __launch_bounds__(kDetThreads) void det_window_kernel(DetArgs a)
 {
-    __shared__ int todo[kRefineChunk], wave_cnt[8], n_todo, ls_s[kDetMaxLayers + 1];
+    __shared__ int todo[kRefineChunk], wave_cnt[16], n_todo, ls_s[kDetMaxLayers + 1];
     __shared__ DetGeom geom_s;
     const int p = blockIdx.y, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
@@ -1473,32 +1473,47 @@ __global__ __launch_bounds__(kDetThreads) void det_window_kernel(DetArgs a)
     if (threadIdx.x <= kDetMaxLayers) ls_s[threadIdx.x] = (int)threadIdx.x <= n_layers ? ls[threadIdx.x] : 0x7fffffff;
     geom_to_lds(&geom_s, a.dg);
     const int64_t cb = (int64_t)p * a.cand_cap;
-    {  // the chunk's walkers, in candidate order: both halves of the chunk in one go
+    {  // the chunk's walkers, in candidate order: both halves of the chunk in one go; and the ties among them, with their
+       // positions, as a list of their own for det_tie_kernel
         static_assert(kRefineChunk == 2 * kDetThreads, "a thread takes two candidates of the chunk");
         const int i_a = c0 + threadIdx.x, i_b = i_a + kDetThreads;
-        const bool take_a = i_a < n && a.cand_flag[cb + i_a] != kDetNotMax, take_b = i_b < n && a.cand_flag[cb + i_b] != kDetNotMax;
-        const unsigned long long m_a = __ballot(take_a), m_b = __ballot(take_b);
+        const uint8_t f_a = a.cand_flag[cb + min(i_a, n - 1)], f_b = a.cand_flag[cb + min(i_b, n - 1)];
+        const uint32_t xy_a = a.cand_xy[cb + min(i_a, n - 1)], xy_b = a.cand_xy[cb + min(i_b, n - 1)];
+        const bool take_a = i_a < n && f_a != kDetNotMax, take_b = i_b < n && f_b != kDetNotMax;
+        const bool tie_a = i_a < n && f_a == kDetTie, tie_b = i_b < n && f_b == kDetTie;
+        const unsigned long long m_a = __ballot(take_a), m_b = __ballot(take_b), t_a = __ballot(tie_a), t_b = __ballot(tie_b);
         if (lane == 0) {
             wave_cnt[wave] = __popcll(m_a);
             wave_cnt[4 + wave] = __popcll(m_b);
+            wave_cnt[8 + wave] = __popcll(t_a);
+            wave_cnt[12 + wave] = __popcll(t_b);
         }
         __syncthreads();
         int before_a = 0, before_b = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        int tbefore_a = 0, tbefore_b = wave_cnt[8] + wave_cnt[9] + wave_cnt[10] + wave_cnt[11];
         for (int w = 0; w < wave; ++w) {
             before_a += wave_cnt[w];
             before_b += wave_cnt[4 + w];
+            tbefore_a += wave_cnt[8 + w];
+            tbefore_b += wave_cnt[12 + w];
         }
+        const unsigned long long below = (1ull << lane) - 1;
         if (take_a) {
-            const int k = before_a + __popcll(m_a & ((1ull << lane) - 1));
+            const int k = before_a + __popcll(m_a & below);
             todo[k] = i_a;
             a.walk_list[cb + c0 + k] = i_a;
         }
         if (take_b) {
-            const int k = before_b + __popcll(m_b & ((1ull << lane) - 1));
+            const int k = before_b + __popcll(m_b & below);
             todo[k] = i_b;
             a.walk_list[cb + c0 + k] = i_b;
         }
-        if (threadIdx.x == 0) n_todo = before_b + wave_cnt[4] + wave_cnt[5] + wave_cnt[6] + wave_cnt[7];
+        if (tie_a) a.tie_list[cb + c0 + tbefore_a + __popcll(t_a & below)] = DetTie{i_a, xy_a};
+        if (tie_b) a.tie_list[cb + c0 + tbefore_b + __popcll(t_b & below)] = DetTie{i_b, xy_b};
+        if (threadIdx.x == 0) {
+            n_todo = before_b + wave_cnt[4] + wave_cnt[5] + wave_cnt[6] + wave_cnt[7];
+            a.tie_count[(int64_t)p * a.walk_chunks + blockIdx.x] = tbefore_b + wave_cnt[12] + wave_cnt[13] + wave_cnt[14] + wave_cnt[15];
+        }
         __syncthreads();
     }
     const int nt = n_todo;
@@ -1622,17 +1637,26 @@ struct TieStep {
 // A candidate lies at least 3 pixels inside its layer (the score is zero in the border), so every row segment read
 // here starts inside the layer: fourteen 8-byte loads, issued together (the two bytes some run past the end of a row
 // stay inside the padded plane and are masked out).
-__device__ __forceinline__ TieStep tie_step(const PairView &v, const DetLayer &L, int safe_threshold, int px, int py)
+struct TieRows {
+    unsigned long long st[4], sc[5], tc[5];
+};
+__device__ __forceinline__ TieRows tie_load(const PairView &v, const DetLayer &L, int px, int py)
 {
     const int64_t at = L.off + (int64_t)py * L.w + px;
-    unsigned long long st_row[4], sc_row[5], tc_row[5];
+    TieRows r;
 #pragma unroll
-    for (int dy = -3; dy <= 0; ++dy) st_row[dy + 3] = load8(v.status + at + dy * L.w - 3);
+    for (int dy = -3; dy <= 0; ++dy) r.st[dy + 3] = load8(v.status + at + dy * L.w - 3);
 #pragma unroll
     for (int dy = -2; dy <= 2; ++dy) {
-        sc_row[dy + 2] = load8(v.score + at + dy * L.w - 2);
-        tc_row[dy + 2] = load8(v.touch + at + dy * L.w - 2);
+        r.sc[dy + 2] = load8(v.score + at + dy * L.w - 2);
+        r.tc[dy + 2] = load8(v.touch + at + dy * L.w - 2);
     }
+    return r;
+}
+#ifdef MOFREAK_DEBUG_BOUNDS  // cell by cell, as the text above goes: the bounds-checking build holds the fast form below against it
+__device__ __forceinline__ TieStep tie_decide_plain(const TieRows &rows, const DetLayer &L, int safe_threshold, int px, int py)
+{
+    const unsigned long long(&st_row)[4] = rows.st, (&sc_row)[5] = rows.sc, (&tc_row)[5] = rows.tc;
     uint8_t st[7][7];
     int sc[5][5];
     uint8_t tc[5][5];
@@ -1687,16 +1711,95 @@ __device__ __forceinline__ TieStep tie_step(const PairView &v, const DetLayer &L
         }
     return TieStep{!waits, is_max};
 }
+#endif
+// The same decision on whole rows: the 25 cells' nine status comparisons each are a few hundred operations cell by cell, and a
+// workgroup per pair has the ties of a pair to itself.  Bytes stay in their 8-byte rows: a flag is bit 7 of its byte.
+__device__ __forceinline__ TieStep tie_decide_rows(const TieRows &rows, const DetLayer &L, int safe_threshold, int px, int py)
+{
+    typedef unsigned long long u64;
+    constexpr u64 k80 = 0x8080808080808080ull, k7f = 0x7f7f7f7f7f7f7f7full, k01 = 0x0101010101010101ull;
+    auto nonzero = [&](u64 x) -> u64 { return (((x & k7f) + k7f) | x) & k80; };          // flag: byte != 0
+    auto equals = [&](u64 x, int c) -> u64 { return ~nonzero(x ^ (k01 * (u64)c)) & k80; };  // flag: byte == c
+    auto three = [&](u64 m) -> u64 { return m | (m >> 8) | (m >> 16); };                  // flag of byte x: any of bytes x, x + 1, x + 2
+    // status: rows dy = -3 .. 0, byte b <-> dx = b - 3; only cells before the candidate in raster order count
+    u64 reached[4], pending[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u64 valid = i < 3 ? 0x0080808080808080ull : 0x0000000000808080ull;
+        reached[i] = three(equals(rows.st[i], kStReached) & valid);
+        pending[i] = three(equals(rows.st[i], kStPending) & valid);
+    }
+    // cell row y of the 5 x 5 window (dy = y - 2) has the status rows dy - 1 .. dy + 1 around it: rows y, y + 1, y + 2 of the
+    // seven, of which 4 .. 6 lie behind the candidate
+    const u64 reached_near[5] = {reached[0] | reached[1] | reached[2], reached[1] | reached[2] | reached[3], reached[2] | reached[3], reached[3], 0ull};
+    const u64 pending_near[5] = {pending[0] | pending[1] | pending[2], pending[1] | pending[2] | pending[3], pending[2] | pending[3], pending[3], 0ull};
+    // scores and touch marks: rows dy = -2 .. 2, byte b <-> dx = b - 2; cells outside the scored region count as empty
+    u64 cols = 0;
+#pragma unroll
+    for (int x = 0; x < 5; ++x) cols |= (px + x - 2 >= 3 && px + x - 2 < L.w - 3) ? 0xffull << (8 * x) : 0ull;
+    const u64 t7 = k01 * (u64)(safe_threshold & 0x7f);
+    const bool t_high = (safe_threshold & 0x80) != 0;
+    u64 waits = 0, r_row[5];
+#pragma unroll
+    for (int y = 0; y < 5; ++y) {
+        const u64 in = (py + y - 2 >= 3 && py + y - 2 < L.h - 3) ? cols : 0ull;
+        const u64 s = rows.sc[y] & in, t = rows.tc[y] & in;
+        const u64 low_ge = (((s & k7f) | k80) - t7) & k80;                 // low seven bits >= the threshold's
+        const u64 ge = t_high ? (s & low_ge) : ((s | low_ge) & k80);       // flag: score >= safe_threshold
+        const u64 touched = nonzero(t);
+        const u64 settled = (~nonzero(s) & k80) | ge | touched;
+        const u64 filled = (ge | touched | reached_near[y]) & 0x0000008080808080ull;
+        waits |= ~settled & pending_near[y] & 0x0000008080808080ull;
+        r_row[y] = s & ((filled - (filled >> 7)) | filled);               // the score where the cache holds it, else 0
+    }
+    int r[5][5];
+#pragma unroll
+    for (int y = 0; y < 5; ++y)
+#pragma unroll
+        for (int x = 0; x < 5; ++x) r[y][x] = (int)((r_row[y] >> (8 * x)) & 0xff);
+    // 1 2 1 / 2 4 2 / 1 2 1 around the nine inner cells, rows first
+    int h[5][3];
+#pragma unroll
+    for (int y = 0; y < 5; ++y)
+#pragma unroll
+        for (int x = 0; x < 3; ++x) h[y][x] = r[y][x] + 2 * r[y][x + 1] + r[y][x + 2];
+    auto smooth = [&](int cx, int cy) { return h[cy - 1][cx - 1] + 2 * h[cy][cx - 1] + h[cy + 1][cx - 1]; };
+    const int center = r[2][2], smoothedcenter = smooth(2, 2);
+    bool is_max = true;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            if (dx == 0 && dy == 0) continue;
+            if (r[2 + dy][2 + dx] == center && smooth(2 + dx, 2 + dy) > smoothedcenter) is_max = false;
+        }
+    return TieStep{waits == 0, is_max};
+}
+
+// (the bounds-checking build decides every tie both ways and reports a difference: status bit 32)
+__device__ __forceinline__ TieStep tie_decide(const DetArgs &a, const TieRows &rows, const DetLayer &L, int px, int py)
+{
+    const TieStep s = tie_decide_rows(rows, L, a.safe_threshold, px, py);
+#ifdef MOFREAK_DEBUG_BOUNDS
+    const TieStep q = tie_decide_plain(rows, L, a.safe_threshold, px, py);
+    if (q.ready != s.ready || q.is_max != s.is_max) atomicOr(a.status_word, 32);
+#endif
+    return s;
+}
+__device__ __forceinline__ TieStep tie_step(const DetArgs &a, const PairView &v, const DetLayer &L, int px, int py)
+{
+    return tie_decide(a, tie_load(v, L, px, py), L, px, py);
+}
 
 // What a tie needs besides its neighbourhood, fetched together with it (nothing here depends on the decision)
 struct TieCand {
     uint32_t xy, win;
-    uint8_t flag, spec;
+    uint8_t spec;
     unsigned long long asked;
 };
-__device__ __forceinline__ TieCand tie_cand(const DetArgs &a, int64_t ci)
+__device__ __forceinline__ TieCand tie_cand(const DetArgs &a, int64_t ci, uint32_t xy)
 {
-    return TieCand{a.cand_xy[ci], a.cand_win[ci], a.cand_flag[ci], a.cand_spec[ci], a.cand_asked[ci]};
+    return TieCand{xy, a.cand_win[ci], a.cand_spec[ci], a.cand_asked[ci]};
 }
 
 // The status map is the one thing ties of a layer tell each other: a byte per pixel that goes from pending to its
@@ -1716,135 +1819,229 @@ __device__ __forceinline__ void tie_apply(const DetArgs &a, const PairView &v, c
     }
 }
 
-// The ties of a pair: one workgroup per pair, layer after layer (a layer reads what the maxima of the layer below asked for
-// in it), for each layer:  (1) The layer's ties are picked out of its candidates into an LDS list.  (2) First sight: every tie
-// looks at its neighbourhood once; the ones that are ready -- the great majority -- decide and publish on the spot (a
-// ready tie depends on no tie that is still pending, so two of them never need each other's outcome, and a status byte
-// changes once, from pending to final: whoever reads the old value merely waits); the others go on the waiting list.
-// (3) Chains: what first sight left waiting are ties that depend on each other: a thread per link (or several), each
-// spinning until the links before it have published; the earliest pending tie of a layer is always ready, so the
-// spinning ends.  Everything the threads tell each other stays inside the workgroup -- one CU, one vector cache -- so
-// workgroup-scope ordering is all it takes, and all the waves involved are resident.
-constexpr int kTieThreads = 512;
+// Layer 0's ties at first sight, chip-wide: nothing a layer-0 tie reads is still to come once the walks are through (its
+// layer has no layer below that could ask for cells in it), so every tie of layer 0 can take its first look at the same
+// time -- a workgroup per chunk of candidates, straight off the chunk's tie list -- instead of one CU per pair fetching their
+// 17 scattered lines each.  A tie that is ready decides, publishes and is crossed off its list (the candidate index
+// complemented); the others are left to det_tie_kernel's chains.  Ties that decide here side by side: as there (a ready tie
+// depends on no pending one; a status byte changes once; whoever reads the old value merely waits).
+__device__ __forceinline__ int tie_candidate(const DetTie &e) { return e.cand < 0 ? ~e.cand : e.cand; }
+
+__global__ __launch_bounds__(kDetThreads) void det_tie_first_kernel(DetArgs a)
+{
+    const int p = blockIdx.y;
+    const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
+    const int n0 = ls[1];  // layer 0's candidates: [0, n0)
+    const int64_t cb = (int64_t)p * a.cand_cap;
+    const PairView v = pair_view(a, p);
+    const DetLayer L = a.dg->L[0];
+    for (int c = blockIdx.x; c * kRefineChunk < n0; c += gridDim.x) {
+        const int nt = a.tie_count[(int64_t)p * a.walk_chunks + c];
+        DetTie *list = a.tie_list + cb + (int64_t)c * kRefineChunk;
+        for (int k = threadIdx.x; k < nt; k += kDetThreads) {
+            const DetTie e = list[k];
+            if (e.cand >= n0) continue;  // (the chunk that runs on into layer 1)
+            const int px = (int)(e.xy & 0xffff), py = (int)(e.xy >> 16);
+            const TieCand cnd = tie_cand(a, cb + e.cand, e.xy);
+            const TieStep step = tie_step(a, v, L, px, py);
+            if (step.ready) {
+                tie_apply(a, v, L, cb + e.cand, cnd, 0, px, py, step.is_max);
+                list[k].cand = ~e.cand;
+            }
+        }
+    }
+}
+
+// The ties of a pair: one workgroup per pair.  det_window_kernel left the ties of every chunk of candidates as a list
+// (candidate, position); the chunks' lists, one behind the other, are the pair's ties in candidate order -- layer after
+// layer, raster order inside a layer.  Prologue: the chunk counts are summed up, the list is copied into LDS (what does not
+// fit is read from global memory where it lies), the layers' ranges in it are looked up; layer 0's ties have had their first
+// sight (det_tie_first_kernel): the ones it left are put on layer 0's waiting list on the way.  Then layer after layer (a layer
+// reads what the maxima of the layer below -- its ties included -- asked for in it):  (1) First sight: every tie looks at its
+// neighbourhood once, two ties per thread at a time with all their loads in flight together; the ones that are ready --
+// the great majority -- decide and publish on the spot (a ready tie depends on no tie that is still pending, so two of
+// them never need each other's outcome, and a status byte changes once, from pending to final: whoever reads the old
+// value merely waits); the others go on the waiting list.  (2) Chains: what first sight left waiting are ties that
+// depend on each other: a thread per link (or several), each spinning until the links before it have published; the
+// earliest pending tie of a layer is always ready, so the spinning ends.  Everything the threads tell each other stays
+// inside the workgroup -- one CU, one vector cache -- so workgroup-scope ordering is all it takes, and all the waves
+// involved are resident.
+constexpr int kTieThreads = 512, kTieWaves = kTieThreads / 64;
 #ifdef MOFREAK_DEBUG_BOUNDS
-constexpr int kTieListCap = 64, kDetWaitCap = 8;  // the debug build overflows both lists on every tie-heavy image: the scanning fallbacks get tested
+constexpr int kTieListCap = 64, kDetWaitCap = 8, kTieChunksMax = 16;  // the debug build overflows all three on every tie-heavy image: the fallbacks get tested
 #else
-constexpr int kTieListCap = 6144, kDetWaitCap = 4096;  // ties / waiting ties per pair and layer held in LDS lists (more: the candidates are scanned instead)
+constexpr int kTieListCap = 6144, kDetWaitCap = 2048;  // ties per pair / waiting ties per pair and layer held in LDS
+constexpr int kTieChunksMax = kTieThreads;             // chunks of candidates per pair the prologue takes a thread each for (more: a run of chunks each)
 #endif
+static_assert(kTieChunksMax <= kTieThreads && (kTieChunksMax & (kTieChunksMax - 1)) == 0, "a thread per run of chunks; the look-up halves a power of two");
 
 __global__ __launch_bounds__(kTieThreads) void det_tie_kernel(DetArgs a)
 {
-    __shared__ int tie_idx[kTieListCap], wait_idx[kDetWaitCap], n_ties_s, n_wait_s, ls_s[kDetMaxLayers + 1];
-    const int p = blockIdx.x, lane = threadIdx.x & 63;
+    __shared__ DetTie tie_s[kTieListCap];
+    __shared__ int wait_idx[kDetWaitCap], chunk_off[kTieChunksMax + 1], wave_tot[kTieWaves], n_wait_s[kDetMaxLayers], ls_s[kDetMaxLayers + 1],
+        tie_lo_s[kDetMaxLayers + 1];
+    __shared__ DetGeom geom_s;
+    const int p = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int32_t *ls = a.layer_start + (int64_t)p * (kDetMaxLayers + 1);
     const int n_layers = a.dg->n_layers;
-    if (threadIdx.x <= kDetMaxLayers) ls_s[threadIdx.x] = (int)threadIdx.x <= n_layers ? ls[threadIdx.x] : 0;
-    const PairView v = pair_view(a, p);
+    const int n_chunks = (ls[n_layers] + kRefineChunk - 1) / kRefineChunk;  // (det_window_kernel wrote the counts of exactly these)
     const int64_t cb = (int64_t)p * a.cand_cap;
-    // layer after layer in one launch: a layer reads what the maxima of the layer below -- its ties included -- asked for in
-    // it, and this workgroup is the only one that works on the pair
-    for (int layer = 0; layer < n_layers; ++layer) {
-    __syncthreads();  // the layer below is through (its threads' last decisions included); the lists are free again
-    const int lo = ls_s[layer], hi = ls_s[layer + 1];
-    if (hi <= lo) continue;
-    const DetLayer L = a.dg->L[layer];
-    if (threadIdx.x == 0) {
-        n_ties_s = 0;
-        n_wait_s = 0;
+    // ---- prologue
+    // (a thread per chunk; a pair with more chunks than threads -- a raised candidate capacity and an image that fills it --
+    // has a thread sum a run of `per` consecutive chunks, and a look-up walks the run it lands in)
+    const int per = (n_chunks + kTieChunksMax - 1) / kTieChunksMax;
+    const int32_t *chunk_cnt = a.tie_count + (int64_t)p * a.walk_chunks;
+    int own_cnt = 0;
+    for (int c = threadIdx.x * per; c < min((int)(threadIdx.x + 1) * per, n_chunks); ++c) own_cnt += chunk_cnt[c];
+    if (threadIdx.x <= kDetMaxLayers) ls_s[threadIdx.x] = (int)threadIdx.x <= n_layers ? ls[threadIdx.x] : 0x7fffffff;
+    if (threadIdx.x < kDetMaxLayers) n_wait_s[threadIdx.x] = 0;
+    geom_to_lds(&geom_s, a.dg);
+    int incl = own_cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
     }
+    if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
-    // (1) sixteen flag bytes per thread and load (one candidate in eight is a tie): the layer's flags in one or two round trips
-    for (int i0 = lo; i0 < hi; i0 += 16 * kTieThreads) {
-        const int i = i0 + 16 * (int)threadIdx.x;
-        uint4 f = make_uint4(0, 0, 0, 0);
-        if (i < hi) __builtin_memcpy(&f, a.cand_flag + cb + i, 16);  // (the flag array is padded: the last load may run past hi)
-        const uint32_t w[4] = {f.x, f.y, f.z, f.w};
-        uint32_t ties = 0;
+    int before = 0, n_ties = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) ties |= (((w[k >> 2] >> (8 * (k & 3))) & 0xff) == kDetTie && i + k < hi) ? 1u << k : 0u;
-        const int cnt = __popc(ties);
-        int incl = cnt;
+    for (int w = 0; w < kTieWaves; ++w) {
+        before += w < wave ? wave_tot[w] : 0;
+        n_ties += wave_tot[w];
+    }
+    if (threadIdx.x < kTieChunksMax) chunk_off[threadIdx.x] = before + incl - own_cnt;  // (runs past the last chunk: the total)
+    if (threadIdx.x == 0) chunk_off[kTieChunksMax] = n_ties;
+    __syncthreads();
+    // tie k of the pair: in which chunk's list, and there
+    auto from_global = [&](int k) -> DetTie {
+        int c = 0;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o);
-            if (lane >= o) incl += t;
-        }
-        const int total = __shfl(incl, 63);
-        if (total) {  // wave-uniform
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&n_ties_s, total);
-            int k = __builtin_amdgcn_readfirstlane(base) + incl - cnt;
-            while (ties) {
-                const int b = __ffs((int)ties) - 1;
-                ties &= ties - 1;
-                if (k < kTieListCap) tie_idx[k] = i + b;
-                ++k;
+        for (int step = kTieChunksMax / 2; step >= 1; step >>= 1)
+            if (chunk_off[c + step] <= k) c += step;  // the last run that starts at or before k (empty ones in front of it start there too)
+        int off = chunk_off[c];
+        if (per > 1) {
+            c *= per;
+            for (int cnt = chunk_cnt[c]; off + cnt <= k; cnt = chunk_cnt[c]) {
+                off += cnt;
+                ++c;
             }
         }
-    }
-    __syncthreads();
-    const int n_ties = n_ties_s;
-    const bool ties_listed = n_ties <= kTieListCap;
-    const int n_first = ties_listed ? n_ties : hi - lo;
-    // (2) first sight
-    for (int k = threadIdx.x; k < n_first; k += kTieThreads) {
-        const int i = ties_listed ? tie_idx[k] : lo + k;
-        const TieCand c = tie_cand(a, cb + i);
-        if (c.flag != kDetTie) continue;
-        const int px = (int)(c.xy & 0xffff), py = (int)(c.xy >> 16);
-        const TieStep step = tie_step(v, L, a.safe_threshold, px, py);
-        if (step.ready)
-            tie_apply(a, v, L, cb + i, c, layer, px, py, step.is_max);
-        else {
-            const int w = atomicAdd(&n_wait_s, 1);
-            if (w < kDetWaitCap) wait_idx[w] = i;
+        return a.tie_list[cb + (int64_t)c * kRefineChunk + (k - off)];
+    };
+    auto tie_at = [&](int k) -> DetTie { return k < kTieListCap ? tie_s[k] : from_global(k); };
+    {
+        const int n_lds = min(n_ties, kTieListCap);
+        constexpr int kU = 4;  // loads in flight per thread
+        for (int k0 = threadIdx.x; k0 < n_lds; k0 += kU * kTieThreads) {
+            DetTie e[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) e[u] = from_global(min(k0 + u * kTieThreads, n_lds - 1));
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+                if (k0 + u * kTieThreads < n_lds) {
+                    tie_s[k0 + u * kTieThreads] = e[u];
+                    if (e[u].cand >= 0 && e[u].cand < ls_s[1]) {  // layer 0, not ready at first sight
+                        const int w = atomicAdd(&n_wait_s[0], 1);
+                        if (w < kDetWaitCap) wait_idx[w] = k0 + u * kTieThreads;
+                    }
+                }
         }
     }
     __syncthreads();
-    // (3) chains
-    const int n_wait = n_wait_s;
-    if (n_wait == 0) continue;
-    const bool listed = n_wait <= kDetWaitCap;  // list overflow: every candidate of the layer
-    const int n_items = listed ? n_wait : hi - lo;
-    // a thread's first tie stays in registers between passes (there are rarely more than a few hundred per pair and
-    // layer): a pass is then one round of neighbourhood loads, not list entry -> record -> neighbourhood
-    const int own_i = (int)threadIdx.x < n_items ? (listed ? wait_idx[threadIdx.x] : lo + (int)threadIdx.x) : lo;
-    const TieCand own = tie_cand(a, cb + own_i);
-    bool own_waits = (int)threadIdx.x < n_items && own.flag == kDetTie;
-    // The earliest pending tie of a layer is always ready, so a pass decides at least one tie and n_items + 1 passes
-    // are enough for the longest possible chain.  Should that invariant ever break (a status byte left pending by a
-    // candidate nobody lists), the thread gives up and says so (status bit 32 -> MOFREAK_ERR_HIP) instead of hanging
-    // the device.
-    for (int pass = 0;; ++pass) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // the pass reads what has been published by now
-        bool waits = false;
-        if (own_waits) {
-            const int px = (int)(own.xy & 0xffff), py = (int)(own.xy >> 16);
-            const TieStep step = tie_step(v, L, a.safe_threshold, px, py);
-            if (step.ready) {
-                tie_apply(a, v, L, cb + own_i, own, layer, px, py, step.is_max);
-                own_waits = false;
-            } else {
-                waits = true;
-            }
-        }
-        for (int k = threadIdx.x + kTieThreads; k < n_items; k += kTieThreads) {
-            const int i = listed ? wait_idx[k] : lo + k;
-            const TieCand c = tie_cand(a, cb + i);
-            if (c.flag != kDetTie) continue;  // written by this thread only
-            const int px = (int)(c.xy & 0xffff), py = (int)(c.xy >> 16);
-            const TieStep step = tie_step(v, L, a.safe_threshold, px, py);
-            if (step.ready)
-                tie_apply(a, v, L, cb + i, c, layer, px, py, step.is_max);
+    if (threadIdx.x == 0 && n_ties > kTieListCap) n_wait_s[0] = kDetWaitCap + 1;  // not all of them seen here: every tie of layer 0 is looked at again
+    if (threadIdx.x <= n_layers) {  // where a layer's ties begin: the first tie whose candidate is not below the layer's first
+        const int first = ls_s[threadIdx.x];
+        int lo = 0, hi = n_ties;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (tie_candidate(tie_at(mid)) < first)
+                lo = mid + 1;
             else
-                waits = true;
+                hi = mid;
         }
-        if (!waits) break;
-        if (pass > n_items) {
-            atomicOr(a.status_word, 32);
-            break;
-        }
+        tie_lo_s[threadIdx.x] = lo;
     }
+    __syncthreads();
+    PairView v = pair_view(a, p);
+    v.g = &geom_s;
+    // ---- layer after layer
+    for (int layer = 0; layer < n_layers; ++layer) {
+        const int lo = tie_lo_s[layer], hi = tie_lo_s[layer + 1];
+        if (hi <= lo) continue;
+        const DetLayer L = geom_s.L[layer];
+        // (1) first sight, ties k and k + kTieThreads of a thread's stretch together
+        auto settle = [&](int k, const DetTie e, const TieCand &c, const TieStep step) {
+            const int px = (int)(e.xy & 0xffff), py = (int)(e.xy >> 16);
+            if (step.ready)
+                tie_apply(a, v, L, cb + e.cand, c, layer, px, py, step.is_max);
+            else {
+                const int w = atomicAdd(&n_wait_s[layer], 1);
+                if (w < kDetWaitCap) wait_idx[w] = k;
+            }
+        };
+        for (int k0 = lo + (int)threadIdx.x; k0 < hi && layer > 0; k0 += 2 * kTieThreads) {  // (layer 0: det_tie_first_kernel)
+            const int k1 = k0 + kTieThreads;
+            const bool two = k1 < hi;
+            const DetTie e0 = tie_at(k0), e1 = tie_at(two ? k1 : k0);
+            const TieCand c0 = tie_cand(a, cb + e0.cand, e0.xy), c1 = tie_cand(a, cb + e1.cand, e1.xy);
+            const TieRows r0 = tie_load(v, L, (int)(e0.xy & 0xffff), (int)(e0.xy >> 16)), r1 = tie_load(v, L, (int)(e1.xy & 0xffff), (int)(e1.xy >> 16));
+            const TieStep s0 = tie_decide(a, r0, L, (int)(e0.xy & 0xffff), (int)(e0.xy >> 16));
+            const TieStep s1 = tie_decide(a, r1, L, (int)(e1.xy & 0xffff), (int)(e1.xy >> 16));
+            settle(k0, e0, c0, s0);
+            if (two) settle(k1, e1, c1, s1);
+        }
+        __syncthreads();  // the waiting list is complete; what first sight published is visible
+        // (2) chains
+        const int n_wait = n_wait_s[layer];
+        if (n_wait != 0) {
+            const bool listed = n_wait <= kDetWaitCap;  // list overflow: every tie of the layer, each by the thread that saw it first
+            const int n_items = listed ? n_wait : hi - lo;
+            auto item = [&](int j) -> int { return listed ? wait_idx[j] : lo + j; };
+            // a thread's first tie stays in registers between passes (there are rarely more than a few hundred per pair and
+            // layer): a pass is then one round of neighbourhood loads
+            const bool has_own = (int)threadIdx.x < n_items;
+            DetTie own_e = tie_at(has_own ? item(threadIdx.x) : lo);
+            own_e.cand = tie_candidate(own_e);
+            const TieCand own = tie_cand(a, cb + own_e.cand, own_e.xy);
+            bool own_waits = has_own && a.cand_flag[cb + own_e.cand] == kDetTie;  // (all of them unless the list overflowed)
+            // The earliest pending tie of a layer is always ready, so a pass decides at least one tie and n_items + 1 passes
+            // are enough for the longest possible chain.  Should that invariant ever break (a status byte left pending by a
+            // candidate nobody lists), the thread gives up and says so (status bit 32 -> MOFREAK_ERR_HIP) instead of hanging
+            // the device.
+            for (int pass = 0;; ++pass) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // the pass reads what has been published by now
+                bool waits = false;
+                if (own_waits) {
+                    const int px = (int)(own.xy & 0xffff), py = (int)(own.xy >> 16);
+                    const TieStep step = tie_step(a, v, L, px, py);
+                    if (step.ready) {
+                        tie_apply(a, v, L, cb + own_e.cand, own, layer, px, py, step.is_max);
+                        own_waits = false;
+                    } else {
+                        waits = true;
+                    }
+                }
+                for (int j = threadIdx.x + kTieThreads; j < n_items; j += kTieThreads) {
+                    DetTie e = tie_at(item(j));
+                    e.cand = tie_candidate(e);
+                    if (a.cand_flag[cb + e.cand] != kDetTie) continue;  // written by this thread only (or before this launch)
+                    const TieCand c = tie_cand(a, cb + e.cand, e.xy);
+                    const int px = (int)(e.xy & 0xffff), py = (int)(e.xy >> 16);
+                    const TieStep step = tie_step(a, v, L, px, py);
+                    if (step.ready)
+                        tie_apply(a, v, L, cb + e.cand, c, layer, px, py, step.is_max);
+                    else
+                        waits = true;
+                }
+                if (!waits) break;
+                if (pass > n_items) {
+                    atomicOr(a.status_word, 32);
+                    break;
+                }
+            }
+        }
+        __syncthreads();  // the layer is through (its threads' last decisions included); the waiting list is free again
     }
 }
 
@@ -2045,6 +2242,7 @@ int launch_det_keypoints(const DetArgs &a, int64_t *running, void *stream)
     else
         hipLaunchKernelGGL(det_walk_kernel<false>, rgrid, dim3(kDetThreads), 0, s, a);
     // ties: layer by layer (a layer's ties read what the maxima of the layer below asked for in it)
+    hipLaunchKernelGGL(det_tie_first_kernel, dim3(std::min(a.walk_chunks, 64), a.n_pairs), dim3(kDetThreads), 0, s, a);  // layer 0 at first sight
     hipLaunchKernelGGL(det_tie_kernel, dim3(a.n_pairs), dim3(kTieThreads), 0, s, a);  // every layer's ties, layer after layer
     const dim3 egrid((a.cand_cap + kEmitChunk - 1) / kEmitChunk, a.n_pairs);
     hipLaunchKernelGGL(det_emit_count_kernel, egrid, dim3(kDetThreads), 0, s, a);

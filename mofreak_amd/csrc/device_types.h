@@ -214,6 +214,11 @@ enum : uint8_t { kStNone = 0, kStPending = 1, kStReached = 2, kStDone = 3 };
 struct DetResult {
     float x, y, size, response;
 };
+struct DetTie {
+    int32_t cand;   // candidate index within the pair
+    uint32_t xy;    // x | y << 16 in its layer
+};
+
 struct DetArgs {
     DetGeom g;          // host copy for the launchers; device code reads *dg (indexing a by-value kernel argument with a
     const DetGeom *dg;  // per-thread layer number would spill the whole argument block to scratch)
@@ -241,6 +246,9 @@ struct DetArgs {
     int32_t *walk_count;                    // [n_pairs][walk_chunks]
     int32_t walk_chunks;
     uint8_t *cand_cells;                    // [n_pairs][cand_cap][128]
+    // the ties among a chunk's walkers, in candidate order: tie k of chunk c is tie_list[512 c + k]
+    DetTie *tie_list;                       // [n_pairs][cand_cap]
+    int32_t *tie_count;                     // [n_pairs][walk_chunks]
     DetResult *cand_res;                    // [n_pairs][cand_cap]
     int32_t *layer_start;                   // [n_pairs][kDetMaxLayers + 1]
     int32_t *emit_count;                    // [n_pairs]

@@ -36,6 +36,33 @@ ABLATIONS = {
 }
 
 
+def _tie_stamps(t):
+    """det_tie_kernel with wall-clock stamps (100 MHz) around its phases; workgroup 0 prints them (device printf)."""
+    t = sub1(t, "    // ---- prologue\n", "    // ---- prologue\n    __shared__ long long st_fs[8], st_ch[8]; __shared__ int st_pass[8], st_nw[8];\n"
+                "    if (threadIdx.x < 8) { st_fs[threadIdx.x] = 0; st_ch[threadIdx.x] = 0; st_pass[threadIdx.x] = 0; st_nw[threadIdx.x] = 0; }\n    const long long t_start = wall_clock64();\n")
+    t = sub1(t, "    // ---- layer after layer\n", "    const long long t_pro = wall_clock64();\n    // ---- layer after layer\n")
+    t = sub1(t, "        const DetLayer L = geom_s.L[layer];\n        // (1) first sight", "        const DetLayer L = geom_s.L[layer];\n        const long long t_l0 = wall_clock64();\n        // (1) first sight")
+    t = sub1(t, "        __syncthreads();  // the waiting list is complete; what first sight published is visible\n",
+             "        __syncthreads();  // the waiting list is complete; what first sight published is visible\n        const long long t_l1 = wall_clock64();\n")
+    t = sub1(t, "                if (!waits) break;\n                if (pass > n_items) {", "                if (!waits) { atomicMax(&st_pass[layer], pass + 1); break; }\n                if (pass > n_items) {")
+    t = sub1(t, "        __syncthreads();  // the layer is through (its threads' last decisions included); the waiting list is free again\n",
+             "        __syncthreads();  // the layer is through (its threads' last decisions included); the waiting list is free again\n"
+             "        if (threadIdx.x == 0) { st_fs[layer] = t_l1 - t_l0; st_ch[layer] = wall_clock64() - t_l1; st_nw[layer] = n_wait; }\n")
+    t = sub1(t, "// ------------------------------------------------------------------ ordered emission",
+             "// ------------------------------------------------------------------ ordered emission (stamps build)")
+    # the kernel's closing brace: the last '}' before the emission banner
+    i = t.index("// ------------------------------------------------------------------ ordered emission")
+    j = t.rindex("}", 0, i)
+    tail = ("    __syncthreads();\n    if (blockIdx.x == 0 && threadIdx.x == 0) {\n        const long long t_end = wall_clock64();\n"
+            "        printf(\"tie stamps (us): total %.1f prologue %.1f ties %d |\", (t_end - t_start) / 100.0, (t_pro - t_start) / 100.0, n_ties);\n"
+            "        for (int l = 0; l < n_layers; ++l) printf(\" L%d n=%d first %.1f chain %.1f passes %d waiting %d |\", l, tie_lo_s[l + 1] - tie_lo_s[l], st_fs[l] / 100.0, st_ch[l] / 100.0, st_pass[l], st_nw[l]);\n"
+            "        printf(\"\\n\");\n    }\n")
+    return t[:j] + tail + t[j:]
+
+
+ABLATIONS["tiestamps"] = _tie_stamps
+
+
 def build(name, flags, patch=None):
     sys.path.insert(0, ROOT)
     from mofreak_amd import build as B
