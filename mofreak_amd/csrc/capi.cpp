@@ -646,6 +646,8 @@ int mofreak_create(int device_id, const mofreak_params *params, mofreak_ctx **ou
     std::memcpy(st.orient, t.orient, sizeof(st.orient));
     std::memcpy(st.bit_pair_i, t.bit_pair_i, 64);
     std::memcpy(st.bit_pair_j, t.bit_pair_j, 64);
+    for (int k = 0; k < kNbOrientPairs; ++k) st.need_orient |= 1ull << t.orient[k].i | 1ull << t.orient[k].j;
+    for (int b = 0; b < 64; ++b) st.need_bits |= 1ull << t.bit_pair_i[b] | 1ull << t.bit_pair_j[b];
     st.fixed_scale_index = t.fixed_scale_index;
     st.orientation_normalized = p.freak_orientation_normalized != 0;
     st.scale_normalized = p.freak_scale_normalized != 0;
@@ -1761,7 +1763,7 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     a.walk_chunks = (ctx->det_cand_cap + 511) / 512;
     if ((rc = ensure(ctx, ctx->det_walk_list, cands * sizeof(int32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_walk_count, (size_t)batch * a.walk_chunks * sizeof(int32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->det_cand_cells, cands * 128))) return rc;
+    if ((rc = ensure(ctx, ctx->det_cand_cells, cands * 64))) return rc;
     if ((rc = ensure(ctx, ctx->det_tie_list, cands * 8))) return rc;
     if ((rc = ensure(ctx, ctx->det_tie_count, (size_t)batch * a.walk_chunks * sizeof(int32_t)))) return rc;
     // one buffer, one fill: the call's running keypoint total (16 bytes) and the per-row counts
@@ -1823,7 +1825,7 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
 int det_batch(const mofreak_ctx *ctx, const DetGeom &g, int n_pairs)
 {
     const size_t per_pair = 4 * (size_t)g.plane_bytes + (size_t)g.mask_words * 8 +
-                            (size_t)ctx->det_cand_cap * (sizeof(uint32_t) + 3 + 12 + sizeof(DetResult) + sizeof(int32_t) + 128);
+                            (size_t)ctx->det_cand_cap * (sizeof(uint32_t) + 3 + 12 + sizeof(DetResult) + sizeof(int32_t) + 64 + 8);
     const size_t b = std::max<size_t>(1, ((size_t)8 << 30) / per_pair);
     return (int)std::min<size_t>({b, (size_t)std::max(n_pairs, 1), (size_t)16384});
 }

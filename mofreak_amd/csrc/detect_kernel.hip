@@ -801,7 +801,6 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
                 a.cand_flag[cbase + idx] = flag;
                 a.cand_emit[cbase + idx] = 0;
                 a.cand_spec[cbase + idx] = flag == kDetTie ? kWasTie : 0;
-                a.cand_asked[cbase + idx] = 0ull;
                 if (flag == kDetTie) a.status[plane + (int64_t)y * L.w + x] = kStPending;
             }
         }
@@ -814,16 +813,17 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetArgs a)
 // is computed here where the reference computes it: for the cells a refinement walk can ask for.  A walk reads at most
 // 5 x 5 cells of a neighbouring layer, from the corner ((int)x_1 - 1, (int)y_1 - 1) of getScoreMaxAbove/Below's sampling
 // square (patch and tie rings included), and its own 3 x 3 patch.  det_window_kernel scores those cells -- a thread per
-// (walker, window), the 11 x 11 image bytes behind a window held in registers -- into a 128-byte record per walker;
+// (walker, window), the 11 x 11 image bytes behind a window held in registers -- into a 64-byte record per walker;
 // det_walk_kernel copies the record's windows into the thread's LDS and walks on them (the walk itself is a chain of
 // data-dependent early exits: cell by cell on global memory it would pay a latency per step).
 constexpr int kWinSide = 6, kWinRow = 8, kWinBytes = 48;   // a window in LDS: 6 rows of 8 bytes (5 x 5 cells are filled; a walk that asks for more is reported)
 constexpr int kWinCells = 5;
 constexpr int kPatchRows = kWinCells + 6;                   // image rows oy - 3 .. oy + 7, 16 bytes from column ox - 3
 constexpr int kWinStride = 2 * kWinBytes + 4;               // 100 bytes = 25 dwords per thread: odd, neighbouring threads on different banks
-// a walker's record: the 5 x 5 cells of the window above (5 rows of 8 bytes), of the window below, the own 3 x 3 patch
-// (first index x) and, on layer 0, the nine 5/8 scores of the guessed layer below
-constexpr int kRecBytes = 128, kRecAbove = 0, kRecBelow = 40, kRecOwn = 80, kRec58 = 96;
+// a walker's record, one 64-byte line: dwords 0..3 the 4 x 4 cells of the window above (a row each), 4..8 the first four
+// cells of the five rows of the window below, 9..10 their fifth cells (a byte each), 11..15 the own 3 x 3 patch (nine bytes,
+// first index x) and behind it, on layer 0, the nine 5/8 scores of the guessed layer below
+constexpr int kRecBytes = 64, kRecBelowDw = 4, kRecBelowHiDw = 9, kRecOwnDw = 11;
 struct Window {
     uint8_t *cells;
     int ox, oy, layer, side;  // side: cells per row and column that are filled (4 above, 5 below: window_place)
@@ -1435,25 +1435,25 @@ __device__ __forceinline__ void finish_candidate(const DetArgs &a, const PairVie
 // maxima without ties: independent of everything else; ties: refined ahead of their decision
 constexpr int kRefineChunk = 512;  // candidates per workgroup
 
-// the SIDE x SIDE cells of window w from the image bytes behind it, a row of eight bytes at a time into the walker's record
+// the SIDE x SIDE cells of window w from the image bytes behind it: the first four cells of a row in lo, the fifth in hi
 template <int SIDE>
-__device__ __forceinline__ void window_scores(const Patch &q, const DetLayer &L, const Window &w, uint2 *d)
+__device__ __forceinline__ void window_scores(const Patch &q, const DetLayer &L, const Window &w, uint32_t (&lo)[SIDE], uint32_t (&hi)[SIDE])
 {
 #pragma unroll
     for (int iy = 0; iy < SIDE; ++iy) {
         const int y = w.oy + iy;
         const bool row_in = y >= 3 && y < L.h - 3;
-        uint32_t lo = 0, hi = 0;
+        lo[iy] = 0;
+        hi[iy] = 0;
 #pragma unroll
         for (int ix = 0; ix < SIDE; ++ix) {
             const int x = w.ox + ix;
             const int sc = (row_in && x >= 3 && x < L.w - 3) ? patch_ring_score(q, iy + 3, ix + 3) : 0;
             if (ix < 4)
-                lo |= (uint32_t)sc << (8 * ix);
+                lo[iy] |= (uint32_t)sc << (8 * ix);
             else
-                hi = (uint32_t)sc;
+                hi[iy] = (uint32_t)sc;
         }
-        d[iy] = make_uint2(lo, hi);
     }
 }
 
@@ -1545,13 +1545,12 @@ __global__ __launch_bounds__(kDetThreads) void det_window_kernel(DetArgs a)
 #pragma unroll
                 for (int c = 0; c < 9; ++c) f[c >> 2] |= (uint32_t)patch_score_5_8(q, 5 + c % 3 - 1, 5 + c / 3 - 1) << (8 * (c & 3));
             }
-            uint32_t *d = reinterpret_cast<uint32_t *>(rec + kRecOwn);
+            uint32_t *d = reinterpret_cast<uint32_t *>(rec) + kRecOwnDw;  // bytes 0..8: the patch, 9..17: the 5/8 scores
             d[0] = o[0];
             d[1] = o[1];
-            d[2] = o[2];
-            d[(kRec58 - kRecOwn) / 4] = f[0];
-            d[(kRec58 - kRecOwn) / 4 + 1] = f[1];
-            d[(kRec58 - kRecOwn) / 4 + 2] = f[2];
+            d[2] = (o[2] & 0xffu) | f[0] << 8;
+            d[3] = f[0] >> 24 | f[1] << 8;
+            d[4] = f[1] >> 24 | (f[2] & 0xffu) << 8;
             continue;
         }
         const bool above = part == 0;
@@ -1563,11 +1562,19 @@ __global__ __launch_bounds__(kDetThreads) void det_window_kernel(DetArgs a)
             window_place<false>(w, layer, px, py);
         const DetLayer &L = v.g->L[w.layer];
         const Patch q = patch_fetch(v.img, L, w.ox - 3, w.oy - 3);
-        uint2 *d = reinterpret_cast<uint2 *>(rec + (above ? kRecAbove : kRecBelow));
-        if (above)
-            window_scores<kWinCells - 1>(q, L, w, d);
-        else
-            window_scores<kWinCells>(q, L, w, d);
+        uint32_t *d = reinterpret_cast<uint32_t *>(rec);
+        if (above) {
+            uint32_t lo[kWinCells - 1], hi[kWinCells - 1];
+            window_scores<kWinCells - 1>(q, L, w, lo, hi);
+            *reinterpret_cast<uint4 *>(d) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        } else {
+            uint32_t lo[kWinCells], hi[kWinCells];
+            window_scores<kWinCells>(q, L, w, lo, hi);
+#pragma unroll
+            for (int iy = 0; iy < kWinCells; ++iy) d[kRecBelowDw + iy] = lo[iy];
+            d[kRecBelowHiDw] = hi[0] | hi[1] << 8 | hi[2] << 16 | hi[3] << 24;
+            d[kRecBelowHiDw + 1] = hi[4];
+        }
     }
 }
 
@@ -1595,26 +1602,28 @@ __global__ __launch_bounds__(kDetThreads) void det_walk_kernel(DetArgs a)
         const uint32_t xy = a.cand_xy[cb + i];
         const uint8_t flag = a.cand_flag[cb + i];
         const uint4 *rec = reinterpret_cast<const uint4 *>(a.cand_cells + (cb + c0 + k) * kRecBytes);
-        uint4 r[7];
+        uint4 r[4];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) r[j] = rec[j];  // 112 of the record's 128 bytes: windows, own patch, 5/8 scores
+        for (int j = 0; j < 4; ++j) r[j] = rec[j];  // the record: one line
         int layer = 0;
 #pragma unroll
         for (int l = 1; l < kDetMaxLayers; ++l) layer += i >= ls_s[l] ? 1 : 0;
-        // record rows of 8 bytes -> window rows of 8 bytes (rows 5 of the windows are never read: a walk that leaves the 5 x 5 cells is reported)
+        // record -> window rows of 8 bytes (above: four cells a row, below: four and one; the rest of a window is never read: a
+        // walk that leaves the filled cells is reported)
         uint32_t *cw = reinterpret_cast<uint32_t *>(cells);
-        const uint32_t words[28] = {r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, r[1].z, r[1].w, r[2].x, r[2].y, r[2].z, r[2].w, r[3].x, r[3].y,
-                                    r[3].z, r[3].w, r[4].x, r[4].y, r[4].z, r[4].w, r[5].x, r[5].y, r[5].z, r[5].w, r[6].x, r[6].y, r[6].z, r[6].w};
+        const uint32_t words[16] = {r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, r[1].z, r[1].w, r[2].x, r[2].y, r[2].z, r[2].w, r[3].x, r[3].y, r[3].z, r[3].w};
 #pragma unroll
-        for (int j = 0; j < 10; ++j) {
-            cw[j] = words[j];                       // above: record bytes 0..39 -> window bytes 0..39
-            cw[kWinBytes / 4 + j] = words[10 + j];  // below: record bytes 40..79
+        for (int iy = 0; iy < kWinCells - 1; ++iy) cw[2 * iy] = words[iy];
+#pragma unroll
+        for (int iy = 0; iy < kWinCells; ++iy) {
+            cw[kWinBytes / 4 + 2 * iy] = words[kRecBelowDw + iy];
+            cw[kWinBytes / 4 + 2 * iy + 1] = (words[kRecBelowHiDw + (iy >> 2)] >> (8 * (iy & 3))) & 0xffu;
         }
         int own_patch[9], s58[9];
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
-            own_patch[c] = (int)((words[20 + (c >> 2)] >> (8 * (c & 3))) & 0xff);
-            s58[c] = (int)((words[24 + (c >> 2)] >> (8 * (c & 3))) & 0xff);
+            own_patch[c] = (int)((words[kRecOwnDw + (c >> 2)] >> (8 * (c & 3))) & 0xff);
+            s58[c] = (int)((words[kRecOwnDw + ((9 + c) >> 2)] >> (8 * ((9 + c) & 3))) & 0xff);
         }
         finish_candidate<Fp<X87>>(a, v, cells, own_patch, s58, p, i, layer, (int)(xy & 0xffff), (int)(xy >> 16), flag != kDetMax);
     }

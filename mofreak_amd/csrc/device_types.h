@@ -22,6 +22,9 @@ struct SmallTables {
     int32_t mip_theta;
     int32_t mip_n_cur, mip_n_prev;  // entries of the two lists below
     int32_t pad[1];
+    // which of the 43 pattern points the orientation pairs / the 64 description pairs read (bit = point): the gather path leaves the
+    // others' boxes alone (the default tables: all but point 42; 39 points)
+    unsigned long long need_orient, need_bits;
     // the 19x19 positions the MIP reads of the current / previous buffer (ascending): the gather path resamples only these
     uint16_t mip_cur[64];
     uint16_t mip_prev[256];
@@ -241,11 +244,11 @@ struct DetArgs {
     unsigned long long *cand_asked;         // [n_pairs][cand_cap] cells a walk asked for in the layer above (bit mask over a 6 x 6 window; 0: none)
     uint32_t *cand_win;                     // [n_pairs][cand_cap] that window's origin, x | y << 16
     // refinement: chunk c of 512 candidates has walk_count[c] walkers (maxima and ties); walker k of the chunk is candidate
-    // walk_list[512 c + k] and owns the 128-byte record cand_cells[512 c + k] (the cells its walks can read)
+    // walk_list[512 c + k] and owns the 64-byte record cand_cells[512 c + k] (the cells its walks can read)
     int32_t *walk_list;                     // [n_pairs][cand_cap]
     int32_t *walk_count;                    // [n_pairs][walk_chunks]
     int32_t walk_chunks;
-    uint8_t *cand_cells;                    // [n_pairs][cand_cap][128]
+    uint8_t *cand_cells;                    // [n_pairs][cand_cap][64]
     // the ties among a chunk's walkers, in candidate order: tie k of chunk c is tie_list[512 c + k]
     DetTie *tie_list;                       // [n_pairs][cand_cap]
     int32_t *tie_count;                     // [n_pairs][walk_chunks]

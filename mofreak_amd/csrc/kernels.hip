@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256, 5) void describe_kernel(DescribeArgs a)
             theta = 0;
             if (st.orientation_normalized) {
                 int v0 = 0;
-                if (lane < kNbPoints) v0 = mean_intensity(integ, a.pitch, kx, ky, lut_scale[lane]);
+                if ((st.need_orient >> lane) & 1) v0 = mean_intensity(integ, a.pitch, kx, ky, lut_scale[lane]);  // (bits 43.. are clear)
                 int t0 = 0, t1 = 0;
                 {
                     const OrientPair op = st.orient[lane < kNbOrientPairs ? lane : 0];
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256, 5) void describe_kernel(DescribeArgs a)
                 theta = theta_index(s_theta, direction0, direction1);
             }
             int v = 0;
-            if (lane < kNbPoints) v = mean_intensity(integ, a.pitch, kx, ky, lut_scale[theta * kNbPoints + lane]);
+            if ((st.need_bits >> lane) & 1) v = mean_intensity(integ, a.pitch, kx, ky, lut_scale[theta * kNbPoints + lane]);
             {
                 const int va = __shfl(v, (int)st.bit_pair_i[lane]);
                 const int vb = __shfl(v, (int)st.bit_pair_j[lane]);
