@@ -43,7 +43,7 @@ calls = 3  # probe: 1 warm-up + 2 timed calls of 32 pairs
 names = sorted({c for k in tot for c in tot[k]})
 with open(f'gpurun_out/{tag}_detector_pmc.csv', 'w') as fh:
     # FETCH_SIZE counts a coalesced read at half its bytes and a scattered 64-byte fetch exactly (profiles/r03_fetch_calibration.txt)
-    scattered = {'describe_kernel', 'det_window_kernel', 'det_walk_kernel', 'det_tie_kernel', 'det_candidates_kernel'}
+    scattered = {'describe_kernel', 'det_window_kernel', 'det_walk_kernel', 'det_tie_kernel', 'det_tie_first_kernel', 'det_candidates_kernel'}
     fh.write('kernel,launches_per_call,' + ','.join(f'{c}_per_call' for c in names) + ',valu_busy,lds_busy,wait_any_over_wave_cycles,hbm_MB_per_call,hbm_MB_per_call_fetch_x1,hbm_MB_per_call_fetch_x2,fetch_shape\n')
     for k in sorted(tot, key=lambda k: -tot[k].get('SQ_BUSY_CU_CYCLES', 0)):
         c = tot[k]

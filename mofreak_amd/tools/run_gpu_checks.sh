@@ -1,8 +1,19 @@
+# The round's final measurements on the GPU box, in two gpurun calls (a call is limited to 20 minutes):
+#   bash mofreak_amd/tools/run_gpu_checks.sh 1   tests, the tile kernel's profile + counters, the default bench line, the detector's profile
+#   (copy gpurun_out/r04_traffic.json to profiles/traffic.json and profiles/r04_traffic.json)
+#   bash mofreak_amd/tools/run_gpu_checks.sh 2   the other bench lines, the C2 counter pass, the fuzz tool on both builds, smoke()
 set -x
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out/r4
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+if [ "${1:-1}" = "1" ]; then
+timeout -k 10 400 python -m pytest tests -x -q -m gpu > gpurun_out/r4/final_tests.log 2>&1; echo tests rc=$?; tail -n 2 gpurun_out/r4/final_tests.log
+timeout -k 10 500 bash mofreak_amd/tools/profile_tile.sh r04 > gpurun_out/r4/final_profile_tile.log 2>&1; echo tile prof rc=$?
+cp gpurun_out/r04_traffic.json profiles/traffic.json  # (on the box; the same copy is made in the repo afterwards)
+timeout -k 10 300 python bench.py > gpurun_out/r4/final_bench_default.json 2> gpurun_out/r4/final_bench_default.err; echo rc=$?
 timeout -k 10 600 bash mofreak_amd/tools/profile_detector.sh r04 > gpurun_out/r4/final_profile_detector.log 2>&1; echo det prof rc=$?
+exit 0
+fi
 timeout -k 10 250 python bench.py --no-detector --no-cpu-baseline --steps 50 > gpurun_out/r4/final_bench_counters.json 2> /dev/null; echo rc=$?
 timeout -k 10 250 python bench.py --gpus 1 --backend nccl --force-dist --steps 20 > gpurun_out/r4/final_bench_nccl_n1.json 2> gpurun_out/r4/final_bench_nccl_n1.err; echo rc=$?
 timeout -k 10 250 python bench.py --gpus 2 --backend gloo --share-device --pairs 64 > gpurun_out/r4/final_bench_n2.json 2> gpurun_out/r4/final_bench_n2.err; echo rc=$?
@@ -31,3 +42,6 @@ open('gpurun_out/r4/final_c2_traffic.txt', 'w').write(f"C2 (1000 pairs 640x480, 
 print(open('gpurun_out/r4/final_c2_traffic.txt').read())
 PY
 rm -rf gpurun_out/r4/c2pmc_*
+timeout -k 10 260 python tests/fuzz_parity_gpu.py 200 121 > gpurun_out/r4/final_fuzz121.log 2>&1; echo fuzz rc=$?; tail -n 1 gpurun_out/r4/final_fuzz121.log
+MOFREAK_HIP_LIBRARY=mofreak_amd/libmofreak_hip_debug.so timeout -k 10 260 python tests/fuzz_parity_gpu.py 200 122 > gpurun_out/r4/final_fuzz122.log 2>&1; echo fuzz debug rc=$?; tail -n 1 gpurun_out/r4/final_fuzz122.log
+timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r4/final_smoke.log 2>&1; echo smoke rc=$?; tail -n 1 gpurun_out/r4/final_smoke.log
