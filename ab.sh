@@ -1,7 +1,8 @@
 mkdir -p gpurun_out/r4
-timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r4/all_tests.log 2>&1; echo product rc=$?
-tail -n 3 gpurun_out/r4/all_tests.log
-python mofreak_amd/tools/detector_probe.py 32 10 describe
-python mofreak_amd/tools/detector_probe.py 128 6 describe
+timeout -k 10 400 python -m pytest tests/test_detector_gpu.py -x -q -m gpu > gpurun_out/r4/tie_tests.log 2>&1; echo product rc=$?
+MOFREAK_HIP_LIBRARY=mofreak_amd/libmofreak_hip_debug.so timeout -k 10 400 python -m pytest tests/test_detector_gpu.py -x -q -m gpu > gpurun_out/r4/tie_tests_debug.log 2>&1; echo debug rc=$?
+tail -n 3 gpurun_out/r4/tie_tests.log gpurun_out/r4/tie_tests_debug.log
+python mofreak_amd/tools/detector_probe.py 32 10
+python mofreak_amd/tools/detector_probe.py 32 10
+python mofreak_amd/tools/detector_probe.py 128 6
 python mofreak_amd/tools/detector_probe.py 128 6 loop
-python mofreak_amd/tools/detector_probe.py 256 4 loop

@@ -1771,7 +1771,7 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     if ((rc = ensure(ctx, ctx->det_rows, 16 + n_row_counts * sizeof(int32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_cand_xy, cands * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_cand_flag, cands + 64))) return rc;  // (read sixteen at a time)
-    if ((rc = ensure(ctx, ctx->det_cand_emit, cands))) return rc;
+    if ((rc = ensure(ctx, ctx->det_cand_emit, cands + 64))) return rc;  // (read sixteen at a time)
     if ((rc = ensure(ctx, ctx->det_cand_spec, cands))) return rc;
     if ((rc = ensure(ctx, ctx->det_cand_asked, cands * sizeof(unsigned long long)))) return rc;
     if ((rc = ensure(ctx, ctx->det_cand_win, cands * sizeof(uint32_t)))) return rc;
@@ -1907,12 +1907,9 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
         a.n_pairs = np;
         a.first_pair = p0;
         a.f = FrameArgs{d_cur + (int64_t)p0 * pair_stride, d_prev ? d_prev + (int64_t)p0 * pair_stride : nullptr, W, H, row_stride, pair_stride};
-        // the counters of the batch (and, in front of them, the call's running total before its first batch); the touch
-        // and status maps are zero already (det_workspace) and are left zero by the emission
-        if (p0 == 0)
-            HIP_TRY(ctx, hipMemsetAsync(running, 0, 16 + ctx->det_counter_bytes, ctx->stream));
-        else
-            HIP_TRY(ctx, hipMemsetAsync(a.row_count, 0, ctx->det_counter_bytes, ctx->stream));
+        // (the counters of the batch and, in front of them, the call's running total and status word before its first batch are
+        // zeroed by the batch's first kernel; the touch and status maps are zero already (det_workspace) and are left zero by
+        // the emission)
         int e = launch_det_pyramid(a, ctx->stream);
         if (!e) e = launch_det_corners(a, ctx->stream);
         if (!e) e = launch_det_keypoints(a, running, ctx->stream);

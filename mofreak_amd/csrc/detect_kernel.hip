@@ -92,8 +92,19 @@ __device__ __forceinline__ unsigned long long load8(const uint8_t *p)
 }
 
 // ------------------------------------------------------------------ pyramid
+// The batch's counters -- per-row corner counts of every pair -- are zeroed by the first kernel of the batch (and, before a call's
+// first batch, the running keypoint total and the status word in front of them): nobody counts before det_corner_kernel.
+__device__ __forceinline__ void zero_batch_counters(const DetArgs &a, int total_rows)
+{
+    const int64_t n = (int64_t)a.n_pairs * (total_rows + 1);
+    const int64_t bid = blockIdx.x + (int64_t)gridDim.x * (blockIdx.y + (int64_t)gridDim.y * blockIdx.z), n_blocks = (int64_t)gridDim.x * gridDim.y * gridDim.z;
+    for (int64_t i = bid * kDetThreads + threadIdx.x; i < n; i += n_blocks * kDetThreads) a.row_count[i] = 0;
+    if (bid == 0 && threadIdx.x < 4 && a.first_pair == 0) (a.row_count - 4)[threadIdx.x] = 0;
+}
+
 __global__ __launch_bounds__(kDetThreads) void det_diff_kernel(DetArgs a)
 {
+    zero_batch_counters(a, a.dg->total_rows);
     const int p = blockIdx.y;
     const int W = a.dg->L[0].w, H = a.dg->L[0].h;
     const int per_row = (W + 15) / 16, t = blockIdx.x * kDetThreads + threadIdx.x;  // 16-pixel pieces, row after row
@@ -324,6 +335,7 @@ __device__ __forceinline__ void half_band(const uint8_t *src, int src_pitch, int
 __global__ __launch_bounds__(kDetThreads) void det_pyramid_fused_kernel(DetArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t band_lds[];
+    zero_batch_counters(a, a.g.total_rows);
     const int p = blockIdx.y, band = blockIdx.x, n_layers = a.g.n_layers;
     const PyrBand B = pyr_band(a.g);  // from the argument block: scalar arithmetic
     uint8_t *plane = a.img + (int64_t)p * a.g.plane_bytes;
@@ -688,7 +700,6 @@ __global__ __launch_bounds__(kDetThreads) void det_scan_kernel(DetArgs a)
     __syncthreads();
     if (threadIdx.x == kDetThreads - 1) {
         const int total = part[kDetThreads - 1];
-        a.emit_count[p] = 0;  // summed up by det_emit_count_kernel
         rc[n] = total;
         if (total > a.cand_cap) atomicOr(a.status_word, 4);
     }
@@ -1876,6 +1887,7 @@ __global__ __launch_bounds__(kDetThreads) void det_tie_first_kernel(DetArgs a)
 // inside the workgroup -- one CU, one vector cache -- so workgroup-scope ordering is all it takes, and all the waves
 // involved are resident.
 constexpr int kTieThreads = 512, kTieWaves = kTieThreads / 64;
+constexpr int kEmitChunk = 1024;  // candidates per chunk of the ordered emission
 #ifdef MOFREAK_DEBUG_BOUNDS
 constexpr int kTieListCap = 64, kDetWaitCap = 8, kTieChunksMax = 16;  // the debug build overflows all three on every tie-heavy image: the fallbacks get tested
 #else
@@ -2052,32 +2064,49 @@ __global__ __launch_bounds__(kTieThreads) void det_tie_kernel(DetArgs a)
         }
         __syncthreads();  // the layer is through (its threads' last decisions included); the waiting list is free again
     }
-}
-
-// ------------------------------------------------------------------ ordered emission
-// The candidates of a pair in chunks of kEmitChunk, one workgroup per chunk: how many of each chunk are emitted
-// (and, summed up, of the pair); det_emit_scatter_kernel places a chunk behind the chunks before it.
-constexpr int kEmitChunk = 1024;
-
-__global__ __launch_bounds__(kDetThreads) void det_emit_count_kernel(DetArgs a)
-{
-    __shared__ int total;
-    const int p = blockIdx.y, c = blockIdx.x;
-    const int n = a.layer_start[(int64_t)p * (kDetMaxLayers + 1) + a.dg->n_layers];
-    if (c * kEmitChunk >= n) return;
-    if (threadIdx.x == 0) total = 0;
-    __syncthreads();
-    int cnt = 0;
-    for (int i = c * kEmitChunk + threadIdx.x; i < min(n, (c + 1) * kEmitChunk); i += kDetThreads) cnt += a.cand_emit[(int64_t)p * a.cand_cap + i];
-    cnt = wave_sum(cnt);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&total, cnt);
+    // ---- how many of each chunk of kEmitChunk candidates are emitted, and of the pair (det_emit_scan / scatter place the chunks):
+    //      the flags are final now; a wave per chunk, sixteen flag bytes (0 or 1) per lane
+    static_assert(kEmitChunk == 64 * 16, "a wave reads a chunk's flags in one go");
+    const int n = ls_s[n_layers];
+    int mine = 0;
+    for (int c0 = wave; c0 * kEmitChunk < n; c0 += 4 * kTieWaves) {
+        uint4 f[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // (the flag array is padded: a load may run past n, never past the buffer)
+            const int i = min((c0 + u * kTieWaves) * kEmitChunk + lane * 16, n);
+            __builtin_memcpy(&f[u], a.cand_emit + cb + i, 16);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * kTieWaves, i = c * kEmitChunk + lane * 16;
+            if (c * kEmitChunk >= n) break;  // wave-uniform
+            const int valid = min(max(n - i, 0), 16);  // bytes of this lane's sixteen that are candidates
+            const uint32_t w[4] = {f[u].x, f[u].y, f[u].z, f[u].w};
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int vb = min(max(valid - 4 * q, 0), 4);
+                const uint32_t m = vb >= 4 ? 0xffffffffu : (1u << (8 * vb)) - 1u;
+                cnt = __builtin_amdgcn_udot4(w[q] & m, 0x01010101u, cnt, false);
+            }
+            const int total = wave_sum((int)cnt);
+            if (lane == 0) a.emit_chunks[(int64_t)p * a.emit_chunk_cap + c] = total;
+            mine += total;
+        }
+    }
+    if (lane == 0) wave_tot[wave] = mine;  // (the prologue's slots)
     __syncthreads();
     if (threadIdx.x == 0) {
-        a.emit_chunks[(int64_t)p * a.emit_chunk_cap + c] = total;
-        atomicAdd(&a.emit_count[p], total);  // zeroed by det_scan_kernel
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < kTieWaves; ++w) total += wave_tot[w];
+        a.emit_count[p] = total;
     }
 }
 
+// ------------------------------------------------------------------ ordered emission
+// The candidates of a pair in chunks of kEmitChunk: det_tie_kernel has counted how many of each chunk are emitted (and,
+// summed up, of the pair); det_emit_scatter_kernel places a chunk behind the chunks before it.
 // one workgroup: CSR offsets of the batch's pairs, continuing the running total of the call
 __global__ __launch_bounds__(kDetThreads) void det_emit_scan_kernel(DetArgs a, int64_t *running)
 {
@@ -2254,7 +2283,6 @@ int launch_det_keypoints(const DetArgs &a, int64_t *running, void *stream)
     hipLaunchKernelGGL(det_tie_first_kernel, dim3(std::min(a.walk_chunks, 64), a.n_pairs), dim3(kDetThreads), 0, s, a);  // layer 0 at first sight
     hipLaunchKernelGGL(det_tie_kernel, dim3(a.n_pairs), dim3(kTieThreads), 0, s, a);  // every layer's ties, layer after layer
     const dim3 egrid((a.cand_cap + kEmitChunk - 1) / kEmitChunk, a.n_pairs);
-    hipLaunchKernelGGL(det_emit_count_kernel, egrid, dim3(kDetThreads), 0, s, a);
     hipLaunchKernelGGL(det_emit_scan_kernel, dim3(1), dim3(kDetThreads), 0, s, a, running);
     hipLaunchKernelGGL(det_emit_scatter_kernel, egrid, dim3(kDetThreads), 0, s, a);
     return (int)hipGetLastError();
