@@ -1,8 +1,4 @@
 mkdir -p gpurun_out/r4
-timeout -k 10 400 python -m pytest tests/test_detector_gpu.py -x -q -m gpu > gpurun_out/r4/tie_tests.log 2>&1; echo product rc=$?
-MOFREAK_HIP_LIBRARY=mofreak_amd/libmofreak_hip_debug.so timeout -k 10 400 python -m pytest tests/test_detector_gpu.py -x -q -m gpu > gpurun_out/r4/tie_tests_debug.log 2>&1; echo debug rc=$?
-tail -n 3 gpurun_out/r4/tie_tests.log gpurun_out/r4/tie_tests_debug.log
-python mofreak_amd/tools/detector_probe.py 32 10
-python mofreak_amd/tools/detector_probe.py 32 10
-python mofreak_amd/tools/detector_probe.py 128 6
-python mofreak_amd/tools/detector_probe.py 128 6 loop
+timeout -k 10 250 python bench.py --gpus 2 --backend gloo --share-device --pairs 64 > gpurun_out/r4/final_bench_n2.json 2> gpurun_out/r4/final_bench_n2.err; echo rc=$?
+timeout -k 10 250 python bench.py --config C4 --gpus 2 --backend gloo --share-device > gpurun_out/r4/final_bench_c4_n2.json 2> /dev/null; echo rc=$?
+timeout -k 10 400 python -m pytest tests/test_dataset_gpu.py tests/test_rccl_gpu.py tests/test_facade.py -x -q -m gpu > gpurun_out/r4/port_tests.log 2>&1; echo rc=$?; tail -n 2 gpurun_out/r4/port_tests.log

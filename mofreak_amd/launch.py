@@ -27,6 +27,20 @@ def launched_by_a_launcher() -> bool:
 
 
 def free_port() -> int:
+    """A port rank 0's store can listen on.  Not simply bind(0): the kernel hands out a port again while connections of the
+    job that had it a moment ago are still in TIME_WAIT (back-to-back runs), and a listener without SO_REUSEADDR -- the
+    store's -- is then refused.  A port picked at random that takes a plain bind + listen has no such leftovers."""
+    import random
+    rng = random.Random(os.getpid() ^ time.monotonic_ns())
+    for _ in range(64):
+        port = rng.randrange(20000, 60000)
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            try:
+                s.bind(("127.0.0.1", port))
+                s.listen(1)
+            except OSError:
+                continue
+            return port
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]

@@ -2,7 +2,6 @@
 size-12 keypoints per pair): harness.run_dataset = shard -> extract -> gather -> rank 0 writes ordered .mofreak text
 (main.cpp:854-924).  Needs a GPU; the two-rank case shares device 0 over gloo."""
 import os
-import socket
 
 import numpy as np
 import pytest
@@ -11,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import mofreak_amd as M
-from mofreak_amd import harness, synth
+from mofreak_amd import harness, synth, launch
 
 pytestmark = pytest.mark.gpu
 
@@ -88,11 +87,7 @@ def test_mixed_frame_sizes_and_bounded_rounds(oracle, tmp_path):
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    return launch.free_port()  # (a port without TIME_WAIT leftovers of the test before)
 
 
 def _worker(rank, world, port, out_dir):

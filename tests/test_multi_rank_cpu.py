@@ -3,7 +3,6 @@
 The data path has no collective (videos are independent); the only exchange is gather_rows, which is the
 same code for gloo on CPU tensors and RCCL on device tensors."""
 import os
-import socket
 
 import numpy as np
 import pytest
@@ -11,15 +10,11 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from mofreak_amd import api, harness
+from mofreak_amd import api, harness, launch
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    return launch.free_port()  # (a port without TIME_WAIT leftovers of the test before)
 
 
 def _rows_for_rank(rank: int, n: int) -> np.ndarray:

@@ -5,11 +5,12 @@ Two ranks cannot share one GPU under RCCL; world size 1 runs the same collective
 import json
 import os
 import signal
-import socket
 import subprocess
 import sys
 
 import pytest
+
+from mofreak_amd import launch
 
 pytestmark = pytest.mark.gpu
 
@@ -17,11 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    return launch.free_port()  # (a port without TIME_WAIT leftovers of the test before)
 
 
 @pytest.fixture(scope="module")
