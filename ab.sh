@@ -1,4 +1,3 @@
 mkdir -p gpurun_out/r4
-timeout -k 10 250 python bench.py --gpus 2 --backend gloo --share-device --pairs 64 > gpurun_out/r4/final_bench_n2.json 2> gpurun_out/r4/final_bench_n2.err; echo rc=$?
-timeout -k 10 250 python bench.py --config C4 --gpus 2 --backend gloo --share-device > gpurun_out/r4/final_bench_c4_n2.json 2> /dev/null; echo rc=$?
-timeout -k 10 400 python -m pytest tests/test_dataset_gpu.py tests/test_rccl_gpu.py tests/test_facade.py -x -q -m gpu > gpurun_out/r4/port_tests.log 2>&1; echo rc=$?; tail -n 2 gpurun_out/r4/port_tests.log
+MOFREAK_HIP_LIBRARY=mofreak_amd/libmofreak_hip_debug.so timeout -k 10 500 python -m pytest tests -q -m gpu > gpurun_out/r4/all_tests_debug.log 2>&1; echo debug-all rc=$?; tail -n 5 gpurun_out/r4/all_tests_debug.log
+timeout -k 10 640 python tests/fuzz_parity_gpu.py 600 131 > gpurun_out/r4/final_fuzz131.log 2>&1; echo fuzz rc=$?; tail -n 1 gpurun_out/r4/final_fuzz131.log
