@@ -1,3 +1,15 @@
 mkdir -p gpurun_out/r4
-MOFREAK_HIP_LIBRARY=mofreak_amd/libmofreak_hip_debug.so timeout -k 10 500 python -m pytest tests -q -m gpu > gpurun_out/r4/all_tests_debug.log 2>&1; echo debug-all rc=$?; tail -n 5 gpurun_out/r4/all_tests_debug.log
-timeout -k 10 640 python tests/fuzz_parity_gpu.py 600 131 > gpurun_out/r4/final_fuzz131.log 2>&1; echo fuzz rc=$?; tail -n 1 gpurun_out/r4/final_fuzz131.log
+timeout -k 10 400 python -m pytest tests/test_detector_gpu.py -x -q -m gpu > gpurun_out/r4/tie_tests.log 2>&1; echo product rc=$?
+MOFREAK_HIP_LIBRARY=mofreak_amd/libmofreak_hip_debug.so timeout -k 10 400 python -m pytest tests/test_detector_gpu.py -x -q -m gpu > gpurun_out/r4/tie_tests_debug.log 2>&1; echo debug rc=$?
+tail -n 3 gpurun_out/r4/tie_tests.log gpurun_out/r4/tie_tests_debug.log
+python mofreak_amd/tools/detector_probe.py 32 10
+python mofreak_amd/tools/detector_probe.py 128 6
+python mofreak_amd/tools/detector_probe.py 128 6 loop
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r4/tieprof -- python3 mofreak_amd/tools/detector_probe.py 128 7 > /dev/null 2>&1
+python3 - <<'PY'
+import glob, csv
+for f in glob.glob('gpurun_out/r4/tieprof/*/*kernel_stats.csv'):
+    for r in csv.DictReader(open(f)):
+        if 'det_' in r['Name']: print(r['Name'][:70], r['Calls'], round(float(r['AverageNs'])/1e3,1))
+PY
