@@ -4,29 +4,35 @@
 // BriskScaleSpace::constructPyramid + getKeypoints (brisk.cpp:572-704) with the OAST 9/16 detector and the
 // AGAST 5/8 score behind them (oast9_16.cc:46, oast9_16_nms.cc:42, agast5_8_nms.cc:42).
 //
-// The reference walks its candidates one by one, asks for corner scores lazily and caches them; this design turns
-// that inside out so that every step is data parallel, and keeps the reference's results bit for bit:
+// The reference walks its candidates one by one, asks for corner scores lazily and caches them; which scores are in the
+// cache when a tie is broken decides the tie.  Here every step is data parallel and scores are computed where the reference
+// computes them -- at corners, and in the cells refinement walks read -- with the reference's results bit for bit:
 //
-//   pyramid     difference image, then the 2/3 and 1/2 resamplers as closed forms of their SSE sequences
-//               (every output byte depends on which part of the SIMD loop produced it: main blocks, the odd
-//               block, the scalar tail), one thread per output pixel
-//   scores      the corner score of EVERY pixel of every layer in one pass: the bisection around the decision
-//               tree evaluates "largest b for which some arc of 9 ring pixels is all brighter than c+b or all
-//               darker than c-b", which is max over arcs of the arc's smallest |difference|, minus one
-//   candidates  pixels with score >= threshold in raster order per layer (counted per row while scoring, scanned,
-//               scattered by one wave per row), classified by the strict part of isMax2D
-//   refinement  one thread per surviving candidate walks the layer above / below exactly as refine3D does, on
-//               the dense score maps
+//   pyramid     difference image, then the 2/3 and 1/2 resamplers as closed forms of their SSE sequences (every output byte
+//               depends on which part of the SIMD loop produced it: main blocks, the odd block, the scalar tail): all
+//               layers of a 12-row band in one launch, lower layers read from LDS (det_pyramid_fused_kernel; odd widths,
+//               very wide frames and octaves = 4: a kernel per layer)
+//   corners     det_corner_kernel: a necessary four-point test on every pixel (packed 16-bit, four pixels a lane), the
+//               survivors of a 64 x 64 tile compacted, the full score -- max over the 16 arcs of the arc's smallest
+//               |difference|, minus one: what the bisection around the decision tree converges to -- only for them;
+//               score plane (corner score or 0), a 64-bit hit mask per tile row, per-row counts
+//   candidates  the corners in raster order per layer straight from the hit masks (det_scan_kernel, det_candidates_kernel),
+//               classified by the strict part of isMax2D
+//   refinement  det_window_kernel scores the cells a walk can read (the windows above and below, the own patch) per walker
+//               from the image into a 64-byte record; det_walk_kernel walks on them exactly as refine3D does and
+//               publishes what it asked for in the layer above
 //   ties        isMax2D breaks ties on the reference's RAW score cache, which holds a score only where one has
 //               been asked for before -- so the outcome depends on the processing order.  Reproduced exactly:
 //               refinement marks the cells it asks for in the layer above ("touch" map), a maximum that reaches
 //               its own 3x3 patch marks itself ("status" map), and a tie is decided from score * (detected |
-//               touched from below | inside the patch of a raster-earlier maximum).  Ties that could depend on
-//               each other are resolved in rounds by one workgroup per pair, layer by layer.
+//               touched from below | inside the patch of a raster-earlier maximum).  Layer 0's ties take their first
+//               look chip-wide (det_tie_first_kernel); the rest -- and the ties that depend on each other -- are
+//               resolved by one workgroup per pair, layer after layer (det_tie_kernel).
 //   emission    ordered compaction in (layer, raster) order -- the order of the reference's keypoint vector, which
-//               the rows of a .mofreak file inherit.
+//               the rows of a .mofreak file inherit -- and every maximum and tie takes back the bytes it put into the
+//               two maps, which are all zero between calls.
 //
-// Integer/byte work bound by LDS and VALU issue, no MFMA.  Floating point mirrors the reference's expressions
+// Integer/byte work bound by vector issue and, in the tie kernels, by scattered line fetches; no MFMA.  Floating point mirrors the reference's expressions
 // (float vs double literals) one operation at a time; compile with -ffp-contract=off.
 #include <type_traits>
 
