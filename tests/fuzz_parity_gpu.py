@@ -4,7 +4,7 @@
 fractional coordinates, shared list or one list per pair), random byte frames or the synthetic ones, and compares
 descriptors and validity flags byte for byte; every few rounds also the detector's keypoints on a moving-object pair,
 a set of clips of random lengths through mofreak_extract_clips (against one call per clip), and the whole frame loop
-(mofreak_compute_stream) on two lanes against the one-lane loop.
+in one call (mofreak_compute_stream) against the detector and the descriptors in two.
 A new context every 20 s, a third of them with random FREAK parameters (bit mode, orientation / scale normalisation)."""
 import os
 import sys
