@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity run, GPU against the oracle (a tool, not part of the test suites: `python tests/fuzz_parity_gpu.py
-[seconds] [seed]` on a GPU box).  Every round draws a frame size, a keypoint population (counts, sizes, integer or
+[seconds] [seed] [detector]` on a GPU box; `detector`: detector rounds only, several pairs a call; a mismatch prints the
+frame size, octaves and frame seed that replay it: `python tests/fuzz_parity_gpu.py replay W H octaves frame_seed`).  Every round draws a frame size, a keypoint population (counts, sizes, integer or
 fractional coordinates, shared list or one list per pair), random byte frames or the synthetic ones, and compares
 descriptors and validity flags byte for byte; every few rounds also the detector's keypoints on a moving-object pair,
 a set of clips of random lengths through mofreak_extract_clips (against one call per clip), and the whole frame loop
@@ -21,9 +22,46 @@ import oracle_lib as O  # noqa: E402
 from mofreak_amd import synth  # noqa: E402
 
 
+def detector_case(ctx, Wd, Hd, octaves, frame_seed, n_pairs=1):
+    """The detector on n_pairs moving-object pairs against the oracle; None, or what differs."""
+    fr = synth.moving_objects_stack(5 + n_pairs, Wd, Hd, seed=frame_seed)
+    k, offs, resp, layer = ctx.detect_pairs_host(fr[5:], fr[:n_pairs], 30, octaves)
+    for p in range(n_pairs):
+        want = O.brisk_detect(O.absdiff(fr[5 + p], fr[p]), 30, octaves)
+        wk = np.stack([want["x"], want["y"], want["size"]], 1).astype(np.float32).reshape(-1, 3)
+        kp, rp = k[offs[p]:offs[p + 1]], resp[offs[p]:offs[p + 1]]
+        if not (len(kp) == len(wk) and kp.tobytes() == wk.tobytes() and rp.tobytes() == want["response"].tobytes()):
+            return f"{Wd}x{Hd} octaves {octaves} frame seed {frame_seed} pairs {n_pairs}, pair {p}: {len(kp)} vs {len(wk)} keypoints"
+    return None
+
+
+def detector_only(budget, seed):
+    rng = np.random.default_rng(seed)
+    t_end, runs, t_say = time.time() + budget, 0, time.time()
+    with M.Context(0) as ctx:
+        while time.time() < t_end:
+            Wd, Hd = int(rng.choice([160, 320, 481, 640])), int(rng.choice([120, 240, 360]))
+            bad = detector_case(ctx, Wd, Hd, int(rng.integers(0, 4)), int(rng.integers(0, 1 << 30)), int(rng.integers(1, 4)))
+            if bad:
+                print(f"DETECTOR MISMATCH run {runs} seed {seed}: {bad}")
+                sys.exit(1)
+            runs += 1
+            if time.time() - t_say > 30:
+                t_say = time.time()
+                print(f"... {runs} detector runs", flush=True)
+    print(f"fuzz ok: {runs} detector runs, seed {seed}")
+
+
 def main():
+    if len(sys.argv) > 5 and sys.argv[1] == "replay":
+        with M.Context(0) as ctx:
+            for n_pairs in (1, 2, 3):
+                print(n_pairs, detector_case(ctx, int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), n_pairs) or "equal")
+        return
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if len(sys.argv) > 3 and sys.argv[3] == "detector":
+        return detector_only(budget, seed)
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
     rounds = descriptors = detector_rounds = clip_rounds = loop_rounds = 0
@@ -65,13 +103,15 @@ def main():
               descriptors += n_pairs * n_kp
               if rounds % 5 == 0:
                   Wd, Hd = int(rng.choice([160, 320, 481, 640])), int(rng.choice([120, 240, 360]))
-                  fr = synth.moving_objects_stack(6, Wd, Hd, seed=int(rng.integers(0, 1 << 30)))
-                  octaves = int(rng.integers(0, 4))
-                  k, offs, resp, layer = ctx.detect_pairs_host(fr[5], fr[0], 30, octaves)
-                  want = O.brisk_detect(O.absdiff(fr[5], fr[0]), 30, octaves)
-                  wk = np.stack([want["x"], want["y"], want["size"]], 1).astype(np.float32).reshape(-1, 3)
-                  if not (len(k) == len(wk) and k.tobytes() == wk.tobytes() and resp.tobytes() == want["response"].tobytes()):
-                      print(f"DETECTOR MISMATCH round {rounds} seed {seed}: {Wd}x{Hd} octaves {octaves}: {len(k)} vs {len(wk)} keypoints")
+                  d_oct, d_seed = int(rng.integers(0, 4)), int(rng.integers(0, 1 << 30))
+                  bad = detector_case(ctx, Wd, Hd, d_oct, d_seed)
+                  if bad:
+                      print(f"DETECTOR MISMATCH round {rounds} seed {seed}: {bad}")
+                      # the same case again: in this context, then in a fresh one (is it the input, or the moment?)
+                      again = [detector_case(ctx, Wd, Hd, d_oct, d_seed) is not None for _ in range(5)]
+                      with M.Context(0) as fresh:
+                          anew = [detector_case(fresh, Wd, Hd, d_oct, d_seed) is not None for _ in range(5)]
+                      print(f"  replayed: same context {again}, fresh context {anew} (True = differs again)")
                       sys.exit(1)
                   detector_rounds += 1
               if rounds % 7 == 0 and not par:  # many clips in one pipelined call == one call per clip
