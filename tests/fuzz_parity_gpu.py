@@ -36,19 +36,33 @@ def detector_case(ctx, Wd, Hd, octaves, frame_seed, n_pairs=1):
 
 
 def detector_only(budget, seed):
+    """Detector calls only, as the full tool makes them: a new context every 150 calls (fresh device buffers), other calls of
+    other frame sizes in between (the staging buffers move), one to three pairs a call."""
     rng = np.random.default_rng(seed)
     t_end, runs, t_say = time.time() + budget, 0, time.time()
-    with M.Context(0) as ctx:
-        while time.time() < t_end:
-            Wd, Hd = int(rng.choice([160, 320, 481, 640])), int(rng.choice([120, 240, 360]))
-            bad = detector_case(ctx, Wd, Hd, int(rng.integers(0, 4)), int(rng.integers(0, 1 << 30)), int(rng.integers(1, 4)))
-            if bad:
-                print(f"DETECTOR MISMATCH run {runs} seed {seed}: {bad}")
-                sys.exit(1)
-            runs += 1
-            if time.time() - t_say > 30:
-                t_say = time.time()
-                print(f"... {runs} detector runs", flush=True)
+    while time.time() < t_end:
+        with M.Context(0) as ctx:
+            for _ in range(150):
+                if time.time() >= t_end:
+                    break
+                if rng.integers(0, 2):
+                    W, H = int(rng.choice([97, 160, 320, 640, 1024])), int(rng.choice([80, 121, 240, 480]))
+                    frames = rng.integers(0, 256, (6, H, W), dtype=np.uint8)
+                    ctx.extract_pairs_host(frames[5:], frames[:1], synth.random_keypoints(rng, 60, W, H, sizes=(8.4, 12.0, 27.0)))
+                Wd, Hd = int(rng.choice([160, 320, 481, 640])), int(rng.choice([120, 240, 360]))
+                case = (Wd, Hd, int(rng.integers(0, 4)), int(rng.integers(0, 1 << 30)), int(rng.integers(1, 4)))
+                bad = detector_case(ctx, *case)
+                if bad:
+                    print(f"DETECTOR MISMATCH run {runs} seed {seed}: {bad}")
+                    again = [detector_case(ctx, *case) is not None for _ in range(5)]
+                    with M.Context(0) as fresh:
+                        anew = [detector_case(fresh, *case) is not None for _ in range(5)]
+                    print(f"  replayed: same context {again}, fresh context {anew} (True = differs again)")
+                    sys.exit(1)
+                runs += 1
+                if time.time() - t_say > 30:
+                    t_say = time.time()
+                    print(f"... {runs} detector runs", flush=True)
     print(f"fuzz ok: {runs} detector runs, seed {seed}")
 
 
