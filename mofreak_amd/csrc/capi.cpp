@@ -1751,10 +1751,13 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     if ((rc = ensure(ctx, ctx->det_score, planes))) return rc;
     // The two bookkeeping maps of the tie logic are all zero between calls: the emission takes back every byte a call set.
     // They are filled once when they are (re)allocated, and again after a call that did not run to its end.
-    const void *touch_was = ctx->det_touch.ptr, *status_was = ctx->det_status.ptr;
+    // (A map that has to grow is a new buffer with whatever it holds -- and it may well come back at the address the old one
+    // had, so the address says nothing: round 4's first version compared addresses, and once in some ten thousand calls of
+    // growing frame sizes a tie met a stale byte.)
+    if (!ctx->det_touch.ptr || ctx->det_touch.bytes < planes || !ctx->det_status.ptr || ctx->det_status.bytes < planes) ctx->det_maps_dirty = true;
     if ((rc = ensure(ctx, ctx->det_touch, planes))) return rc;
     if ((rc = ensure(ctx, ctx->det_status, planes))) return rc;
-    if (ctx->det_touch.ptr != touch_was || ctx->det_status.ptr != status_was || ctx->det_maps_dirty) {
+    if (ctx->det_maps_dirty) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->det_touch.ptr, 0, ctx->det_touch.bytes, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->det_status.ptr, 0, ctx->det_status.bytes, ctx->stream));
         ctx->det_maps_dirty = false;
@@ -1921,7 +1924,8 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
     const int64_t total = head[0];
     const int32_t st = (int32_t)(uint32_t)(uint64_t)head[1];
     if (n_out) *n_out = total;
-    ctx->det_maps_dirty = (st & (16 | 32)) != 0;  // the emission of every batch has taken its bytes back
+    ctx->det_maps_dirty = (st & (16 | 32 | 64)) != 0;  // (else) the emission of every batch has taken its bytes back
+    if (st & 64) return fail(ctx, MOFREAK_ERR_HIP, "detector: the bookkeeping maps were not clean when the call started (internal error; bounds-checking build)");
     if (st & 16) return fail(ctx, MOFREAK_ERR_HIP, "detector: a refinement walk left its staged window (internal error)");
     if (st & 32) return fail(ctx, MOFREAK_ERR_HIP, "detector: a chain of tied scores did not resolve within its pass budget (internal error)");
     if (st & 4) return fail(ctx, MOFREAK_ERR_CAPACITY, "more corner candidates in one pair than the detector reserved (mofreak_detect_set_capacity)");

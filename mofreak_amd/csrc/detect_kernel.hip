@@ -2266,8 +2266,26 @@ int launch_det_scores(const DetArgs &a, void *stream)
     return (int)hipGetLastError();
 }
 
+#ifdef MOFREAK_DEBUG_BOUNDS
+// (bounds-checking build) The two bookkeeping maps must be all zero when a call starts -- every call takes back the bytes it
+// set, a new buffer is cleared: status bit 64 if a byte is not (a stale byte bends a tie decision once in a long while).
+__global__ __launch_bounds__(kDetThreads) void det_maps_clean_check_kernel(DetArgs a)
+{
+    const int64_t n16 = (int64_t)a.n_pairs * a.dg->plane_bytes / 16;
+    unsigned int any = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kDetThreads + threadIdx.x; i < n16; i += (int64_t)gridDim.x * kDetThreads) {
+        const uint4 t = reinterpret_cast<const uint4 *>(a.touch)[i], u = reinterpret_cast<const uint4 *>(a.status)[i];
+        any |= t.x | t.y | t.z | t.w | u.x | u.y | u.z | u.w;
+    }
+    if (any) atomicOr(a.status_word, 64);
+}
+#endif
+
 int launch_det_corners(const DetArgs &a, void *stream)
 {
+#ifdef MOFREAK_DEBUG_BOUNDS
+    if (a.n_pairs > 0) hipLaunchKernelGGL(det_maps_clean_check_kernel, dim3(1024), dim3(kDetThreads), 0, static_cast<hipStream_t>(stream), a);  // (after the pyramid: the status word is zero)
+#endif
     const int tiles = a.g.tile_start[a.g.n_layers];  // every layer's tiles in one launch, an eighth of the list per XCD
     if (tiles > 0 && a.n_pairs > 0)
         hipLaunchKernelGGL(det_corner_kernel, dim3(((tiles + 7) / 8) * 8, a.n_pairs), dim3(kDetThreads), 0, static_cast<hipStream_t>(stream), a);

@@ -264,7 +264,7 @@ struct DetArgs {
     int64_t out_capacity, out_base;
     int64_t *out_offsets;                   // whole-call CSR offsets; this batch fills [first_pair .. first_pair + n_pairs]
     int64_t first_pair;
-    int32_t *status_word;                   // bit 2: more candidates than cand_cap; bit 3: more keypoints than out_capacity; bit 4: internal (a walk left its window)
+    int32_t *status_word;                   // bit 2: more candidates than cand_cap; bit 3: more keypoints than out_capacity; bit 4: internal (a walk left its window); bit 5: internal (ties); bit 6: the bounds-checking build found the bookkeeping maps not clean at the start
 };
 
 // launchers (kernels.hip); all asynchronous on `stream`, return a hipError_t value as int
