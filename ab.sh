@@ -1,3 +1,3 @@
 mkdir -p gpurun_out/r4
-timeout -k 10 640 python tests/fuzz_parity_gpu.py 600 205 detector > gpurun_out/r4/detfuzz205.log 2>&1; echo product rc=$?; tail -n 1 gpurun_out/r4/detfuzz205.log
-timeout -k 10 500 python tests/fuzz_parity_gpu.py 460 138 > gpurun_out/r4/fuzz138.log 2>&1; echo product rc=$?; tail -n 1 gpurun_out/r4/fuzz138.log
+python mofreak_amd/tools/ab_tile.py mofreak_amd/libmofreak_hip.so mofreak_amd/_exp/libvar_abl1.so mofreak_amd/_exp/libvar_abl4.so mofreak_amd/_exp/libvar_abl5.so mofreak_amd/libmofreak_hip.so > gpurun_out/r4/stage_ablation.log 2>&1; echo rc=$?
+cat gpurun_out/r4/stage_ablation.log | tail -12
