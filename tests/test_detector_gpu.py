@@ -371,9 +371,11 @@ def test_other_frame_gaps(native_lib, oracle):
 
 
 def test_tie_chains_when_the_waiting_list_overflows():
-    """det_tie_chain_kernel takes the ties that were not ready at first sight from a list of 4096 per pair and layer and
-    scans the whole layer when the list overflows.  The debug library (libmofreak_hip_debug.so) is the same source with
-    a list of 8, so tie-heavy images take the scanning path on every layer: same keypoints as the oracle."""
+    """det_tie_kernel keeps a pair's ties (6144) and a layer's waiting ties (2048) in LDS lists, reads the ties from global
+    memory and scans the whole layer when a list overflows.  The debug library (libmofreak_hip_debug.so) is the same source
+    with lists of 64 and 8 (and 16 chunks of candidates per prologue thread instead of 512), so tie-heavy images take the
+    fallback paths on every layer; it also decides every tie both on whole rows and cell by cell and reports a difference:
+    same keypoints as the oracle."""
     import subprocess
     from mofreak_amd import build
     build.build_native(debug=True)  # rebuilt whenever a source is newer than it (same check as the product build)
@@ -395,3 +397,39 @@ print("overflow path ok")
     env = dict(os.environ, MOFREAK_HIP_LIBRARY=build.DEBUG_LIB_PATH)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "overflow path ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_growing_frame_sizes_in_one_context_keep_the_tie_maps_clean():
+    """The tie logic's two bookkeeping maps are all zero between calls: every call takes back the bytes it set, and a map
+    that has to grow is cleared (a grown buffer can come back from the allocator at its old address, stale bytes behind
+    its old end: the fuzz tool found that once in some ten thousand calls).  The debug library checks at the start of
+    every detector call that both maps are zero and fails the call if not: a sequence of calls whose frames and pair
+    counts grow and shrink, other calls in between, against the oracle."""
+    import subprocess
+    from mofreak_amd import build
+    build.build_native(debug=True)
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import mofreak_amd as M
+import oracle_lib as O
+from mofreak_amd import synth
+assert M.api.load().mofreak_build_flags() == 1, "not the debug build"
+rng = np.random.default_rng(11)
+with M.Context(0) as ctx:
+    for i, (W, H, n_pairs, octaves) in enumerate([(160, 120, 1, 3), (320, 240, 2, 3), (161, 120, 1, 2), (640, 360, 1, 3), (320, 240, 3, 1), (640, 480, 2, 3),
+                                                  (160, 120, 3, 0), (736, 480, 1, 3), (640, 360, 3, 3), (1024, 576, 1, 3)]):
+        fr = synth.moving_objects_stack(5 + n_pairs, W, H, seed=100 + i)
+        k, offs, resp, layer = ctx.detect_pairs_host(fr[5:], fr[:n_pairs], 30, octaves)
+        for p in range(n_pairs):
+            want = O.brisk_detect(O.absdiff(fr[5 + p], fr[p]), 30, octaves)
+            wk = np.stack([want["x"], want["y"], want["size"]], 1).astype(np.float32).reshape(-1, 3)
+            assert k[offs[p]:offs[p + 1]].tobytes() == wk.tobytes() and resp[offs[p]:offs[p + 1]].tobytes() == want["response"].tobytes(), (i, p)
+        frames = rng.integers(0, 256, (6, 97 + 40 * i, 131 + 60 * i), dtype=np.uint8)  # the staging buffers move as well
+        ctx.extract_pairs_host(frames[5:], frames[:1], synth.random_keypoints(rng, 50, frames.shape[2], frames.shape[1], sizes=(8.4, 12.0)))
+print("maps stay clean")
+""" % (os.path.dirname(here), here)
+    env = dict(os.environ, MOFREAK_HIP_LIBRARY=build.DEBUG_LIB_PATH)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "maps stay clean" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
