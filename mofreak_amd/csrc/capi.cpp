@@ -127,6 +127,11 @@ int ensure(mofreak_ctx *ctx, DeviceBuffer &b, size_t bytes)
     bytes = std::max<size_t>(bytes, 256);
     HIP_TRY(ctx, hipMalloc(&b.ptr, bytes));
     b.bytes = bytes;
+    // A new buffer starts as zeros, whatever the allocator hands out (fresh device memory usually is zero, memory this process
+    // freed a moment ago is not): padding columns, list tails and counters that a kernel reads before anybody has written them
+    // read the same on the ten-thousandth call as on the first.  (Buffers grow rarely; the fill is not on any hot path.)
+    HIP_TRY(ctx, hipMemsetAsync(b.ptr, 0, bytes, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MOFREAK_OK;
 }
 
