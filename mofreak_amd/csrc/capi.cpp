@@ -130,7 +130,15 @@ int ensure(mofreak_ctx *ctx, DeviceBuffer &b, size_t bytes)
     // A new buffer starts as zeros, whatever the allocator hands out (fresh device memory usually is zero, memory this process
     // freed a moment ago is not): padding columns, list tails and counters that a kernel reads before anybody has written them
     // read the same on the ten-thousandth call as on the first.  (Buffers grow rarely; the fill is not on any hot path.)
+#ifdef MOFREAK_DEBUG_BOUNDS
+    // (bounds-checking build) MOFREAK_FILL_NEW_BUFFERS=165 fills new buffers with 0xA5 instead: whoever reads an entry that
+    // nobody wrote shows up in the tests
+    const char *fill_env = std::getenv("MOFREAK_FILL_NEW_BUFFERS");
+    const int fill = fill_env ? std::atoi(fill_env) & 0xff : 0;
+    HIP_TRY(ctx, hipMemsetAsync(b.ptr, fill, bytes, ctx->stream));
+#else
     HIP_TRY(ctx, hipMemsetAsync(b.ptr, 0, bytes, ctx->stream));
+#endif
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MOFREAK_OK;
 }
