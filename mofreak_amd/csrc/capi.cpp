@@ -128,11 +128,12 @@ int ensure(mofreak_ctx *ctx, DeviceBuffer &b, size_t bytes)
     HIP_TRY(ctx, hipMalloc(&b.ptr, bytes));
     b.bytes = bytes;
     // A new buffer starts as zeros, whatever the allocator hands out (fresh device memory usually is zero, memory this process
-    // freed a moment ago is not): padding columns, list tails and counters that a kernel reads before anybody has written them
-    // read the same on the ten-thousandth call as on the first.  (Buffers grow rarely; the fill is not on any hot path.)
+    // freed a moment ago is not): a precaution -- the GPU suite and the fuzz tool also pass with new buffers holding a pattern
+    // (below) -- that makes a grown buffer a fresh one.  (Buffers grow rarely; the fill is not on any hot path.  On the
+    // context's stream and waited for: the stream does not wait for the null stream, where a plain hipMemset would run.)
 #ifdef MOFREAK_DEBUG_BOUNDS
     // (bounds-checking build) MOFREAK_FILL_NEW_BUFFERS=165 fills new buffers with 0xA5 instead: whoever reads an entry that
-    // nobody wrote shows up in the tests
+    // nobody wrote shows up in the tests (profiles/README.md, round 4: the suite passes with it)
     const char *fill_env = std::getenv("MOFREAK_FILL_NEW_BUFFERS");
     const int fill = fill_env ? std::atoi(fill_env) & 0xff : 0;
     HIP_TRY(ctx, hipMemsetAsync(b.ptr, fill, bytes, ctx->stream));
