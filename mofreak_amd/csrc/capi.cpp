@@ -611,7 +611,7 @@ int mofreak_create(int device_id, const mofreak_params *params, mofreak_ctx **ou
     CREATE_TRY(hipMalloc((void **)&ctx->d_status, 2 * sizeof(int32_t)));  // [0] describe kernels (read by mofreak_check_status), [1] detector
     if (const char *ev = std::getenv("MOFREAK_TILE_STAMPS"); ev && ev[0] == '1') {
         CREATE_TRY(hipMalloc((void **)&ctx->d_stamps, kTileStampSlots * sizeof(unsigned long long)));
-        CREATE_TRY(hipMemset(ctx->d_stamps, 0, kTileStampSlots * sizeof(unsigned long long)));
+        CREATE_TRY(hipMemsetAsync(ctx->d_stamps, 0, kTileStampSlots * sizeof(unsigned long long), ctx->stream));  // (on the stream the kernels run on: it does not wait for the null stream)
     }
     CREATE_TRY(hipMalloc((void **)&ctx->d_theta, t.theta_bounds.size() * sizeof(ThetaBound)));
     CREATE_TRY(hipMemcpy(ctx->d_theta, t.theta_bounds.data(), t.theta_bounds.size() * sizeof(ThetaBound), hipMemcpyHostToDevice));
@@ -678,7 +678,8 @@ int mofreak_create(int device_id, const mofreak_params *params, mofreak_ctx **ou
     CREATE_TRY(hipMemcpy(ctx->d_lut, t.lut.data(), t.lut.size() * sizeof(PatternPoint), hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(ctx->d_resize, t.resize.data(), t.resize.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(ctx->d_small, &st, sizeof(st), hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemset(ctx->d_status, 0, 2 * sizeof(int32_t)));
+    CREATE_TRY(hipMemsetAsync(ctx->d_status, 0, 2 * sizeof(int32_t), ctx->stream));
+    CREATE_TRY(hipStreamSynchronize(ctx->stream));
 #undef CREATE_TRY
     *out = ctx;
     return MOFREAK_OK;
@@ -804,7 +805,7 @@ int mofreak_get_tile_stamps(mofreak_ctx *ctx, uint64_t *out, int n, int reset)
     n = std::min(n, kTileStampSlots);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out, ctx->d_stamps, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(ctx, hipMemset(ctx->d_stamps, 0, kTileStampSlots * sizeof(unsigned long long)));
+    if (reset) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stamps, 0, kTileStampSlots * sizeof(unsigned long long), ctx->stream));
     return MOFREAK_OK;
 }
 
