@@ -86,6 +86,18 @@ def test_no_oracle_in_the_product():
     assert "oracle" not in out
 
 
+def test_no_fill_on_the_null_stream():
+    """The library's streams are created non-blocking: they do not wait for the null stream, which is where a plain hipMemset
+    runs (and it returns before the fill is done).  Round 4 met that twice -- a fill that overwrote live data, words cleared at
+    context creation -- so every fill in csrc/ names its stream."""
+    import re
+    csrc = os.path.join(ROOT, "mofreak_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".cpp", ".hip", ".h")):
+            code = re.sub(r"//[^\n]*", "", open(os.path.join(csrc, f), errors="ignore").read())  # (comments may talk about it)
+            assert not re.search(r"\bhipMemset\s*\(", code), f
+
+
 def test_host_code_under_address_sanitizer(tmp_path):
     """SURVEY.md section 5 (sanitizers): the C ABI's host code (tables, .mofreak text, argument checks) and the C++
     facade's reader / writer built with -fsanitize=address,undefined, kernel launchers stubbed out (no GPU involved;
