@@ -10,7 +10,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmofreak_hip.so")
 DEBUG_LIB_PATH = os.path.join(PKG_DIR, "libmofreak_hip_debug.so")  # -DMOFREAK_DEBUG_BOUNDS: checked LDS accesses / stores
 SOURCES = ["kernels.hip", "tile_kernel.hip", "bow_kernel.hip", "detect_kernel.hip", "capi.cpp", "tables.cpp", "format.cpp"]
-HEADERS = ["tables.h", "device_types.h", "device_helpers.h", "mip_lane_order.inc", os.path.join("..", "..", "include", "mofreak_hip.h")]
+HEADERS = ["tables.h", "device_types.h", "device_helpers.h", "mip_lane_order.inc", "mip_lane.h", "resize_axis.h", os.path.join("..", "..", "include", "mofreak_hip.h")]
 # -ffp-contract=off / -fno-fast-math: a handful of float/double expressions restate reference
 # expressions whose rounding is part of the result.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
@@ -31,23 +31,42 @@ def is_stale(lib: str = LIB_PATH) -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+def _compile_and_link(out: str, extra: list[str], verbose: bool) -> None:
+    """One hipcc process per source (the tile kernel's per-ROI-side MIP instantiations take minutes; the other files
+    compile beside it), objects under build/obj/<library name>/, then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    obj_dir = os.path.join(os.path.dirname(PKG_DIR), "build", "obj", os.path.splitext(os.path.basename(out))[0])
+    os.makedirs(obj_dir, exist_ok=True)
+    compile_flags = [f for f in FLAGS if f != "-shared"]
+
+    def one(src: str) -> str:
+        obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc(), *compile_flags, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(one, SOURCES))
+    cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out, *objs]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
 def build_native(force: bool = False, verbose: bool = False, debug: bool = False) -> str:
     """Compile the shared library if it is missing or older than its sources; returns its path.
     debug=True: the bounds-checking build of the same sources (tests only; never what api.load() picks up)."""
     if debug:
         if not force and not is_stale(DEBUG_LIB_PATH):
             return DEBUG_LIB_PATH
-        cmd = [hipcc(), *FLAGS, "-DMOFREAK_DEBUG_BOUNDS", "-o", DEBUG_LIB_PATH, *[os.path.join(CSRC, s) for s in SOURCES]]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        _compile_and_link(DEBUG_LIB_PATH, ["-DMOFREAK_DEBUG_BOUNDS"], verbose)
         return DEBUG_LIB_PATH
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [hipcc(), *FLAGS, "-o", LIB_PATH, *[os.path.join(CSRC, s) for s in SOURCES]]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    _compile_and_link(LIB_PATH, [], verbose)
     return LIB_PATH
 
 

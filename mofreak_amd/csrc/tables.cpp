@@ -2,6 +2,8 @@
 // Compile with -ffp-contract=off: the float/double expression order below is part of the contract.
 #include "tables.h"
 
+#include "resize_axis.h"
+
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -331,6 +333,19 @@ void build_tables(const FreakParams &p, Tables &t)
         build_resize_axis(L, true, &t.resize[(static_cast<size_t>(L) * 2 + 0) * kPatch]);
         build_resize_axis(L, false, &t.resize[(static_cast<size_t>(L) * 2 + 1) * kPatch]);
     }
+
+    // The tile kernel's lane-per-keypoint MIP (mip_lane.h) is compiled per ROI side against the compile-time construction of
+    // the same rows (resize_axis.h): the two must agree entry by entry, or that kernel would resample with other taps than
+    // every other path.
+    for (int L = 1; L <= kTileMaxRoi; ++L)
+        for (int axis = 0; axis < 2; ++axis) {
+            const ResizeAxisC c = make_resize_axis(L, axis == 0);
+            const ResizeTap *r = &t.resize[(static_cast<size_t>(L) * 2 + axis) * kPatch];
+            for (int d = 0; d < kPatch; ++d)
+                if (r[d].ofs != c.ofs[d] || r[d].ofs1 != c.ofs1[d] || r[d].c0 != c.c0[d] || r[d].c1 != c.c1[d])
+                    throw std::logic_error("resize taps: the compile-time rows of resize_axis.h differ from build_resize_axis at ROI side " +
+                                           std::to_string(L));
+        }
 
     build_theta_bounds(t.theta_bounds);
 

@@ -28,13 +28,18 @@
 #include <type_traits>
 
 #include "device_helpers.h"
+#include "mip_lane.h"
 
 namespace mofreak {
 namespace {
 
 constexpr int kTileThreads = 512;                    // 8 waves; two workgroups per CU = 4 waves per SIMD (ten-wave workgroups at
                                                      // <= 96 registers were tried: the second one does not fit beside the first)
-constexpr int kStageRows = kTileThreads / 16;        // region rows a staging step takes (16 lanes per row)
+constexpr int kMipLaneMinL = 7, kMipLaneMaxL = 13;   // ROI sides the lane-per-keypoint MIP is compiled for (keypoint sizes 6 < s <= 13: FREAK's smallest
+                                                     // pattern up to what the tile's halo admits); other sides take the wave-per-keypoint stage
+constexpr int kMipWaves = 2;                         // waves that compute the MIP (a lane per keypoint, mip_lane.h) while the others stage the tile
+constexpr int kStageThreads = kTileThreads - 64 * kMipWaves;
+constexpr int kStageRows = kStageThreads / 16;       // region rows a staging step takes (16 lanes per row)
 constexpr int kTileLdsLimit = 80 * 1024;             // a workgroup's LDS budget (two per CU); debug builds check accesses against it
 constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kBatch = 128;                          // keypoints described per pass over a tile's list
@@ -589,16 +594,16 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     // (a last group of fewer than kGroup keypoints is filled up with copies of the batch's last one: stage 3 then has whole
     // groups only, and what it computes for the copies is not stored)
     auto table_block = [](uint32_t scale) { return scale * (uint32_t)(kNbOrientation * kNbPoints * 16); };
-    auto make_records = [&](int b0, int nb, bool for_mip) {
-        if (tid < ((nb + kGroup - 1) & ~(kGroup - 1))) {
-            const SortedKp kp = tile_kps[b0 + min(tid, nb - 1)];
+    auto make_records = [&](int b0, int nb, bool for_mip, int rt) {  // rt: the thread's index among the threads that make records
+        if (rt >= 0 && rt < ((nb + kGroup - 1) & ~(kGroup - 1))) {
+            const SortedKp kp = tile_kps[b0 + min(rt, nb - 1)];
             KpRec k;
             k.kx = kp.x;
             k.ky = kp.y;
             k.g = kp.g;
             k.pk = (uint16_t)((kp.packed >> 16) | (kp.packed & 0xff) << 6 | ((kp.packed >> 8) & 0xff) << 11);
             k.unused = 0;
-            kf[tid] = k;
+            kf[rt] = k;
             // a keypoint at integer coordinates: LDS address of its own corner (ky, kx) in the integral; else the top bit
             const int xi = (int)kp.x, yi = (int)kp.y;
             const bool integral = (float)xi == kp.x && (float)yi == kp.y;
@@ -606,7 +611,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             // of the keypoint's 43 un-rotated points in the pattern tables (16-byte entries), which the orientation pass
             // replaces by the offset of the rotated ones
             const int half = (int)((kp.packed >> 8) & 0xff);
-            kint[tid] = make_uint2(integral ? lds0 + kOffIntegral + 2 * (kIColOff + (yi - oy) * kIPitch + (xi - ox)) : 0x80000000u,
+            kint[rt] = make_uint2(integral ? lds0 + kOffIntegral + 2 * (kIColOff + (yi - oy) * kIPitch + (xi - ox)) : 0x80000000u,
                                    for_mip ? (uint32_t)((yi - half - oy + 1) * kTileStagePitch + (xi - half - ox)) : table_block(kp.packed >> 16));
         }
     };
@@ -616,45 +621,22 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     // the row pass), a workgroup takes 32 rows (kStageRows) per step: per-lane offsets are computed once, a step moves the scalar
     // base.  All loads are issued before anything waits on one (a branch per load would make the compiler drain the
     // memory queue at every join); the small tables and the first batch's keypoint records are fetched behind them.
+    // Waves 0 .. kMipWaves - 1 take no part in it: when the tile qualifies (mip_lane below) they compute the MIP of the
+    // tile's keypoints meanwhile, a lane per keypoint, straight from the frames -- the time the others spend waiting for
+    // memory.  stid: a thread's index among the staging threads (negative in the MIP waves).
+    const int stid = tid - 64 * kMipWaves;
+    const bool stager = stid >= 0;
     const int runs = RW >> 4;
-    const int sq = tid & 15, sr = tid >> 4;
+    const int sq = stid & 15, sr = stid >> 4;
     const bool inside = ox >= 0 && oy >= 0 && ox + RW <= W && oy + RH <= H;  // the whole region lies in the image
     const bool wide = fast8 && (inside || (W & 7) == 0);
-    const uint32_t stage_lds = lds0 + kOffIntegral + (sr + 1) * kTileStagePitch + 16 * sq;
-    Px16 v[2][kStageIters];
-    if (wide) {
-        if (inside) {
-            const uint32_t voff = (uint32_t)sr * (uint32_t)a.f.row_stride + 16u * (uint32_t)min(sq, runs - 1);
-#pragma unroll
-            for (int u = 0; u < kStageIters; ++u) {
-                const int64_t base = (int64_t)(oy + min(kStageRows * u, RH - kStageRows)) * a.f.row_stride + ox;  // (a last partial step re-reads rows)
-                v[0][u] = *reinterpret_cast<const Px16 *>(cur + base + voff);
-                v[1][u] = *reinterpret_cast<const Px16 *>(prev + base + voff);
-            }
-        } else {
-            // a tile on the image border, W a multiple of 8: every 8-byte half of a piece is all inside or all outside
-            // the image.  Outside pixels are never read by a keypoint that passed the border tests: any value will do,
-            // so the loads are clamped into the image instead of branching.
-            const int gx = ox + 16 * min(sq, runs - 1);
-            const uint32_t xlo = (uint32_t)min(max(gx, 0), W - 8), xhi = (uint32_t)min(max(gx + 8, 0), W - 8);
-#pragma unroll
-            for (int u = 0; u < kStageIters; ++u) {
-                const int gy = min(max(oy + min(kStageRows * u, RH - kStageRows) + sr, 0), H - 1);
-                const int64_t ro = (int64_t)gy * a.f.row_stride;
-#pragma unroll
-                for (int f = 0; f < 2; ++f) {
-                    const uint8_t *row = (f ? prev : cur) + ro;
-                    const uint2 lo = *reinterpret_cast<const uint2 *>(row + xlo);
-                    const uint2 hi = *reinterpret_cast<const uint2 *>(row + xhi);
-                    v[f][u].w[0] = lo.x;
-                    v[f][u].w[1] = lo.y;
-                    v[f][u].w[2] = hi.x;
-                    v[f][u].w[3] = hi.y;
-                }
-            }
-        }
-    }
-
+    // The lane-per-keypoint MIP: one ROI side in the tile, a side it is compiled for, frames and rows on 4-byte boundaries
+    // (a lane fetches 12 to 20 bytes from each ROI row's start rounded down to 4), not the tile(s) at the end of the
+    // frame's last rows, where that fetch could pass the end of the caller's buffer, and at most kBatch keypoints (64 per
+    // MIP wave; a crowded tile's batches go through stage 1 below).
+    const bool mip_lane = uniform && tile_L >= kMipLaneMinL && tile_L <= kMipLaneMaxL && (!STAMPS || tile_L == 12) &&
+                          (((uintptr_t)cur | (uintptr_t)prev | (uintptr_t)a.f.row_stride) & 3) == 0 &&
+                          !(ty == a.tiles_y - 1 && (tx + 1) * kTileW + 32 > W) && one_batch;
     // per-lane constants of the MIP sampling passes: the LDS address the lane's pixels go to, and -- once the ROI side
     // is known -- the LDS addresses of each pixel's two source rows for a ROI at the region's origin (the second byte
     // of a row pair is the next one: where cv::resize clamps the column instead, its weight is zero) and its weights.
@@ -680,42 +662,104 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             ml.c1ys[u] = sm.c1y_s12;
         }
     };
-    if (uniform) load_samples(tile_L);  // one ROI side in the whole tile (the usual case): its samples stay in registers
     const bool tail_ok = lane + 64 * (kMipIters - 1) < a.mip_n;  // the last pass is a partial one (launch_tile checks mip_n)
 
-    make_records(0, min(kBatch, n_tile_kp), true);
-    if (tid < kThetaBounds) s_theta[tid] = a.theta[tid];
-    if (wide) {
-        if (sq < runs) {
+    if (mip_lane && wave < kMipWaves) {  // (a scalar branch: nothing of the staging path is alive in here)
+        // ---- stage 1 for the usual tile, beside stage 0: wave w takes keypoints 64 w .. 64 w + 63 (a single batch: mip_lane)
+        auto run = [&](auto LL) {
+            constexpr int L = decltype(LL)::value;
+            const int k = 64 * wave + lane;
+            int64_t roi;
+            {
+                const SortedKp kp = tile_kps[min(k, n_tile_kp - 1)];  // (a partial wave: the spare lanes repeat the last keypoint)
+                // :293-295 with :460's float -> int parameters: the ROI starts at (x - size / 2, y - size / 2)
+                const int half = (int)((kp.packed >> 8) & 0xff);
+                roi = (int64_t)((int)kp.y - half) * a.f.row_stride + ((int)kp.x - half);
+            }
+            const uint2 mv = mip_lane_keypoint<L>(cur + roi, prev - cur, a.f.row_stride, mip_theta);
+            s_mot[k] = mv;  // kept for one 16-byte store per descriptor at the end of stage 3 (spare lanes: spare slots)
+        };
+        switch (tile_L) {
+        case 7: run(std::integral_constant<int, 7>{}); break;
+        case 8: run(std::integral_constant<int, 8>{}); break;
+        case 9: run(std::integral_constant<int, 9>{}); break;
+        case 10: run(std::integral_constant<int, 10>{}); break;
+        case 11: run(std::integral_constant<int, 11>{}); break;
+        case 12: run(std::integral_constant<int, 12>{}); break;
+        default: run(std::integral_constant<int, 13>{}); break;
+        }
+    } else {
+        const uint32_t stage_lds = lds0 + kOffIntegral + (sr + 1) * kTileStagePitch + 16 * sq;
+        Px16 v[2][kStageIters];
+        if (wide && stager) {
+            if (inside) {
+                const uint32_t voff = (uint32_t)sr * (uint32_t)a.f.row_stride + 16u * (uint32_t)min(sq, runs - 1);
 #pragma unroll
-            for (int u = 0; u < kStageIters; ++u) {
-                if (kStageRows * u < RH) {  // a last partial step: the rows it re-read are written again, with the same bytes
-                    const uint32_t d = stage_lds + min(kStageRows * u, RH - kStageRows) * kTileStagePitch;
-                    lds_st<LdsU4>(d, LdsU4{v[0][u].w[0], v[0][u].w[1], v[0][u].w[2], v[0][u].w[3]});
-                    lds_st<LdsU4>(d + kTileRW, LdsU4{v[1][u].w[0], v[1][u].w[1], v[1][u].w[2], v[1][u].w[3]});
+                for (int u = 0; u < kStageIters; ++u) {
+                    const int64_t base = (int64_t)(oy + min(kStageRows * u, RH - kStageRows)) * a.f.row_stride + ox;  // (a last partial step re-reads rows)
+                    v[0][u] = *reinterpret_cast<const Px16 *>(cur + base + voff);
+                    v[1][u] = *reinterpret_cast<const Px16 *>(prev + base + voff);
+                }
+            } else {
+                // a tile on the image border, W a multiple of 8: every 8-byte half of a piece is all inside or all outside
+                // the image.  Outside pixels are never read by a keypoint that passed the border tests: any value will do,
+                // so the loads are clamped into the image instead of branching.
+                const int gx = ox + 16 * min(sq, runs - 1);
+                const uint32_t xlo = (uint32_t)min(max(gx, 0), W - 8), xhi = (uint32_t)min(max(gx + 8, 0), W - 8);
+#pragma unroll
+                for (int u = 0; u < kStageIters; ++u) {
+                    const int gy = min(max(oy + min(kStageRows * u, RH - kStageRows) + sr, 0), H - 1);
+                    const int64_t ro = (int64_t)gy * a.f.row_stride;
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const uint8_t *row = (f ? prev : cur) + ro;
+                        const uint2 lo = *reinterpret_cast<const uint2 *>(row + xlo);
+                        const uint2 hi = *reinterpret_cast<const uint2 *>(row + xhi);
+                        v[f][u].w[0] = lo.x;
+                        v[f][u].w[1] = lo.y;
+                        v[f][u].w[2] = hi.x;
+                        v[f][u].w[3] = hi.y;
+                    }
                 }
             }
         }
-    } else {  // unaligned frames or an odd width: byte by byte, zero outside the image
-        for (int t = tid; t < 2 * RH * runs; t += kTileThreads) {
-            const int fr = t >= RH * runs ? 1 : 0, tt = t - fr * RH * runs;
-            const int r = tt / runs, q = tt - r * runs;
-            const int gy = oy + r, gx = ox + 16 * q;
-            const uint8_t *row = (fr ? prev : cur) + (int64_t)gy * a.f.row_stride;
-            uint32_t w4[4] = {0, 0, 0, 0};
-            if (gy >= 0 && gy < H) {
-                for (int k = 0; k < 16; ++k) {
-                    const int x = gx + k;
-                    if (x >= 0 && x < W) w4[k >> 2] |= (uint32_t)row[x] << (8 * (k & 3));
+
+        if (uniform && !mip_lane) load_samples(tile_L);  // one ROI side in the whole tile (the usual case): its samples stay in registers
+        make_records(0, min(kBatch, n_tile_kp), !mip_lane, stid);
+        if (stid >= 0 && stid < kThetaBounds) s_theta[stid] = a.theta[stid];
+        if (wide) {
+            if (stager && sq < runs) {
+#pragma unroll
+                for (int u = 0; u < kStageIters; ++u) {
+                    if (kStageRows * u < RH) {  // a last partial step: the rows it re-read are written again, with the same bytes
+                        const uint32_t d = stage_lds + min(kStageRows * u, RH - kStageRows) * kTileStagePitch;
+                        lds_st<LdsU4>(d, LdsU4{v[0][u].w[0], v[0][u].w[1], v[0][u].w[2], v[0][u].w[3]});
+                        lds_st<LdsU4>(d + kTileRW, LdsU4{v[1][u].w[0], v[1][u].w[1], v[1][u].w[2], v[1][u].w[3]});
+                    }
                 }
             }
-            lds_st<LdsU4>(lds0 + kOffIntegral + (r + 1) * kTileStagePitch + fr * kTileRW + 16 * q, LdsU4{w4[0], w4[1], w4[2], w4[3]});
+        } else if (stager) {  // unaligned frames or an odd width: byte by byte, zero outside the image
+            for (int t = stid; t < 2 * RH * runs; t += kStageThreads) {
+                const int fr = t >= RH * runs ? 1 : 0, tt = t - fr * RH * runs;
+                const int r = tt / runs, q = tt - r * runs;
+                const int gy = oy + r, gx = ox + 16 * q;
+                const uint8_t *row = (fr ? prev : cur) + (int64_t)gy * a.f.row_stride;
+                uint32_t w4[4] = {0, 0, 0, 0};
+                if (gy >= 0 && gy < H) {
+                    for (int k = 0; k < 16; ++k) {
+                        const int x = gx + k;
+                        if (x >= 0 && x < W) w4[k >> 2] |= (uint32_t)row[x] << (8 * (k & 3));
+                    }
+                }
+                lds_st<LdsU4>(lds0 + kOffIntegral + (r + 1) * kTileStagePitch + fr * kTileRW + 16 * q, LdsU4{w4[0], w4[1], w4[2], w4[3]});
+            }
         }
     }
     __syncthreads();  TILE_STAMP(0);
 
-    // ================= stage 1: MIP
-    {  // <stage 1>  (mofreak_amd/tools/ab_tile.py --ablate builds copies of this file with a stage's block disabled)
+    // ================= stage 1: MIP, one wave per keypoint out of the staged rows -- for tiles the lane-per-keypoint form
+    // above does not take (mixed ROI sides, sides outside kMipLaneMinL .. kMipLaneMaxL, frames off 4-byte boundaries)
+    if (!mip_lane) {  // <stage 1>  (mofreak_amd/tools/ab_tile.py --ablate builds copies of this file with a stage's block disabled)
         // per-lane constants of the bit pass: lane = 8*centre + offset (MoFREAKUtilities.cpp:56-70, 308-316)
         const int mc = lane >> 3, mi = lane & 7;
         const int mcx = (0xDDD99555u >> (4 * mc)) & 15, mcy = (0xD95D5D95u >> (4 * mc)) & 15;
@@ -777,7 +821,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             const int nb = min(kBatch, n_tile_kp - b0);
             if (b0 > 0) {  // further batches of a crowded tile: their records
                 __syncthreads();
-                make_records(b0, nb, true);
+                make_records(b0, nb, true, tid);
                 __syncthreads();
             }
             if (uniform) {
@@ -832,11 +876,12 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
                 }
             }
         }
+        __syncthreads();
+        // a single batch keeps its records for stage 3: the slot that held the ROI offsets now takes the table blocks (stage
+        // 2's barriers come before anyone reads them)
+        if (one_batch && tid < ((n_tile_kp + kGroup - 1) & ~(kGroup - 1))) kint[tid].y = table_block(kf[tid].pk & 63);
     }
-    __syncthreads();  TILE_STAMP(1);
-    // a single batch keeps its records for stage 3: the slot that held the ROI offsets now takes the table blocks (stage 2's
-    // barriers come before anyone reads them)
-    if (one_batch && tid < ((n_tile_kp + kGroup - 1) & ~(kGroup - 1))) kint[tid].y = table_block(kf[tid].pk & 63);
+    TILE_STAMP(1);
 
     // ================= stage 2: integral of |cur - prev| over tile + halo, modulo 2^16, in LDS
     {  // <stage 2>
@@ -969,7 +1014,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             const int nb = min(kBatch, n_tile_kp - b0);
             if (!one_batch) {  // crowded tile: the records of this batch (a single batch still has them from stage 0)
                 __syncthreads();
-                make_records(b0, nb, false);
+                make_records(b0, nb, false, tid);
                 __syncthreads();
             }
             // What the batch's keypoints have in common (every wave works it out for itself from the records): one
