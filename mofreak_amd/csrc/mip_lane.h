@@ -51,10 +51,17 @@ MIP_FN uint32_t mip_udot4(uint32_t a, uint32_t b, uint32_t c)
 MIP_FN uint32_t mip_umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 MIP_FN void mip_and_or(uint32_t &word, uint32_t v, uint32_t mask) { word |= v & mask; }
 MIP_FN void mip_sched_barrier() {}
-template <int N>
-MIP_FN void mip_load_dwords(const uint8_t *p4, uint32_t *d)  // N dwords from a 4-byte-aligned address
+// byte B of `word` = s >> 2 (a value below 256); FIRST: the other bytes become zero, else they stay
+template <int B, bool FIRST>
+MIP_FN void mip_put_quarter(uint32_t &word, uint32_t s)
 {
-    std::memcpy(d, p4, 4 * N);
+    const uint32_t v = ((s >> 2) & 0xffu) << (8 * B);
+    word = FIRST ? v : ((word & ~(0xffu << (8 * B))) | v);
+}
+template <int N>
+MIP_FN void mip_load_dwords(const uint8_t *frame, uint32_t off4, uint32_t *d)  // N dwords from frame + off4 (4-byte aligned)
+{
+    std::memcpy(d, frame + off4, 4 * N);
 }
 MIP_FN MipUint2 mip_make_uint2(uint32_t x, uint32_t y) { return MipUint2{x, y}; }
 }  // namespace
@@ -74,12 +81,33 @@ MIP_FN uint32_t mip_umulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 // register of its own and joins them in trees later
 MIP_FN void mip_and_or(uint32_t &word, uint32_t v, uint32_t mask) { asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(word) : "v"(v), "s"(mask)); }
 MIP_FN void mip_sched_barrier() { __builtin_amdgcn_sched_barrier(0); }
+// byte B of `word` = s >> 2 (a value below 256); FIRST: the other bytes become zero, else they stay.  The shift writes its
+// result straight into the byte (SDWA destination select): packing four cells into a dword costs no instruction of its own.
+template <int B, bool FIRST>
+MIP_FN void mip_put_quarter(uint32_t &word, uint32_t s)
+{
+    static_assert(B >= 0 && B < 4, "a byte of a dword");
+    if constexpr (FIRST) {
+        if constexpr (B == 0) asm("v_lshrrev_b32_e32 %0, 2, %1" : "=v"(word) : "v"(s));
+        if constexpr (B == 1) asm("v_lshrrev_b32_sdwa %0, 2, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(word) : "v"(s));
+        if constexpr (B == 2) asm("v_lshrrev_b32_sdwa %0, 2, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(word) : "v"(s));
+        if constexpr (B == 3) asm("v_lshrrev_b32_sdwa %0, 2, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(word) : "v"(s));
+    } else {
+        if constexpr (B == 0) asm("v_lshrrev_b32_sdwa %0, 2, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(word) : "v"(s));
+        if constexpr (B == 1) asm("v_lshrrev_b32_sdwa %0, 2, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(word) : "v"(s));
+        if constexpr (B == 2) asm("v_lshrrev_b32_sdwa %0, 2, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(word) : "v"(s));
+        if constexpr (B == 3) asm("v_lshrrev_b32_sdwa %0, 2, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(word) : "v"(s));
+    }
+}
 typedef uint32_t MipU4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t MipU3 __attribute__((ext_vector_type(3), aligned(4)));
+// N dwords from frame + off4: `frame` is the same in every lane (a scalar base), off4 the lane's 32-bit byte offset, a
+// multiple of 4 -- the address costs no vector arithmetic; one 12- or 16-byte load (+ a dword)
 template <int N>
-MIP_FN void mip_load_dwords(const uint8_t *p4, uint32_t *d)  // N dwords from a 4-byte-aligned address: one 12- or 16-byte load (+ a dword)
+MIP_FN void mip_load_dwords(const uint8_t *frame, uint32_t off4, uint32_t *d)
 {
     static_assert(N >= 1 && N <= 5, "ROI sides up to 16");
+    const uint8_t *p4 = frame + off4;
     if constexpr (N <= 3) {
         const MipU3 v = *reinterpret_cast<const MipU3 *>(p4);
         d[0] = v.x;
@@ -134,11 +162,12 @@ struct MipPlan {
     int rows[16];
 };
 
-template <int L, bool PREV>
+template <int L, bool PREV, int CM>
 constexpr MipPlan make_mip_plan()
 {
     MipPlan p{};
     for (int c = 0; c < 8; ++c) {
+        if (!((CM >> c) & 1)) continue;
         if (!PREV) {
             for (int k = 0; k < 9; ++k) p.need[mip_cur_start(c) + k] = true;
         } else {
@@ -158,21 +187,21 @@ constexpr MipPlan make_mip_plan()
     return p;
 }
 
-template <int L, bool PREV>
+template <int L, bool PREV, int CM>
 struct MipTables {
     static constexpr ResizeAxisC X = make_resize_axis(L, true);
     static constexpr ResizeAxisC Y = make_resize_axis(L, false);
-    static constexpr MipPlan P = make_mip_plan<L, PREV>();
+    static constexpr MipPlan P = make_mip_plan<L, PREV, CM>();
 };
 
 // Cells are produced source row by source row, inside one column by column, inside a column output row by output row: is
 // `pos` the first needed cell of its dword to be produced?  (It assigns the dword, the others OR into it; two output rows that
 // hang on the same source row share dwords at the 19-byte pitch, and there the higher position can come first.)
-template <int L, bool PREV>
+template <int L, bool PREV, int CM>
 constexpr bool mip_first_of_dword(int pos)
 {
-    const ResizeAxisC &Y = MipTables<L, PREV>::Y;
-    const MipPlan &P = MipTables<L, PREV>::P;
+    const ResizeAxisC &Y = MipTables<L, PREV, CM>::Y;
+    const MipPlan &P = MipTables<L, PREV, CM>::P;
     const int dy = pos / kAxisOut, dx = pos % kAxisOut;
     const int key = ((Y.ofs[dy] > Y.ofs1[dy] ? Y.ofs[dy] : Y.ofs1[dy]) * kAxisOut + dx) * kAxisOut + dy;
     for (int q = pos - (pos & 3); q < pos - (pos & 3) + 4 && q < kMipCells; ++q) {
@@ -192,25 +221,26 @@ struct MipRawRow {
                     // never uses its bytes
 };
 
-// the dwords that cover one ROI row; `p4` is the row's address rounded down to 4 bytes
+// the dwords that cover one ROI row: `row` = the frame row's address (the same in every lane), off4 = the ROI's byte offset
+// in it rounded down to 4 bytes
 template <int L>
-MIP_FN MipRawRow mip_load_row(const uint8_t *p4)
+MIP_FN MipRawRow mip_load_row(const uint8_t *row, uint32_t off4)
 {
     MipRawRow r;
     r.d[0] = r.d[1] = r.d[2] = r.d[3] = r.d[4] = r.d[5] = 0;
-    mip_load_dwords<(mip_raw_dwords(L) < 3 ? 3 : mip_raw_dwords(L))>(p4, r.d);
+    mip_load_dwords<(mip_raw_dwords(L) < 3 ? 3 : mip_raw_dwords(L))>(row, off4, r.d);
     return r;
 }
 
 // cv::resize's two passes over one frame's ROI for the cells the MIP reads.  OUT[k] receives bytes 4k .. 4k+3 of the 19x19
 // buffer (only needed cells are written; a dword's first needed cell assigns it).  row_done(dy) is called when output row dy
 // is complete (all needed cells of rows <= dy are in OUT).
-//   roi4: address of the ROI's first row rounded down to 4 bytes; shift: the bytes dropped by that (the same in every row:
-//   the row stride is a multiple of 4)
-template <int L, bool PREV, class RowDone>
-MIP_FN void mip_resample(const uint8_t *roi4, uint32_t shift, int64_t row_stride, uint32_t (&OUT)[kMipDwords], RowDone &&row_done)
+//   frame: the frame (a scalar); off4: byte offset of the ROI's top-left pixel in it, rounded down to 4 bytes; shift: the
+//   bytes dropped by that (the same in every row: the row stride is a multiple of 4)
+template <int L, bool PREV, int CM, class RowDone>
+MIP_FN void mip_resample(const uint8_t *frame, uint32_t off4, uint32_t shift, int64_t row_stride, uint32_t (&OUT)[kMipDwords], RowDone &&row_done)
 {
-    using TB = MipTables<L, PREV>;
+    using TB = MipTables<L, PREV, CM>;
     constexpr int kAhead = 2;  // source rows requested ahead of the one being worked on
     constexpr int kRing = kAhead + 1;
     constexpr int n_rows = TB::P.n_rows;
@@ -218,12 +248,12 @@ MIP_FN void mip_resample(const uint8_t *roi4, uint32_t shift, int64_t row_stride
     uint32_t T[kAxisOut];  // horizontal sums (low four bits cleared) of the source row above the one being worked on
     static_for<(kAhead < n_rows ? kAhead : n_rows)>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        raw[i % kRing] = mip_load_row<L>(roi4 + (int64_t)TB::P.rows[i] * row_stride);
+        raw[i % kRing] = mip_load_row<L>(frame + (int64_t)TB::P.rows[i] * row_stride, off4);
     });
     static_for<n_rows>([&](auto I) {
         constexpr int i = decltype(I)::value;
         constexpr int r = TB::P.rows[i];
-        if constexpr (i + kAhead < n_rows) raw[(i + kAhead) % kRing] = mip_load_row<L>(roi4 + (int64_t)TB::P.rows[i + kAhead] * row_stride);
+        if constexpr (i + kAhead < n_rows) raw[(i + kAhead) % kRing] = mip_load_row<L>(frame + (int64_t)TB::P.rows[i + kAhead] * row_stride, off4);
         // the row's bytes 4k .. 4k+3
         uint32_t W[mip_row_dwords(L)];
         static_for<mip_row_dwords(L)>([&](auto K) {
@@ -254,13 +284,8 @@ MIP_FN void mip_resample(const uint8_t *roi4, uint32_t shift, int64_t row_stride
                         uint32_t s = 2u;
                         if constexpr (b0 != 0) s += mip_umulhi(r0 == r ? t : T[dx], b0);
                         if constexpr (b1 != 0) s += mip_umulhi(t, b1);
-                        const uint32_t px = s >> 2;
                         constexpr int pos = dy * kAxisOut + dx, k = pos >> 2, b = pos & 3;
-                        constexpr bool first = mip_first_of_dword<L, PREV>(pos);
-                        if constexpr (first)
-                            OUT[k] = px << (8 * b);
-                        else
-                            OUT[k] |= px << (8 * b);
+                        mip_put_quarter<b, mip_first_of_dword<L, PREV, CM>(pos)>(OUT[k], s);  // the cell: s >> 2
                     }
                 });
                 T[dx] = t;
@@ -276,41 +301,52 @@ MIP_FN void mip_resample(const uint8_t *roi4, uint32_t shift, int64_t row_stride
     });
 }
 
-// The 8 motion bytes of one keypoint (byte = patch centre, bit = offset: MoFREAKUtilities.cpp:79-96, 308-316), .x = centres
-// 0..3, .y = centres 4..7 -- the uint2 the tile kernel stores behind the appearance bytes.
-//   cur_roi: address of the ROI's top-left pixel in the current frame (:293-295, 303-304); prev_delta: what to add to reach the
-//   same pixel of the previous frame (a scalar: the same for every keypoint of a frame pair).  Frames, row stride and
-//   prev_delta must be multiples of 4 bytes; mip_raw_dwords(L) dwords are read from each row's start rounded down to 4 bytes
-//   (the caller keeps ROIs whose last row could take that read past the end of the frame off this path).
-template <int L>
-MIP_FN MipUint2 mip_lane_keypoint(const uint8_t *cur_roi, int64_t prev_delta, int64_t row_stride, int mip_theta)
+// The motion bytes of one keypoint (byte = patch centre, bit = offset: MoFREAKUtilities.cpp:79-96, 308-316) for the patch
+// centres in the mask CM (bit c = centre c), packed in ascending order of c: the k-th centre of the mask is byte k & 3 of .x
+// (k < 4) or .y.  CM = 0xff: .x = centres 0..3, .y = centres 4..7 -- the uint2 the tile kernel stores behind the appearance
+// bytes; the tile kernel gives the centres {0, 1, 3, 5} and {2, 4, 6, 7} of a keypoint to two waves (kMipMaskA / kMipMaskB: the
+// split that shares the fewest cells of the previous buffer, 137 each of the 225).
+//   cur / prev: the two frames (scalars); roi: byte offset of the ROI's top-left pixel (:293-295, 303-304) in both, below
+//   2^32.  Frames and row stride must be multiples of 4 bytes; mip_raw_dwords(L) dwords (at least 3) are read from each
+//   row's start rounded down to 4 bytes (the caller keeps ROIs whose last row could take that read past the end of the frame
+//   off this path).
+constexpr int kMipMaskAll = 0xff, kMipMaskA = 0x2b, kMipMaskB = 0xd4;
+constexpr int mip_rank_in_mask(int cm, int c)
 {
-    const uint32_t shift = (uint32_t)(uintptr_t)cur_roi & 3u;
-    const uint8_t *cur4 = cur_roi - shift, *prev4 = cur4 + prev_delta;
+    int k = 0;
+    for (int i = 0; i < c; ++i) k += (cm >> i) & 1;
+    return k;
+}
+template <int L, int CM = kMipMaskAll>
+MIP_FN MipUint2 mip_lane_keypoint(const uint8_t *cur, const uint8_t *prev, uint32_t roi, int64_t row_stride, int mip_theta)
+{
+    const uint32_t shift = roi & 3u, off4 = roi - shift;
 
     // ---- the current buffer: the eight 9-byte strips start on dwords of the 19-byte-pitch buffer (19 * 4k and x - 1 = 4, 8,
     // 12 are multiples of 4): strip c is CW[s / 4], CW[s / 4 + 1] and the low byte of CW[s / 4 + 2]
     uint32_t CW[kMipDwords];
-    mip_resample<L, false>(cur4, shift, row_stride, CW, [](auto) {});
+    mip_resample<L, false, CM>(cur, off4, shift, row_stride, CW, [](auto) {});
     uint32_t CC[8];  // sum of squares of each strip
     static_for<8>([&](auto C) {
         constexpr int c = decltype(C)::value;
         constexpr int s = mip_cur_start(c);
         static_assert((s & 3) == 0, "current strips are dword-aligned");
-        const uint32_t c8 = CW[s / 4 + 2] & 0xffu;
-        CC[c] = mip_udot4(CW[s / 4], CW[s / 4], mip_udot4(CW[s / 4 + 1], CW[s / 4 + 1], c8 * c8));
+        if constexpr ((CM >> c) & 1) {
+            const uint32_t c8 = CW[s / 4 + 2] & 0xffu;
+            CC[c] = mip_udot4(CW[s / 4], CW[s / 4], mip_udot4(CW[s / 4 + 1], CW[s / 4 + 1], c8 * c8));
+        }
     });
 
     // ---- the previous buffer, row by row; a strip's SSD as soon as its last byte exists:
     // SSD = sum c^2 + sum p^2 - 2 sum c p (packed u8 dot products over the first eight bytes + the ninth byte's terms)
     uint32_t PW[kMipDwords];
     uint32_t mot[2] = {0u, 0u};
-    mip_resample<L, true>(prev4, shift, row_stride, PW, [&](auto DY) {
+    mip_resample<L, true, CM>(prev, off4, shift, row_stride, PW, [&](auto DY) {
         constexpr int dy = decltype(DY)::value;
         static_for<64>([&](auto CO) {
             constexpr int c = decltype(CO)::value >> 3, o = decltype(CO)::value & 7;
             constexpr int s = mip_prev_start(c, o);
-            if constexpr ((s + 8) / kAxisOut == dy) {
+            if constexpr (((CM >> c) & 1) && (s + 8) / kAxisOut == dy) {
                 constexpr int k = s >> 2, sh = s & 3, q = s + 8;
                 uint32_t p0, p1;
                 if constexpr (sh == 0) {
@@ -326,12 +362,13 @@ MIP_FN MipUint2 mip_lane_keypoint(const uint8_t *cur_roi, int64_t prev_delta, in
                 const uint32_t sq = mip_udot4(p0, p0, mip_udot4(p1, p1, CC[c] + p8 * p8));
                 const uint32_t cross = mip_udot4(CW[cs], p0, mip_udot4(CW[cs + 1], p1, c8 * p8));
                 const int d = mip_theta - (int)sq + 2 * (int)cross;  // negative <=> SSD > theta (:93)
-                // the sign bit goes to bit 8 (c & 3) + o of the centre's word
-                constexpr int bit = 8 * (c & 3) + o;
+                // the sign bit goes to bit o of the centre's byte
+                constexpr int rank = mip_rank_in_mask(CM, c);
+                constexpr int bit = 8 * (rank & 3) + o;
                 const uint32_t moved = (uint32_t)d >> (31 - bit);
-                uint32_t word = mot[c >> 2];  // (a copy: an asm operand does not capture)
+                uint32_t word = mot[rank >> 2];  // (a copy: an asm operand does not capture)
                 mip_and_or(word, moved, 1u << bit);
-                mot[c >> 2] = word;
+                mot[rank >> 2] = word;
             }
         });
     });

@@ -7,7 +7,7 @@ metric is bench.py's, on the in-tree library.
                                 must agree bit for bit)
   ab_tile.py --build NAME -DX   compile mofreak_amd/_exp/libvar_NAME.so from the tree's sources with extra flags
   ab_tile.py --ablate MASK      the stage ablation builds of profiles/: libvar_ablMASK.so from a COPY of tile_kernel.hip in which
-                                the blocks marked <stage 1> (MIP), <stage 2> (integral), <stage 3> (FREAK) are disabled for the
+                                the blocks marked <stage 1> (MIP, both forms), <stage 2> (integral), <stage 3> (FREAK) are disabled for the
                                 bits set in MASK (1, 2, 4).  The product source has no switch for this; results are wrong by
                                 construction (only the time is of interest)
 """
@@ -51,6 +51,12 @@ def ablate(mask):
     def patch(text):
         for bit, tag in ((1, "<stage 1>"), (2, "<stage 2>"), (4, "<stage 3>")):
             if mask & bit:
+                if bit == 1:  # the MIP: the lane-per-keypoint form beside stage 0 and the wave-per-keypoint stage
+                    call = "const uint2 mv = mip_lane_keypoint<L, decltype(CM)::value>(cur, prev, roi, a.f.row_stride, mip_theta);"
+                    assert text.count(call) == 1 and text.count("if (!mip_lane) {  // " + tag) == 1
+                    text = text.replace(call, "const uint2 mv = make_uint2(roi, 0u);")
+                    text = text.replace("if (!mip_lane) {  // " + tag, "if (false) {  // " + tag)
+                    continue
                 assert text.count("{  // " + tag) == 1, tag
                 text = text.replace("{  // " + tag, "if (false) {  // " + tag)
         return text

@@ -27,7 +27,8 @@ def test_instantiated_sides_match_the_kernel():
     import re
     kern = open(os.path.join(ROOT, "mofreak_amd", "csrc", "tile_kernel.hip")).read()
     lo, hi = map(int, re.search(r"kMipLaneMinL = (\d+), kMipLaneMaxL = (\d+)", kern).groups())
-    cases = sorted(int(m) for m in re.findall(r"run\(std::integral_constant<int, (\d+)>\{\}\)", kern))
+    cases = sorted(int(m) for m in re.findall(r"run_half\(std::integral_constant<int, (\d+)>\{\}\)", kern))
     assert cases == list(range(lo, hi + 1))
     host = open(os.path.join(ROOT, "tests", "helpers", "mip_lane_host.cpp")).read()
-    assert sorted(set(int(m) for m in re.findall(r"run_side<(\d+)>", host))) == cases
+    assert sorted(set(int(m) for m in re.findall(r"run_side<(\d+), kMipMaskA>", host))) == cases
+    assert sorted(set(int(m) for m in re.findall(r"run_side<(\d+), kMipMaskB>", host))) == cases
