@@ -210,24 +210,31 @@ int mofreak_gather_rows(mofreak_comm *c, const mofreak_row *d_rows, const int64_
 
 int mofreak_comm_self_exchange(mofreak_comm *c, int64_t n_bytes)
 {
-    if (!c || n_bytes <= 0) return fail(MOFREAK_ERR_BAD_ARG, "mofreak_comm_self_exchange: bad argument");
+    constexpr int64_t kMaxBytes = (int64_t)1 << 30;  // a self-test, not a transport: a gigabyte is plenty
+    if (!c || n_bytes <= 0 || n_bytes > kMaxBytes) return fail(MOFREAK_ERR_BAD_ARG, "mofreak_comm_self_exchange: bad argument");
     uint8_t *d = nullptr;
-    HIPD_TRY(hipMalloc((void **)&d, (size_t)2 * n_bytes));
-    std::vector<uint8_t> h((size_t)n_bytes), back((size_t)n_bytes, 0);
-    for (int64_t i = 0; i < n_bytes; ++i) h[(size_t)i] = (uint8_t)(i * 131 + 7);
     int rc = MOFREAK_OK;
-    RcclTransport t{c};
-    if (hipMemcpyAsync(d, h.data(), (size_t)n_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-        hipMemsetAsync(d + n_bytes, 0, (size_t)n_bytes, c->stream) != hipSuccess)
-        rc = fail(MOFREAK_ERR_HIP, "self exchange: upload failed");
-    if (!rc && !(rc = t.group_start())) {
-        int a = t.send(d, n_bytes, c->rank), b = t.recv(d + n_bytes, n_bytes, c->rank), e = t.group_end();
-        rc = a ? a : b ? b : e;
+    try {  // (no exception leaves this file: the vectors' allocations included)
+        std::vector<uint8_t> h((size_t)n_bytes), back((size_t)n_bytes, 0);
+        for (int64_t i = 0; i < n_bytes; ++i) h[(size_t)i] = (uint8_t)(i * 131 + 7);
+        if (hipMalloc((void **)&d, (size_t)2 * n_bytes) != hipSuccess) return fail(MOFREAK_ERR_OOM, "self exchange: device allocation failed");
+        RcclTransport t{c};
+        if (hipMemcpyAsync(d, h.data(), (size_t)n_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemsetAsync(d + n_bytes, 0, (size_t)n_bytes, c->stream) != hipSuccess)
+            rc = fail(MOFREAK_ERR_HIP, "self exchange: upload failed");
+        if (!rc && !(rc = t.group_start())) {
+            int a = t.send(d, n_bytes, c->rank), b = t.recv(d + n_bytes, n_bytes, c->rank), e = t.group_end();
+            rc = a ? a : b ? b : e;
+        }
+        if (!rc) rc = t.sync();
+        if (!rc && hipMemcpy(back.data(), d + n_bytes, (size_t)n_bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MOFREAK_ERR_HIP, "self exchange: download failed");
+        if (!rc && back != h) rc = fail(MOFREAK_ERR_HIP, "self exchange: the bytes that came back differ");
+    } catch (const std::bad_alloc &) {
+        rc = fail(MOFREAK_ERR_OOM, "self exchange: host allocation failed");
+    } catch (...) {
+        rc = fail(MOFREAK_ERR_HIP, "self exchange: unexpected exception");
     }
-    if (!rc) rc = t.sync();
-    if (!rc && hipMemcpy(back.data(), d + n_bytes, (size_t)n_bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MOFREAK_ERR_HIP, "self exchange: download failed");
-    (void)hipFree(d);
-    if (!rc && back != h) rc = fail(MOFREAK_ERR_HIP, "self exchange: the bytes that came back differ");
+    if (d) (void)hipFree(d);
     return rc;
 }
 

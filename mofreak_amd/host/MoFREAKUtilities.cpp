@@ -22,9 +22,10 @@ using std::string;
 namespace {
 
 // Gray frame stack in NumPy .npy format (v1/v2), dtype uint8, C order, shape (T, H, W).
-bool load_npy_u8_3d(const string &path, std::vector<uint8_t> &data, int &T, int &H, int &W)
+// the header of a .npy stack of u8 frames: its shape, and the file positioned at the first frame byte
+bool open_npy_u8_3d(std::ifstream &f, const string &path, int &T, int &H, int &W)
 {
-    std::ifstream f(path.c_str(), std::ios::binary);
+    f.open(path.c_str(), std::ios::binary);
     if (!f) return false;
     char magic[8];
     f.read(magic, 8);
@@ -65,6 +66,13 @@ bool load_npy_u8_3d(const string &path, std::vector<uint8_t> &data, int &T, int 
     T = (int)dims[0];
     H = (int)dims[1];
     W = (int)dims[2];
+    return true;
+}
+
+bool load_npy_u8_3d(const string &path, std::vector<uint8_t> &data, int &T, int &H, int &W)
+{
+    std::ifstream f;
+    if (!open_npy_u8_3d(f, path, T, H, W)) return false;
     data.resize((size_t)T * H * W);
     f.read(reinterpret_cast<char *>(data.data()), (std::streamsize)data.size());
     return (size_t)f.gcount() == data.size();
@@ -254,11 +262,16 @@ void MoFREAKUtilities::computeMoFREAKFromFilesSharded(const std::vector<std::str
     };
     const int rank = mofreak_comm_rank(comm), world = mofreak_comm_world(comm), n = (int)video_filenames.size();
     // the same plan on every rank: costs = file sizes, LPT shard, a rank's share cut into rounds of batch_bytes_
+    // (the sizes rank 0 sees, handed to everyone: ranks whose own stat() of a file differed -- a file that appears or
+    // goes away, attribute caches of a network file system -- would build different plans and hang in the exchange; a file
+    // rank 0 cannot stat costs nothing and is reported when its owner fails to open it)
     std::vector<int64_t> cost((size_t)n, 0);
-    for (int i = 0; i < n; ++i) {
-        struct stat st;
-        if (stat(video_filenames[i].c_str(), &st) == 0) cost[i] = (int64_t)st.st_size;
-    }
+    if (rank == 0)
+        for (int i = 0; i < n; ++i) {
+            struct stat st;
+            if (stat(video_filenames[i].c_str(), &st) == 0) cost[i] = (int64_t)st.st_size;
+        }
+    if (n > 0) dist_check(mofreak_allreduce_sum_i64(comm, cost.data(), n), "mofreak_allreduce_sum_i64 (file sizes)");
     std::vector<int32_t> rank_of((size_t)n, 0);
     dist_check(mofreak_shard_lpt(cost.data(), n, world, rank_of.data()), "mofreak_shard_lpt");
     std::vector<std::vector<std::vector<int>>> plan((size_t)world);  // rank -> round -> videos (ascending)
@@ -295,16 +308,32 @@ void MoFREAKUtilities::computeMoFREAKFromFilesSharded(const std::vector<std::str
             if (round < plan[r].size()) ids.insert(ids.end(), plan[r][round].begin(), plan[r][round].end());
         const std::vector<int> mine = round < plan[rank].size() ? plan[rank][round] : std::vector<int>();
         // my clips of the round: loaded, then run by run of one frame size through mofreak_extract_clips, rows left in HBM
-        struct Clip {
-            std::vector<uint8_t> frames;
+        struct Clip {  // frames in page-locked memory of the library (mofreak_host_alloc): mofreak_extract_clips copies them down by
+            uint8_t *frames = nullptr;  // DMA straight from here, pageable memory would go through its staging buffer first
             int T = 0, H = 0, W = 0;
             bool ok = false;
+            Clip() = default;
+            Clip(const Clip &) = delete;
+            Clip &operator=(const Clip &) = delete;
+            ~Clip()
+            {
+                if (frames) (void)mofreak_host_free(nullptr, frames);
+            }
         };
         std::vector<Clip> clips(mine.size());
         int64_t capacity = 0;
         for (size_t k = 0; k < mine.size(); ++k) {
             Clip &c = clips[k];
-            c.ok = load_npy_u8_3d(video_filenames[mine[k]], c.frames, c.T, c.H, c.W);
+            std::ifstream f;
+            c.ok = open_npy_u8_3d(f, video_filenames[mine[k]], c.T, c.H, c.W);
+            if (c.ok) {
+                const size_t bytes = (size_t)c.T * c.H * c.W;
+                void *mem = nullptr;
+                check(ctx, mofreak_host_alloc(ctx, std::max<size_t>(bytes, 1), &mem), "mofreak_host_alloc");
+                c.frames = static_cast<uint8_t *>(mem);
+                f.read(reinterpret_cast<char *>(c.frames), (std::streamsize)bytes);
+                c.ok = (size_t)f.gcount() == bytes;
+            }
             if (!c.ok) {
                 cout << "Could not open file: " << video_filenames[mine[k]] << endl;  // :383-386
                 continue;
@@ -325,7 +354,7 @@ void MoFREAKUtilities::computeMoFREAKFromFilesSharded(const std::vector<std::str
             std::vector<const uint8_t *> ptr;
             std::vector<int32_t> len;
             for (size_t k = k0; k < k1; ++k) {
-                ptr.push_back(clips[k].frames.data());
+                ptr.push_back(clips[k].frames);
                 len.push_back(clips[k].T);
             }
             const std::vector<mofreak_keypoint> kps = provider_(gap, clips[k0].W, clips[k0].H);

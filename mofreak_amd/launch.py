@@ -29,11 +29,21 @@ def launched_by_a_launcher() -> bool:
 def free_port() -> int:
     """A port rank 0's store can listen on.  Not simply bind(0): the kernel hands out a port again while connections of the
     job that had it a moment ago are still in TIME_WAIT (back-to-back runs), and a listener without SO_REUSEADDR -- the
-    store's -- is then refused.  A port picked at random that takes a plain bind + listen has no such leftovers."""
+    store's -- is then refused.  A port picked at random that takes a plain bind + listen has no such leftovers.  Drawn below
+    the kernel's ephemeral range (net.ipv4.ip_local_port_range, 32768 up by default): no outgoing connection of this host is
+    given such a port between this probe and the store's bind."""
     import random
+    lo, hi = 20000, 32768
+    try:
+        with open("/proc/sys/net/ipv4/ip_local_port_range") as f:
+            eph_lo = int(f.read().split()[0])
+        if eph_lo - 1024 >= 2048:
+            lo, hi = max(1024, min(20000, eph_lo - 8192)), eph_lo
+    except (OSError, ValueError, IndexError):
+        pass
     rng = random.Random(os.getpid() ^ time.monotonic_ns())
     for _ in range(64):
-        port = rng.randrange(20000, 60000)
+        port = rng.randrange(lo, hi)
         with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
             try:
                 s.bind(("127.0.0.1", port))

@@ -69,3 +69,34 @@ def test_bench_parent_starts_the_ranks_before_any_gpu_or_torch_import():
     assert torch_in_parent == "False"
     assert code != "0"  # no GPU in this container: the ranks cannot run the workload
     assert "[launch] rank" in r.stderr
+
+
+def test_cpp_launcher_stops_the_other_ranks_when_one_fails(tmp_path):
+    """facade_ranks (the libc-only launcher of the C++ route): a rank that ends badly, while the others would sit in a
+    collective for ever, ends the job -- the others are stopped and the launcher returns the failing rank's code."""
+    import stat
+    import subprocess
+    import time
+    launcher = os.path.join(ROOT, "mofreak_amd", "host", "facade_ranks")
+    if not os.path.exists(launcher):
+        subprocess.check_call(["make", "-C", os.path.dirname(launcher), "-s", "facade_ranks"])
+    prog = tmp_path / "rank.sh"
+    marks = tmp_path / "marks"
+    marks.mkdir()
+    # argv: files-rank <rank> <world> <id_file> <video_dir> <mofreak_dir>
+    prog.write_text("#!/bin/sh\necho $$ > %s/pid.$2\nif [ \"$2\" = \"1\" ]; then sleep 0.3; exit 3; fi\nsleep 120\n" % marks)
+    prog.chmod(prog.stat().st_mode | stat.S_IEXEC)
+    env = dict(os.environ, MOFREAK_RANK_PROGRAM=str(prog))
+    t0 = time.monotonic()
+    rc = subprocess.run([launcher, "3", str(tmp_path / "videos"), str(tmp_path / "out")], env=env, timeout=60).returncode
+    assert rc == 3
+    assert time.monotonic() - t0 < 20
+    for r in range(3):
+        pid = int((marks / f"pid.{r}").read_text())
+        assert not os.path.exists(f"/proc/{pid}"), f"rank {r} is still running"
+    # and the deadline: all ranks hang -> the launcher gives up and stops them
+    prog.write_text("#!/bin/sh\nsleep 120\n")
+    env["MOFREAK_RANKS_TIMEOUT_S"] = "1"
+    t0 = time.monotonic()
+    rc = subprocess.run([launcher, "2", str(tmp_path / "videos"), str(tmp_path / "out2")], env=env, timeout=60).returncode
+    assert rc == 124 and time.monotonic() - t0 < 20
