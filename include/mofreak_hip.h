@@ -340,10 +340,21 @@ int mofreak_bow_assign(mofreak_ctx *ctx, const uint8_t *desc16, const uint8_t *v
 int mofreak_bow_histogram(mofreak_ctx *ctx, const uint8_t *desc16, const uint8_t *valid, int64_t n, const uint8_t *codebook16,
                           int n_codewords, float *hist_out, int32_t *success_out, unsigned flags);
 
-/* ------------------------------------------------------------------ .mofreak text (host only) */
+/* ------------------------------------------------------------------ .mofreak text */
 /* MoFREAKUtilities::writeMoFREAKFeaturesToFile (MoFREAKUtilities.cpp:691-719), byte for byte.  Writes at
  * most cap bytes to buf (may be NULL) and always stores the full length in *needed. */
 int mofreak_format_rows(const mofreak_row *rows, int64_t n_rows, char *buf, size_t cap, size_t *needed);
+/* The same text made ON THE DEVICE from rows in device memory (the rows mofreak_extract_* leave there with MOFREAK_ROWS_DEVICE,
+ * or the root's gathered rows): writeMoFREAKFeaturesToFile (MoFREAKUtilities.cpp:691-719) byte for byte, `ostream << float`
+ * (printf "%g") included.  `text` (cap bytes; device memory, or page-locked host memory from mofreak_host_alloc, which the
+ * device writes directly; may be NULL to size) receives it, *needed its length.  One call serves many files: row_starts
+ * (host, n_segments ascending row indices; may be NULL with n_segments 0) are the first rows of the videos, and
+ * segment_offsets_out[i] (host, n_segments + 1 entries) the byte offset of row_starts[i]'s text, [n_segments] the total.
+ * A row with a float %g would print with an exponent (outside [1e-4, 1e6)), negative or not finite is not formatted here:
+ * MOFREAK_ERR_UNSUPPORTED, and the caller uses mofreak_format_rows (keypoint coordinates and sizes are never such values).
+ * MOFREAK_ERR_CAPACITY (with *needed set) when cap is too small.  Synchronises the context's stream. */
+int mofreak_format_rows_device(mofreak_ctx *ctx, const mofreak_row *d_rows, int64_t n_rows, char *text, size_t cap, size_t *needed,
+                               const int64_t *row_starts, int n_segments, size_t *segment_offsets_out);
 /* MoFREAKUtilities::readMoFREAKFeatures' row parser (MoFREAKUtilities.cpp:1146-1190), in FILE order (the
  * reference then stores them reversed, :1206-1210).  rows may be NULL to count. */
 int mofreak_parse_rows(const char *text, size_t len, mofreak_row *rows, int64_t rows_capacity,

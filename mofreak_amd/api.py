@@ -34,7 +34,7 @@ EXPORTS = [
     "mofreak_abi_version", "mofreak_build_flags", "mofreak_default_params", "mofreak_create", "mofreak_destroy", "mofreak_last_error",
     "mofreak_set_stream", "mofreak_synchronize", "mofreak_reserve", "mofreak_check_status",
     "mofreak_set_profiling", "mofreak_get_profile", "mofreak_set_path", "mofreak_get_tile_stamps", "mofreak_bgr_to_gray", "mofreak_bow_assign", "mofreak_bow_histogram",
-    "mofreak_extract_pairs", "mofreak_compact_rows", "mofreak_extract_stream", "mofreak_format_rows",
+    "mofreak_extract_pairs", "mofreak_compact_rows", "mofreak_extract_stream", "mofreak_format_rows", "mofreak_format_rows_device",
     "mofreak_extract_stream_pipelined", "mofreak_extract_clips", "mofreak_host_alloc", "mofreak_host_free",
     "mofreak_device_alloc", "mofreak_device_free", "mofreak_copy_to_host",
     "mofreak_parse_rows", "mofreak_diff_integral", "mofreak_mip19", "mofreak_roi19", "mofreak_freak_info",
@@ -125,6 +125,7 @@ def load() -> C.CDLL:
     L.mofreak_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.mofreak_host_free.argtypes = [vp, vp]
     L.mofreak_format_rows.argtypes = [vp, i64, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mofreak_format_rows_device.argtypes = [vp, vp, i64, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, C.c_int, vp]
     L.mofreak_parse_rows.argtypes = [C.c_char_p, C.c_size_t, vp, i64, C.POINTER(i64)]
     L.mofreak_diff_integral.argtypes = [vp, vp, vp, i32, i32, i64, i64, i32, vp, C.c_uint]
     L.mofreak_mip19.argtypes = [vp, vp, vp, i64, vp, C.c_uint]
@@ -486,6 +487,32 @@ class Context:
         fin = weakref.finalize(buf, _free_pinned, self._lib, p.value)
         _PINNED[arr.ctypes.data] = fin
         return arr
+
+    def format_rows_device(self, rows, n_rows: int | None = None, row_starts=None, out: np.ndarray | None = None):
+        """writeMoFREAKFeaturesToFile's text made on the device (mofreak_format_rows_device) from rows in DEVICE memory (a torch
+        CUDA tensor / anything with data_ptr(), or an int address) into a page-locked host array the device writes directly.
+        row_starts: first row of every video -> returns (text array, offsets) with offsets[i] : offsets[i + 1] the text of
+        video i; without it (text array, total).  `out`: a host_alloc() array to reuse (grown when too small).
+        Raises MoFREAKError(ERR_UNSUPPORTED) for rows the device leaves to format_rows (see include/mofreak_hip.h)."""
+        ptr = rows if isinstance(rows, int) else rows.data_ptr()
+        if n_rows is None:
+            n_rows = int(rows.numel() * rows.element_size() // 32)
+        starts = None if row_starts is None else np.ascontiguousarray(row_starts, dtype=np.int64)
+        n_seg = 0 if starts is None else len(starts)
+        seg = np.zeros(n_seg + 1, dtype=np.uint64)
+        need = C.c_size_t(0)
+        if out is None or out.nbytes < n_rows * 80:  # a row is ~75 characters; ERR_CAPACITY below covers the rest
+            out = self.host_alloc(max(int(n_rows) * 96, 256))
+        for _ in range(2):
+            rc = self._lib.mofreak_format_rows_device(self._h, C.c_void_p(ptr), n_rows, _ptr(out), out.nbytes, C.byref(need),
+                                                      None if starts is None else _ptr(starts), n_seg, _ptr(seg) if n_seg else None)
+            if rc != ERR_CAPACITY:
+                break
+            out = self.host_alloc(int(need.value) + 256)
+        self._check(rc)
+        if starts is None:
+            return out, int(need.value)
+        return out, seg.astype(np.int64)
 
     def host_free(self, arr: np.ndarray) -> None:
         """Release a host_alloc() array now (the caller promises that no view of it is used afterwards)."""

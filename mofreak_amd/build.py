@@ -9,7 +9,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmofreak_hip.so")
 DEBUG_LIB_PATH = os.path.join(PKG_DIR, "libmofreak_hip_debug.so")  # -DMOFREAK_DEBUG_BOUNDS: checked LDS accesses / stores
-SOURCES = ["kernels.hip", "tile_kernel.hip", "bow_kernel.hip", "detect_kernel.hip", "capi.cpp", "tables.cpp", "format.cpp"]
+SOURCES = ["tile_kernel.hip", "kernels.hip", "bow_kernel.hip", "detect_kernel.hip", "format_kernel.hip", "capi.cpp", "tables.cpp", "format.cpp"]
 HEADERS = ["tables.h", "device_types.h", "device_helpers.h", "mip_lane_order.inc", "mip_lane.h", "resize_axis.h", os.path.join("..", "..", "include", "mofreak_hip.h")]
 # -ffp-contract=off / -fno-fast-math: a handful of float/double expressions restate reference
 # expressions whose rounding is part of the result.

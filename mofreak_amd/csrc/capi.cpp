@@ -40,7 +40,7 @@ struct mofreak_ctx {
     DeviceBuffer kp_key, sorted_idx, slow_list, slow_count;  // keypoint binning (slow_count: all its counters, BinArgs)
     const int32_t *slow_band_start = nullptr;  // the last binning pass's band starts (inside slow_count) for the gather path behind it
     int slow_bands_per_pair = 0;
-    DeviceBuffer bow_counts, bow_expanded, pair_label;
+    DeviceBuffer bow_counts, bow_expanded, pair_label, fmt_ws;
     // keypoint detector workspace
     DeviceBuffer det_img, det_score, det_touch, det_status, det_rows, det_cand_xy, det_cand_flag, det_cand_emit, det_cand_spec, det_cand_asked, det_cand_win, det_cand_res, det_layer_start,
         det_emit_count, det_emit_chunks, det_geom, det_emit_offsets, det_out_kps, det_out_offsets, det_out_resp, det_out_layer, det_planes_out, det_hit_mask, det_walk_list, det_walk_count, det_cand_cells, det_tie_list, det_tie_count;
@@ -731,6 +731,7 @@ void mofreak_destroy(mofreak_ctx *ctx)
     release(ctx->slow_count);
     release(ctx->bow_counts);
     release(ctx->bow_expanded);
+    release(ctx->fmt_ws);
     for (DeviceBuffer *b : {&ctx->det_img, &ctx->det_score, &ctx->det_touch, &ctx->det_status, &ctx->det_rows, &ctx->det_cand_xy, &ctx->det_cand_flag,
                             &ctx->det_cand_emit, &ctx->det_cand_spec, &ctx->det_cand_asked, &ctx->det_cand_win, &ctx->det_cand_res, &ctx->det_layer_start, &ctx->det_emit_count, &ctx->det_emit_chunks, &ctx->det_geom, &ctx->det_emit_offsets,
                             &ctx->det_out_kps, &ctx->det_out_offsets, &ctx->det_out_resp, &ctx->det_out_layer, &ctx->det_planes_out, &ctx->det_hit_mask, &ctx->det_walk_list, &ctx->det_walk_count, &ctx->det_cand_cells, &ctx->det_tie_list, &ctx->det_tie_count})
@@ -1018,6 +1019,47 @@ static bool is_pinned_host(const void *p)
         return false;
     }
     return at.type == hipMemoryTypeHost;
+}
+
+int mofreak_format_rows_device(mofreak_ctx *ctx, const mofreak_row *d_rows, int64_t n_rows, char *text, size_t cap, size_t *needed,
+                               const int64_t *row_starts, int n_segments, size_t *segment_offsets_out)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    if (n_rows < 0 || (n_rows > 0 && !d_rows) || n_segments < 0 || (n_segments > 0 && (!row_starts || !segment_offsets_out)))
+        return fail(ctx, MOFREAK_ERR_BAD_ARG, "mofreak_format_rows_device: bad argument");
+    NEED_DEVICE(ctx);
+    for (int i = 1; i < n_segments; ++i)
+        if (row_starts[i] < row_starts[i - 1]) return fail(ctx, MOFREAK_ERR_BAD_ARG, "mofreak_format_rows_device: row_starts must ascend");
+    const size_t ws_bytes = format_workspace_bytes(n_rows, n_segments), tail = (size_t)std::max(n_segments, 1) * sizeof(int64_t) + 64;
+    int rc = ensure(ctx, ctx->fmt_ws, ws_bytes + tail);
+    if (rc) return rc;
+    uint8_t *ws = static_cast<uint8_t *>(ctx->fmt_ws.ptr);
+    int64_t *d_starts = reinterpret_cast<int64_t *>(ws + ws_bytes);
+    int32_t *d_bits = reinterpret_cast<int32_t *>(ws + ws_bytes + (size_t)std::max(n_segments, 1) * sizeof(int64_t));
+    HIP_TRY(ctx, hipMemsetAsync(d_bits, 0, sizeof(int32_t), ctx->stream));
+    if (n_segments > 0) HIP_TRY(ctx, hipMemcpyAsync(d_starts, row_starts, (size_t)n_segments * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    uint64_t *d_total = nullptr, *d_seg = nullptr;
+    int e = launch_format_measure(d_rows, n_rows, ws, d_starts, n_segments, d_bits, &d_total, &d_seg, ctx->stream);
+    if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("format (measure) launch: ") + hipGetErrorString((hipError_t)e));
+    uint64_t total = 0;
+    int32_t bits = 0;
+    std::vector<uint64_t> seg((size_t)std::max(n_segments, 1));
+    HIP_TRY(ctx, hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&bits, d_bits, sizeof bits, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_segments > 0) HIP_TRY(ctx, hipMemcpyAsync(seg.data(), d_seg, (size_t)n_segments * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (bits)
+        return fail(ctx, MOFREAK_ERR_UNSUPPORTED,
+                    "mofreak_format_rows_device: a row holds a float outside [1e-4, 1e6) (or negative / not finite): format these rows with mofreak_format_rows");
+    if (needed) *needed = (size_t)total;
+    for (int i = 0; i < n_segments; ++i) segment_offsets_out[i] = (size_t)seg[(size_t)i];
+    if (n_segments > 0) segment_offsets_out[n_segments] = (size_t)total;
+    if (!text) return MOFREAK_OK;
+    if (total > cap) return fail(ctx, MOFREAK_ERR_CAPACITY, "mofreak_format_rows_device: the text needs " + std::to_string(total) + " bytes");
+    e = launch_format_write(d_rows, n_rows, ws, text, (uint64_t)cap, ctx->stream);
+    if (e) return fail(ctx, MOFREAK_ERR_HIP, std::string("format (write) launch: ") + hipGetErrorString((hipError_t)e));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MOFREAK_OK;
 }
 
 int mofreak_device_alloc(mofreak_ctx *ctx, size_t bytes, void **out)

@@ -273,6 +273,11 @@ int launch_describe(const DescribeArgs &a, int n_blocks, void *stream);
 int launch_mip19(const uint8_t *cur19, const uint8_t *prev19, int64_t n, int mip_theta, uint8_t *out, void *stream);
 int launch_theta(const ThetaBound *tb, const int32_t *dirs, int64_t n, int32_t *out, void *stream);
 int launch_compact(const CompactArgs &a, void *stream);
+// .mofreak text on the device (format_kernel.hip): lengths + scan (+ segment offsets), then the text
+size_t format_workspace_bytes(int64_t n_rows, int n_segments);
+int launch_format_measure(const mofreak_row *d_rows, int64_t n_rows, void *ws, const int64_t *d_row_starts, int n_segments, int32_t *d_status_bits,
+                          uint64_t **d_total_out, uint64_t **d_seg_off_out, void *stream);
+int launch_format_write(const mofreak_row *d_rows, int64_t n_rows, void *ws, char *d_text, uint64_t cap, void *stream);
 int launch_bin(const BinArgs &a, void *stream);   // zeroes the counters, classifies, scans, scatters
 int launch_tile(const TileArgs &a, void *stream);
 int launch_bgr2gray(const uint8_t *bgr, int W, int H, int64_t row_stride, int64_t frame_stride, int n_frames, uint8_t *gray,
