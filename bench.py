@@ -514,16 +514,43 @@ def bench_dataset(args):
     clips = [pool[i % len(pool)][: lengths[i]] for i in range(n_clips)]
     names = [f"clip{i:05d}.avi" for i in range(n_clips)]
     batched = not args.per_clip_calls
-    harness.run_dataset(clips[: 64 * world], names[: 64 * world], None, mo, rank, world, on_device=on_device,
-                        workers=args.workers, batched=batched)  # warm-up
+    # --write: the path's product, <name>.mofreak TEXT files, inside the timed region: every rank formats its own videos' rows
+    # on the device and writes their files (tmp + fsync + rename) into one directory on a memory file system
+    out_dir = None
+    kw = {}
+    if args.write:
+        import shutil
+        base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+        out_dir = os.path.join(base or ".", f"mofreak_bench_c4_{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if world > 1 else os.getpid()}")
+        args.write_threads = args.write_threads or max(2, min(16, len(os.sched_getaffinity(0)) // max(1, world)))
+        kw = {"write": "ranks", "keep_rows": False, "write_threads": args.write_threads}
+    harness.run_dataset(clips[: 64 * world], names[: 64 * world], out_dir, mo, rank, world, on_device=on_device,
+                        workers=args.workers, batched=batched, **kw)  # warm-up
     steps = args.steps or 1
     fence(torch, dist, world)
     t0 = time.perf_counter()
     for _ in range(steps):
-        res = harness.run_dataset(clips, names, None, mo, rank, world, on_device=on_device, workers=args.workers, batched=batched)
+        res = harness.run_dataset(clips, names, out_dir, mo, rank, world, on_device=on_device, workers=args.workers, batched=batched, **kw)
     fence(torch, dist, world)
     elapsed = max_over_ranks(torch, dist, world, on_device, time.perf_counter() - t0)
     gather_s = max_over_ranks(torch, dist, world, on_device, res["gather_s"])
+    written = None
+    if args.write:
+        write_s = max_over_ranks(torch, dist, world, on_device, res["write_s"])
+        if rank == 0:  # what is on disk: every file there, a few of them compared byte for byte with the host formatter on a fresh extraction
+            files = [os.path.join(out_dir, n + ".mofreak") for n in names]
+            sizes = [os.path.getsize(f) for f in files]
+            checked = 0
+            for i in sorted({0, n_clips // 3, n_clips - 1}):
+                rows = mo._ctx.extract_stream_host(np.ascontiguousarray(clips[i]), harness.dense_grid_provider(cfg["step"], cfg["size"], cfg["lo"])(5, W, H))
+                import mofreak_amd as M
+                assert open(files[i], "rb").read() == M.format_rows(rows), f"{files[i]} differs from the host formatter's text"
+                checked += 1
+            written = {"files": len(files), "text_MB": sum(sizes) / 1e6, "write_s_max_over_ranks": write_s, "files_checked_against_host_formatter": checked,
+                       "directory": out_dir, "how": f"text made on the device per round (mofreak_format_rows_device), files written by each rank's {args.write_threads} threads, tmp + fsync + rename"}
+        fence(torch, dist, world)
+        if rank == 0:
+            shutil.rmtree(out_dir, ignore_errors=True)
     if rank == 0:
         n_kp = len(synth.config_grid("C4"))
         n_desc = int(((lengths - 5).clip(min=0) * n_kp).sum())
@@ -540,10 +567,11 @@ def bench_dataset(args):
                            "every rank's clips in ONE pipelined mofreak_extract_clips call, rows gathered device to device" if res["batched"]
                            else f"{args.workers} host thread(s) with a context each per rank, one synchronous C-ABI call per clip")},
             "frames_in_GBs": float(lengths.sum() * W * H * steps / elapsed / 1e9),
-            "gather_ms": gather_s * 1e3, "ranks_seen": ranks_seen(dist, world), **dist_info(dist, args), "rounds": res["rounds"],
+            "gather_ms": gather_s * 1e3, "ranks_seen": ranks_seen(dist, world), **dist_info(dist, args), "rounds": res["rounds"], "written": written,
             "rank0_seconds_last_step": {"extract": res["compute_s"], "exchange_and_copy_to_host": res["gather_s"]}, "frames_in_MB_per_step": float(lengths.sum() * W * H / 1e6),
-            "note": f"host frames in ({'pageable' if args.pageable else 'page-locked'} memory) -> rows on rank 0's host; "
-                    "compute, gather and the root's device-to-host copy are all inside the timed region"}))
+            "note": (f"host frames in ({'pageable' if args.pageable else 'page-locked'} memory) -> " + (
+                         "one .mofreak text file per clip, written by the rank that extracted it; extraction, formatting and the files are all inside the timed region"
+                         if args.write else "rows on rank 0's host; compute, gather and the root's device-to-host copy are all inside the timed region"))}))
     mo.close()
     if grouped(dist):
         dist.barrier()
@@ -729,6 +757,8 @@ def main():
     ap.add_argument("--per-clip-calls", action="store_true", help="C4: one synchronous mofreak_extract_stream call per clip (round 2's path) instead of "
                     "one mofreak_extract_clips call per rank")
     ap.add_argument("--pageable", action="store_true", help="C4: clips in ordinary (pageable) host memory instead of page-locked buffers")
+    ap.add_argument("--write", action="store_true", help="C4: write every clip's .mofreak text file inside the timed region (device formatter, each rank its own files)")
+    ap.add_argument("--write-threads", type=int, default=0, help="C4 --write: threads per rank that write the files (default: the rank's share of the cores, at most 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs of the workload the CPU oracle is timed on and the GPU output is verified on (default: all 256 of a step, about 35 core-seconds)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL); 'gloo' + "

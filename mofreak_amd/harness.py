@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import os
 from collections import deque
+from concurrent.futures import ThreadPoolExecutor
 from typing import Callable, Sequence
 
 import numpy as np
@@ -375,7 +376,8 @@ def _extract_batch(mofreak, stacks, use_batched: bool, to_device, workers: int, 
 
 def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mofreak: MoFREAKUtilities, rank: int = 0,
                 world_size: int = 1, costs: Sequence[float] | None = None, group=None, on_device: bool = False,
-                workers: int = 1, batched: bool = True, keep_rows: bool = True, batch_bytes: int = 4 << 30) -> dict:
+                workers: int = 1, batched: bool = True, keep_rows: bool = True, batch_bytes: int = 4 << 30,
+                write: str = "root", write_threads: int = 8) -> dict:
     """BASELINE config 4 end to end (main.cpp:854-924 over a whole dataset).
 
     videos[i]: a (T, H, W) uint8 gray stack or the path of a .npy file holding one; names[i]: its output stem.
@@ -393,6 +395,13 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
        bytes a 1-rank run writes; the files of a finished round are on disk before the next round starts (out_dir None:
        nothing is written).  keep_rows=False: rows are not kept after their round (with out_dir they are still
        written); without out_dir and without keep_rows nothing but the counts comes to the host.
+       write="ranks" (one node = one file system): every rank writes the files of ITS OWN videos -- the text is made on the
+       device from the rows the extraction left in HBM (mofreak_format_rows_device, one call per round with a segment per
+       video), lands in page-locked host memory and goes to the files from `write_threads` threads (tmp + fsync + rename each)
+       -- the same bytes in the same files, a round's files being written while the next round is extracted (two text buffers);
+       with keep_rows=False no row travels to the root at all (the exchange is the counts), so neither the root's link nor
+       its single formatter thread stands between eight GPUs and the disk.  write_s: what the rank waited for formatting and
+       for writes that had not finished when their buffer was needed again (and at the end).
     Returns timings and, on rank 0 with keep_rows, `rows_per_video`: views into a page-locked buffer that belongs to
     `mofreak` and is reused by its next run_dataset call (copy what has to outlive that); with per-frame keypoint sources
     (no capacity known up front) and several rounds: copies.
@@ -417,8 +426,17 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
     prov = getattr(mofreak, "keypoint_provider", None)
     use_batched = batched and not isinstance(prov, str) and getattr(prov, "shared", False)
     cuda = torch.cuda.is_available()
-    rows_dev = torch.device("cuda", mofreak._device) if (use_batched and distributed and cuda) else None
-    want_rows = keep_rows or out_dir is not None
+    by_ranks = write == "ranks" and out_dir is not None
+    if write not in ("root", "ranks"):
+        raise ValueError("write must be 'root' or 'ranks'")
+    rows_dev = torch.device("cuda", mofreak._device) if (use_batched and cuda and (distributed or by_ranks)) else None
+    want_rows = keep_rows or (out_dir is not None and not by_ranks)
+    if out_dir is not None and by_ranks:
+        os.makedirs(out_dir, exist_ok=True)
+    text_bufs = [None, None]  # page-locked text buffers: a round's files are written while the next round is extracted
+    pending = [[], []]        # the file writes still reading from each of them
+    text_bytes = 0
+    writers = ThreadPoolExecutor(max_workers=max(1, write_threads)) if by_ranks else None
     if rank == 0 and out_dir is not None:
         os.makedirs(out_dir, exist_ok=True)
 
@@ -442,6 +460,29 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
         del stacks
         rows_here += n_local
         t_compute += time.perf_counter() - t0
+        if by_ranks and mine:
+            # this rank's files of the round: text on the device, files from a few threads
+            t2 = time.perf_counter()
+            starts = np.concatenate([[0], np.cumsum(local_counts)]).astype(np.int64)
+            texts = None
+            slot = r & 1
+            for fut in pending[slot]:  # the files of two rounds ago read from this buffer
+                fut.result()
+            pending[slot] = []
+            if rows_dev is not None:
+                try:
+                    text_bufs[slot], offs = mofreak._ctx.format_rows_device(local, n_local, row_starts=starts[:-1], out=text_bufs[slot])
+                    texts = [text_bufs[slot][int(offs[k]): int(offs[k + 1])] for k in range(len(mine))]
+                except api.MoFREAKError as e:  # rows the device leaves to the host formatter (see include/mofreak_hip.h)
+                    if e.code != api.ERR_UNSUPPORTED:
+                        raise
+            if texts is None:
+                host_rows = local[: n_local * 32].cpu().numpy().view(api.ROW_DTYPE).reshape(-1) if rows_dev is not None else local
+                texts = list(writers.map(lambda k: api.format_rows(host_rows[starts[k]: starts[k + 1]]), range(len(mine))))
+            text_bytes += int(sum(len(t) for t in texts))
+            pending[slot] = [writers.submit(write_atomic, os.path.join(out_dir, names[mine[k]] + ".mofreak"), [t]) for k, t in enumerate(texts)]
+            del texts
+            t_write += time.perf_counter() - t2
 
         t1 = time.perf_counter()
         round_counts = np.zeros(len(round_ids), np.int64)
@@ -449,7 +490,15 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
         for i, c in zip(mine, local_counts):
             round_counts[pos[i]] = c
         all_rows = None
-        if distributed:
+        if distributed and not want_rows:  # files written by their ranks, rows not kept: the exchange is the counts
+            dev = torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu")
+            c = torch.from_numpy(round_counts).to(dev)
+            dist.all_reduce(c, group=group)
+            round_counts = c.cpu().numpy()
+            n_all = torch.tensor([n_local], dtype=torch.int64, device=dev)
+            dist.all_reduce(n_all, group=group)
+            per_rank = [int(n_all.item())]
+        elif distributed:
             dev = torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu")
             c = torch.from_numpy(round_counts).to(dev)
             dist.all_reduce(c, group=group)  # every video belongs to exactly one rank: the sum is the per-video count
@@ -493,19 +542,33 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
             for i, c in zip(round_ids, round_counts):
                 seg = all_rows[off: off + int(c)]
                 off += int(c)
-                if out_dir is not None:
+                if out_dir is not None and not by_ranks:
                     write_atomic(os.path.join(out_dir, names[i] + ".mofreak"), [api.format_rows(seg)])
                 if keep_rows:
                     rows_per_video[i] = seg if (n_rounds == 1 or keep_buf is not None) else seg.copy()
             keep_at += len(all_rows) if keep_buf is not None else 0
             t_write += time.perf_counter() - t2
 
+    if writers is not None:
+        t2 = time.perf_counter()
+        for slot in (0, 1):
+            for fut in pending[slot]:
+                fut.result()  # (a failed write raises here)
+        writers.shutdown()
+        t_write += time.perf_counter() - t2
+    for b in text_bufs:
+        if b is not None:
+            mofreak._ctx.host_free(b)
     out = {"compute_s": t_compute, "gather_s": t_gather, "videos_here": len(shards[rank]), "rows_here": int(rows_here),
            "batched": bool(use_batched), "rounds": n_rounds, "distributed": bool(distributed)}
+    if by_ranks:
+        out["write_s"] = t_write
+        out["text_bytes_here"] = int(text_bytes)
+        out["write"] = "ranks"
     if rank == 0:
         out["total_rows"] = int(total_rows)
         out["rows_per_video_counts"] = counts
-        if want_rows:
+        if want_rows and not by_ranks:
             out["write_s"] = t_write
         if keep_rows:
             out["rows_per_video"] = {i: rows_per_video.get(i, np.zeros(0, api.ROW_DTYPE)) for i in range(n)}

@@ -161,3 +161,39 @@ def test_one_stream_over_two_ranks_equals_the_whole_stream(tmp_path):
     assert one.tobytes() == want.tobytes() and len(want) == 26 * 5103
     mp.spawn(_stream_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert np.load(tmp_path / "rows.npy").tobytes() == want.tobytes()
+
+
+def test_every_rank_writes_its_own_files_with_text_made_on_the_device(oracle, tmp_path):
+    """write="ranks": the round's rows stay in HBM, mofreak_format_rows_device makes the text of all the rank's videos in one call,
+    the files are written from threads -- the same bytes in the same files as the root-writes-everything route, in several
+    rounds of mixed frame sizes and with a clip too short to have rows (an empty file); nothing is kept on the host."""
+    clips, names, _ = _clips()
+    clips, names = clips[:12], names[:12]
+    clips[3] = np.ascontiguousarray(synth.synth_stack(19, 400, 300, t0=31))
+    clips[5] = clips[5][:4]  # no pair at all
+    mo = _mofreak()
+    try:
+        root = harness.run_dataset(clips, names, str(tmp_path / "root"), mo, batch_bytes=12 << 20, keep_rows=False)
+        ranks = harness.run_dataset(clips, names, str(tmp_path / "ranks"), mo, batch_bytes=12 << 20, keep_rows=False, write="ranks", write_threads=3)
+        kept = harness.run_dataset(clips, names, str(tmp_path / "kept"), mo, write="ranks")  # rows still wanted on the host: both
+        kept_rows = {i: r.copy() for i, r in kept["rows_per_video"].items()}
+    finally:
+        mo.close()
+    assert ranks["rounds"] > 2 and ranks["write"] == "ranks" and "rows_per_video" not in ranks and ranks["total_rows"] == root["total_rows"]
+    f = oracle.Freak()
+    c = synth.CONFIGS["C4"]
+    total = 0
+    for i, clip in enumerate(clips):
+        a = open(tmp_path / "root" / (names[i] + ".mofreak"), "rb").read()
+        assert open(tmp_path / "ranks" / (names[i] + ".mofreak"), "rb").read() == a, names[i]
+        assert open(tmp_path / "kept" / (names[i] + ".mofreak"), "rb").read() == a, names[i]
+        assert M.format_rows(kept_rows[i]) == a
+        total += len(a)
+        if i in (0, 3):
+            kps = synth.dense_grid(clip.shape[2], clip.shape[1], c["step"], c["size"], c["lo"])
+            n_pairs = len(clip) - 5
+            want = f.extract_stream(clip, np.tile(kps, (n_pairs, 1)), np.arange(n_pairs + 1, dtype=np.int64) * len(kps))
+            assert a == oracle.format_rows(want)
+    assert os.path.getsize(tmp_path / "ranks" / (names[5] + ".mofreak")) == 0
+    assert ranks["text_bytes_here"] == total
+    assert not [n for n in os.listdir(tmp_path / "ranks") if n.endswith(".tmp")]
