@@ -379,6 +379,65 @@ void MoFREAKUtilities::computeMoFREAKFromFilesSharded(const std::vector<std::str
         dist_check(mofreak_gather_counts(comm, n_mine, rank_count.data()), "mofreak_gather_counts");
         int64_t total = 0;
         for (int64_t c : rank_count) total += c;
+        {  // what every rank knows of the round
+            int64_t sum = 0;
+            for (int64_t c : video_count) sum += std::max<int64_t>(c, 0);
+            if (sum != total) throw std::runtime_error("computeMoFREAKFromFilesSharded: per-video and per-rank counts disagree");
+        }
+        if (files_by_ranks_) {
+            // my videos' files, from text made where the rows are: one device call for the round, a segment per video
+            check(ctx, mofreak_synchronize(ctx), "mofreak_synchronize");
+            std::vector<int64_t> starts;
+            std::vector<size_t> which;
+            int64_t at = 0;
+            for (size_t k = 0; k < mine.size(); ++k) {
+                if (count_of[k] < 0) continue;  // could not be opened: no file (as the gathered route)
+                starts.push_back(at);
+                which.push_back(k);
+                at += count_of[k];
+            }
+            std::vector<size_t> seg(starts.size() + 1, 0);
+            size_t need = 0;
+            struct HostText {
+                void *p = nullptr;
+                ~HostText()
+                {
+                    if (p) (void)mofreak_host_free(nullptr, p);
+                }
+            } text;
+            bool on_device = true;
+            int rc = mofreak_format_rows_device(ctx, static_cast<const mofreak_row *>(mine_rows.p), n_mine, nullptr, 0, &need, starts.data(), (int)starts.size(), seg.data());
+            if (rc == MOFREAK_OK) {
+                check(ctx, mofreak_host_alloc(ctx, std::max<size_t>(need, 1), &text.p), "mofreak_host_alloc");
+                rc = mofreak_format_rows_device(ctx, static_cast<const mofreak_row *>(mine_rows.p), n_mine, static_cast<char *>(text.p), need, &need, starts.data(),
+                                                (int)starts.size(), seg.data());
+            }
+            if (rc == MOFREAK_ERR_UNSUPPORTED) {
+                on_device = false;  // a float the device leaves to the host formatter: rows to the host, text there
+            } else {
+                check(ctx, rc, "mofreak_format_rows_device");
+            }
+            std::vector<mofreak_row> host_rows;
+            if (!on_device) {
+                host_rows.resize((size_t)std::max<int64_t>(n_mine, 1));
+                check(ctx, mofreak_copy_to_host(ctx, host_rows.data(), mine_rows.p, (size_t)n_mine * sizeof(mofreak_row)), "mofreak_copy_to_host");
+            }
+            for (size_t j = 0; j < which.size(); ++j) {
+                const std::string &name = mofreak_filenames[mine[which[j]]];
+                cout << "Writing this mofreak file: " << name << endl;
+                if (on_device) {
+                    writeTextToFile(name, static_cast<const char *>(text.p) + seg[j], seg[j + 1] - seg[j]);
+                } else {
+                    std::string t;
+                    size_t len = 0;
+                    (void)mofreak_format_rows(host_rows.data() + starts[j], count_of[which[j]], nullptr, 0, &len);
+                    t.resize(len);
+                    (void)mofreak_format_rows(host_rows.data() + starts[j], count_of[which[j]], &t[0], len, &len);
+                    writeTextToFile(name, t.data(), t.size());
+                }
+            }
+            continue;
+        }
         if (rank == 0) check(ctx, mofreak_device_alloc(ctx, (size_t)std::max<int64_t>(total, 1) * sizeof(mofreak_row), &all_rows.p), "mofreak_device_alloc");
         check(ctx, mofreak_synchronize(ctx), "mofreak_synchronize");  // my rows are in place before the exchange stream reads them
         dist_check(mofreak_gather_rows(comm, static_cast<const mofreak_row *>(mine_rows.p), rank_count.data(), 0, static_cast<mofreak_row *>(all_rows.p)),
@@ -510,6 +569,16 @@ mofreak_row row_of(const MoFREAKFeature &f)
 }
 
 }  // namespace
+
+void MoFREAKUtilities::writeTextToFile(const std::string &output_file, const char *text, size_t len)
+{
+    const std::string tmp = output_file + ".tmp";
+    FILE *out = std::fopen(tmp.c_str(), "wb");
+    if (!out) throw std::runtime_error("cannot write " + tmp);
+    const bool written = len == 0 || std::fwrite(text, 1, len, out) == len;
+    const bool synced = written && std::fflush(out) == 0 && fsync(fileno(out)) == 0;
+    if (std::fclose(out) != 0 || !synced || std::rename(tmp.c_str(), output_file.c_str()) != 0) throw std::runtime_error("cannot finish " + output_file);
+}
 
 void MoFREAKUtilities::writeMoFREAKFeaturesToFile(string output_file)
 {

@@ -106,12 +106,18 @@ public:
     // round through mofreak_extract_clips with the rows left in HBM, the per-video row counts summed over the ranks, the
     // rows gathered to rank 0 over RCCL (ncclAllGather of the counts, grouped ncclSend / ncclRecv peer -> root), and rank 0
     // writes the round's files -- the bytes computeMoFREAKFromFiles writes.  Dense-grid keypoints only.
+    // setFilesWrittenByTheirRanks(true) (the default; one node = one file system): the files are the output, so every rank
+    // writes those of ITS OWN videos -- text made on the device from the rows in HBM (mofreak_format_rows_device, one call per
+    // round), file by file through <name>.tmp + fsync + rename -- and only the counts are exchanged: no row crosses a link,
+    // rank 0 formats nothing.  false: the rows are gathered to rank 0 over RCCL and rank 0 writes everything (above).
+    void setFilesWrittenByTheirRanks(bool on) { files_by_ranks_ = on; }
     void computeMoFREAKFromFilesSharded(const std::vector<std::string> &video_filenames, const std::vector<std::string> &mofreak_filenames,
                                         struct mofreak_comm *comm);
 
 private:
     void readMetadata(const std::string &filename, int &action, int &video_number, int &person);
     void appendRows(const mofreak_row *rows, int64_t n_rows, const std::string &video_filename);
+    static void writeTextToFile(const std::string &output_file, const char *text, size_t len);  // <file>.tmp + fsync + rename
     mofreak_ctx *context();
 
     std::deque<MoFREAKFeature> features;
@@ -122,6 +128,7 @@ private:
     KeypointProvider provider_;
     bool provider_shared_;
     size_t batch_bytes_ = (size_t)2 << 30;
+    bool files_by_ranks_ = true;
     bool use_brisk_;
     int brisk_threshold_, brisk_octaves_;
 };

@@ -1,8 +1,10 @@
 // Small driver over the C++ MoFREAKUtilities facade, used by tests/test_facade.py and as a usage example:
 //   facade_main extract <video.npy> <out.mofreak> [grid_step grid_size grid_lo | brisk]   (needs a GPU)
 //   facade_main files <video_dir> <mofreak_dir>      computeMoFREAKFiles() of main.cpp:854-924 for *.npy (needs a GPU)
-//   facade_main files-rank <rank> <N> <id_file> <video_dir> <mofreak_dir>   one rank of the same over N GPUs, rows gathered to
-//                                                     rank 0 over RCCL; started N times by `facade_ranks N <video_dir> <mofreak_dir>`
+//   facade_main files-rank <rank> <N> <id_file> <video_dir> <mofreak_dir>   one rank of the same over N GPUs: every rank writes the
+//                                                     files of its own videos from text made on the device; with
+//                                                     MOFREAK_GATHER_TO_ROOT=1 the rows are gathered to rank 0 over RCCL and
+//                                                     rank 0 writes; started N times by `facade_ranks N <video_dir> <mofreak_dir>`
 //                                                     (facade_ranks.c: a launcher that loads no GPU library at all)
 //   facade_main roundtrip <in.mofreak> <out.mofreak>  read (reversed, as the reference) + write (no GPU)
 #include <dirent.h>
@@ -100,6 +102,7 @@ static int run_rank(int rank, int world, const std::string &id_file, const std::
         mofreak.setDevice(rank);
         mofreak.setDenseGrid(16, 7.0f, 23);
         if (const char *b = std::getenv("MOFREAK_BATCH_BYTES")) mofreak.setBatchBytes((size_t)std::atoll(b));
+        if (const char *g = std::getenv("MOFREAK_GATHER_TO_ROOT")) mofreak.setFilesWrittenByTheirRanks(std::atoi(g) == 0);  // 1: rows to rank 0 over RCCL, rank 0 writes
         std::vector<std::string> videos, outputs;
         walk_dataset(mofreak, video_path, mofreak_path, rank == 0, videos, outputs);
         mofreak.computeMoFREAKFromFilesSharded(videos, outputs, comm);

@@ -126,14 +126,18 @@ def test_cpp_ranks_over_rccl_write_the_files_of_the_plain_walk(facade, tmp_path)
     one.mkdir()
     subprocess.check_call([facade, "files", str(vdir), str(one)])
     launcher = os.path.join(os.path.dirname(facade), "facade_ranks")
-    env = dict(os.environ, MOFREAK_BATCH_BYTES=str(400_000), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    msg = subprocess.run([launcher, "1", str(vdir), str(many)], env=env, text=True, capture_output=True, timeout=300)
-    assert msg.returncode == 0, msg.stdout[-2000:] + msg.stderr[-2000:]
-    assert "ranks 1 videos 6" in msg.stdout
-    for name in clips:
-        a, b = (one / (name + ".mofreak")).read_bytes(), (many / (name + ".mofreak")).read_bytes()
-        assert a == b and (len(a) > 0 or name.endswith("short.npy")), name
-    assert not [f for f in os.listdir(many) if f.startswith(".mofreak_rccl_id")]
+    # both ways to the files: every rank writes its own videos' files from text made on the device (the default), and rows
+    # gathered to rank 0 over RCCL with rank 0 writing
+    for gather, out in (("0", many), ("1", tmp_path / "gathered")):
+        env = dict(os.environ, MOFREAK_BATCH_BYTES=str(400_000), HSA_ENABLE_IPC_MODE_LEGACY="0", MOFREAK_GATHER_TO_ROOT=gather)
+        msg = subprocess.run([launcher, "1", str(vdir), str(out)], env=env, text=True, capture_output=True, timeout=300)
+        assert msg.returncode == 0, msg.stdout[-2000:] + msg.stderr[-2000:]
+        assert "ranks 1 videos 6" in msg.stdout
+        for name in clips:
+            a, b = (one / (name + ".mofreak")).read_bytes(), (out / (name + ".mofreak")).read_bytes()
+            assert a == b and (len(a) > 0 or name.endswith("short.npy")), (gather, name)
+        assert not [f for f in os.listdir(out) if f.startswith(".mofreak_rccl_id")]
+        assert not [f for d, _, fs in os.walk(out) for f in fs if f.endswith(".tmp")]
 
 
 def test_dist_library_exports_its_header_and_the_exchange_logic_runs_on_the_cpu():
