@@ -637,6 +637,10 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
     const bool mip_lane = uniform && tile_L >= kMipLaneMinL && tile_L <= kMipLaneMaxL && (!STAMPS || tile_L == 12) &&
                           (((uintptr_t)cur | (uintptr_t)prev | (uintptr_t)a.f.row_stride) & 3) == 0 && (int64_t)H * a.f.row_stride < ((int64_t)1 << 32) &&
                           !(ty == a.tiles_y - 1 && (tx + 1) * kTileW + 32 > W) && one_batch;
+    // Then nobody reads the staged gray bytes in LDS: the staging waves run the integral's row pass (stage 2a) on the bytes as
+    // they arrive in their registers -- a staging step's 16 lanes per region row ARE the row pass's -- and write integral
+    // rows, not bytes, in the time the MIP waves still need: no stores and re-loads of the bytes, one workgroup barrier less.
+    const bool fuse_rows = mip_lane && wide;
     // per-lane constants of the MIP sampling passes: the LDS address the lane's pixels go to, and -- once the ROI side
     // is known -- the LDS addresses of each pixel's two source rows for a ROI at the region's origin (the second byte
     // of a row pair is the next one: where cv::resize clamps the column instead, its weight is zero) and its weights.
@@ -663,6 +667,42 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
         }
     };
     const bool tail_ok = lane + 64 * (kMipIters - 1) < a.mip_n;  // the last pass is a partial one (launch_tile checks mip_n)
+
+    // One 16-pixel piece of a region row of the integral's row pass (stage 2a): |cur - prev| and the running sum inside the lane's
+    // 16 pixels from v_sad_u8 on masked dwords, the lane totals scanned across the 16 lanes of the DPP row that share the region
+    // row, the piece's 16 sums (modulo 2^16) stored at their place in LDS row r + 1.  cc / pp: the piece's bytes of the two frames;
+    // q: the piece's index in the row.  Every lane of a DPP row must call it (the scan), lanes past the row's pieces with any bytes.
+    auto integral_row_piece = [&](const LdsU4 cc, const LdsU4 pp, int r, int q) {
+        uint32_t pk[8];
+        uint32_t acc = 0;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {
+            const uint32_t x = w4 == 0 ? cc.x : w4 == 1 ? cc.y : w4 == 2 ? cc.z : cc.w;
+            const uint32_t y = w4 == 0 ? pp.x : w4 == 1 ? pp.y : w4 == 2 ? pp.z : pp.w;
+            // the first one, two, three bytes: the other bytes of y replaced by x's, where they add nothing (one v_bfi
+            // per prefix instead of two masks)
+            const uint32_t s0 = __builtin_amdgcn_sad_u8(x, (y & 0xffu) | (x & ~0xffu), acc);
+            const uint32_t s1 = __builtin_amdgcn_sad_u8(x, (y & 0xffffu) | (x & ~0xffffu), acc);
+            const uint32_t s2 = __builtin_amdgcn_sad_u8(x, (y & 0xffffffu) | (x & ~0xffffffu), acc);
+            acc = __builtin_amdgcn_sad_u8(x, y, acc);
+            pk[2 * w4] = __builtin_amdgcn_perm(s1, s0, 0x05040100u);      // low halves: s0 | s1 << 16
+            pk[2 * w4 + 1] = __builtin_amdgcn_perm(acc, s2, 0x05040100u);
+        }
+        int incl = (int)acc;  // inclusive scan of the lane totals across the region row (16 x 255 x 12 < 2^16)
+        incl += dpp_row_shr(incl, 1);
+        incl += dpp_row_shr(incl, 2);
+        incl += dpp_row_shr(incl, 4);
+        incl += dpp_row_shr(incl, 8);
+        const uint32_t excl = (uint32_t)incl - acc;
+        const uint32_t carry2 = __builtin_amdgcn_perm(excl, excl, 0x05040504u);  // low half in both halves
+        if (r < RH && q < runs) {
+            uint8_t *row = lds + kOffIntegral + __umul24(r + 1, kTileStagePitch);
+            uint4 *dst = reinterpret_cast<uint4 *>(row + (8 + 16 * q) * 2);
+            dst[0] = make_uint4(pk_add_u16(pk[0], carry2), pk_add_u16(pk[1], carry2), pk_add_u16(pk[2], carry2), pk_add_u16(pk[3], carry2));
+            dst[1] = make_uint4(pk_add_u16(pk[4], carry2), pk_add_u16(pk[5], carry2), pk_add_u16(pk[6], carry2), pk_add_u16(pk[7], carry2));
+            if (q == 0) *reinterpret_cast<uint32_t *>(row + (kIColOff - 1) * 2) = 0;  // logical column 0
+        }
+    };
 
     if (mip_lane && wave < kMipWaves) {  // (a scalar branch: nothing of the staging path is alive in here)
         // ---- stage 1 for the usual tile, beside stage 0: waves 2 s and 2 s + 1 take keypoints 64 s .. 64 s + 63 (a single
@@ -738,7 +778,17 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
         if (uniform && !mip_lane) load_samples(tile_L);  // one ROI side in the whole tile (the usual case): its samples stay in registers
         make_records(0, min(kBatch, n_tile_kp), !mip_lane, stid);
         if (stid >= 0 && stid < kThetaBounds) s_theta[stid] = a.theta[stid];
-        if (wide) {
+        if (fuse_rows) {
+            if (stager) {
+                for (int i = stid; i < kIPitchDw; i += kStageThreads) reinterpret_cast<uint32_t *>(lds + kOffIntegral)[i] = 0;  // integral row 0
+#pragma unroll
+                for (int u = 0; u < kStageIters; ++u) {
+                    if (kStageRows * u < RH)  // (a last partial step: the rows it re-read are written again, with the same sums)
+                        integral_row_piece(LdsU4{v[0][u].w[0], v[0][u].w[1], v[0][u].w[2], v[0][u].w[3]}, LdsU4{v[1][u].w[0], v[1][u].w[1], v[1][u].w[2], v[1][u].w[3]},
+                                           min(kStageRows * u, RH - kStageRows) + sr, sq);
+                }
+            }
+        } else if (wide) {
             if (stager && sq < runs) {
 #pragma unroll
                 for (int u = 0; u < kStageIters; ++u) {
@@ -899,6 +949,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
         // 2a: row pass, no workgroup barrier.  The 16 lanes of a DPP row share one region row: a lane owns 16 pixels,
         //     |cur - prev| and the running sum inside them come from v_sad_u8 on masked dwords, the lane totals are
         //     scanned across the row with four DPP adds.  A wave takes four region rows per step.
+        if (!fuse_rows) {
         const int rr = lane >> 4, q = lane & 15;
         LdsU4 c[kRowGroupIters], p[kRowGroupIters];
 #pragma unroll
@@ -910,39 +961,10 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
         }
         for (int i = tid; i < kIPitchDw; i += kTileThreads) reinterpret_cast<uint32_t *>(lds + kOffIntegral)[i] = 0;  // integral row 0
 #pragma unroll
-        for (int u = 0; u < kRowGroupIters; ++u) {
-            const int r = 4 * (wave + kTileWaves * u) + rr;
-            uint32_t pk[8];
-            uint32_t acc = 0;
-#pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) {
-                const uint32_t x = w4 == 0 ? c[u].x : w4 == 1 ? c[u].y : w4 == 2 ? c[u].z : c[u].w;
-                const uint32_t y = w4 == 0 ? p[u].x : w4 == 1 ? p[u].y : w4 == 2 ? p[u].z : p[u].w;
-                // the first one, two, three bytes: the other bytes of y replaced by x's, where they add nothing (one v_bfi
-                // per prefix instead of two masks)
-                const uint32_t s0 = __builtin_amdgcn_sad_u8(x, (y & 0xffu) | (x & ~0xffu), acc);
-                const uint32_t s1 = __builtin_amdgcn_sad_u8(x, (y & 0xffffu) | (x & ~0xffffu), acc);
-                const uint32_t s2 = __builtin_amdgcn_sad_u8(x, (y & 0xffffffu) | (x & ~0xffffffu), acc);
-                acc = __builtin_amdgcn_sad_u8(x, y, acc);
-                pk[2 * w4] = __builtin_amdgcn_perm(s1, s0, 0x05040100u);      // low halves: s0 | s1 << 16
-                pk[2 * w4 + 1] = __builtin_amdgcn_perm(acc, s2, 0x05040100u);
-            }
-            int incl = (int)acc;  // inclusive scan of the lane totals across the region row (16 x 255 x 12 < 2^16)
-            incl += dpp_row_shr(incl, 1);
-            incl += dpp_row_shr(incl, 2);
-            incl += dpp_row_shr(incl, 4);
-            incl += dpp_row_shr(incl, 8);
-            const uint32_t excl = (uint32_t)incl - acc;
-            const uint32_t carry2 = __builtin_amdgcn_perm(excl, excl, 0x05040504u);  // low half in both halves
-            if (r < RH && q < runs) {
-                uint8_t *row = lds + kOffIntegral + __umul24(r + 1, kTileStagePitch);
-                uint4 *dst = reinterpret_cast<uint4 *>(row + (8 + 16 * q) * 2);
-                dst[0] = make_uint4(pk_add_u16(pk[0], carry2), pk_add_u16(pk[1], carry2), pk_add_u16(pk[2], carry2), pk_add_u16(pk[3], carry2));
-                dst[1] = make_uint4(pk_add_u16(pk[4], carry2), pk_add_u16(pk[5], carry2), pk_add_u16(pk[6], carry2), pk_add_u16(pk[7], carry2));
-                if (q == 0) *reinterpret_cast<uint32_t *>(row + (kIColOff - 1) * 2) = 0;  // logical column 0
-            }
+        for (int u = 0; u < kRowGroupIters; ++u) integral_row_piece(c[u], p[u], 4 * (wave + kTileWaves * u) + rr, q);
+        __syncthreads();
         }
-        __syncthreads();  TILE_STAMP(2);
+        TILE_STAMP(2);
         // 2b: column pass.  A thread owns a 16-row segment of two adjacent dword columns (four pixels, 8-byte LDS
         //     accesses): running packed sums in registers, segment totals -> LDS; after the barrier it adds the totals
         //     of the segments above.
