@@ -367,7 +367,7 @@ def bench_resident(args):
     # was shorter than two seconds, the same step keeps running for about two more (its own clock, reported as `sustained`,
     # never `value`), so the device is visibly busy and the timed figure has a longer run beside it
     sustained = None
-    if elapsed < 2.0:
+    if elapsed < 2.0 and not args.no_sustain:
         extra = int(min(5000, max(steps, math.ceil(2.0 / (elapsed / steps)))))
         fence(torch, dist, world)
         ts = time.perf_counter()
@@ -495,6 +495,15 @@ def bench_resident(args):
 
 
 # ------------------------------------------------------------------------------------------------ C4: a dataset of clips
+def shard_stats(harness, lengths, world, n_kp):
+    """How even the longest-processing-time-first shard is, and what the root would take in if the rows were gathered to it."""
+    shards = harness.shard_videos([int(x) for x in lengths], world)
+    loads = [int(sum(int(lengths[i]) for i in s)) for s in shards]
+    rows = [int(sum(max(int(lengths[i]) - 5, 0) for i in s)) * n_kp for s in shards]
+    return {"frames_per_rank_max_over_mean": max(loads) / (sum(loads) / len(loads)), "clips_per_rank": [len(s) for s in shards],
+            "root_ingest_MB_if_rows_are_gathered": sum(rows[1:]) * 32 / 1e6, "rows_per_rank": rows}
+
+
 def bench_dataset(args):
     torch, dist, rank, local_rank, world, on_device = dist_setup(args)
     from mofreak_amd import harness, synth
@@ -568,6 +577,7 @@ def bench_dataset(args):
                            else f"{args.workers} host thread(s) with a context each per rank, one synchronous C-ABI call per clip")},
             "frames_in_GBs": float(lengths.sum() * W * H * steps / elapsed / 1e9),
             "gather_ms": gather_s * 1e3, "ranks_seen": ranks_seen(dist, world), **dist_info(dist, args), "rounds": res["rounds"], "written": written,
+            "shard": shard_stats(harness, lengths, world, n_kp),
             "rank0_seconds_last_step": {"extract": res["compute_s"], "exchange_and_copy_to_host": res["gather_s"]}, "frames_in_MB_per_step": float(lengths.sum() * W * H / 1e6),
             "note": (f"host frames in ({'pageable' if args.pageable else 'page-locked'} memory) -> " + (
                          "one .mofreak text file per clip, written by the rank that extracted it; extraction, formatting and the files are all inside the timed region"
@@ -760,6 +770,7 @@ def main():
     ap.add_argument("--write", action="store_true", help="C4: write every clip's .mofreak text file inside the timed region (device formatter, each rank its own files)")
     ap.add_argument("--write-threads", type=int, default=0, help="C4 --write: threads per rank that write the files (default: the rank's share of the cores, at most 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sustain", action="store_true", help="do not keep the step running for two seconds after a short timed region (profiler runs: every launch is traced)")
     ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs of the workload the CPU oracle is timed on and the GPU output is verified on (default: all 256 of a step, about 35 core-seconds)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL); 'gloo' + "
                     "--share-device rehearses the N > 1 control flow on a one-GPU box")

@@ -9,7 +9,7 @@ root=$PWD
 cd /tmp && export TMPDIR=/tmp && cd $root
 out=gpurun_out/prof_$tag
 rm -rf $out && mkdir -p $out
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-detector > $out/bench_stats.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-detector --no-sustain > $out/bench_stats.log 2>&1
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_bench_kernel_stats.csv
 grep "^{" $out/bench_stats.log > gpurun_out/${tag}_bench_line_under_rocprof.json || true
 i=0
@@ -18,7 +18,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CU_C
            "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-detector > $out/pmc$i.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-detector --no-sustain > $out/pmc$i.log 2>&1
 done
 python3 - $tag $out <<'PY'
 import csv, glob, collections, hashlib, json, sys
