@@ -230,6 +230,16 @@ int mofreak_extract_stream_pipelined(mofreak_ctx *ctx, const uint8_t *frames, in
 int mofreak_extract_clips(mofreak_ctx *ctx, const uint8_t *const *clip_frames, const int32_t *clip_n_frames, int n_clips,
                           int W, int H, int chunk_frames, const mofreak_keypoint *kps, int64_t n_kp, mofreak_row *rows_out,
                           int64_t rows_capacity, int64_t *clip_row_offsets_out, int64_t *n_rows_out, unsigned flags);
+/* The same pipeline with the reference's own keypoint source: BriskFeatureDetector(threshold, octaves) on every pair's
+ * difference image (MoFREAKUtilities.cpp:420-423) instead of a caller's list -- computeMoFREAKFromFile's whole frame loop
+ * (:374-498) for MANY clips in one pass.  Windows are detector batches: detector, descriptors of the window's keypoints, rows
+ * (what mofreak_compute_stream does for one resident stack), the next window's frames copied down meanwhile, the previous
+ * window's rows on their way back.  Rows are those of one mofreak_compute_stream call per clip, clip after clip.  The number
+ * of rows is not known up front: MOFREAK_ERR_CAPACITY with the size in *n_rows_out, as in mofreak_extract_clips.
+ * n_keypoints_out (optional): keypoints detected, erased ones included.  flags: MOFREAK_ROWS_DEVICE as above. */
+int mofreak_compute_clips(mofreak_ctx *ctx, const uint8_t *const *clip_frames, const int32_t *clip_n_frames, int n_clips, int W, int H,
+                          int chunk_frames, int threshold, int octaves, mofreak_row *rows_out, int64_t rows_capacity,
+                          int64_t *clip_row_offsets_out, int64_t *n_rows_out, int64_t *n_keypoints_out, unsigned flags);
 /* Device memory for rows that stay in HBM (MOFREAK_ROWS_DEVICE; the RCCL gather of include/mofreak_dist.h) for callers that do
  * not link the HIP runtime themselves: hipMalloc / hipFree on the context's device, and a synchronous device-to-host copy. */
 int mofreak_device_alloc(mofreak_ctx *ctx, size_t bytes, void **out);
@@ -302,7 +312,8 @@ int mofreak_stream_push(mofreak_stream *s, const uint8_t *frame, int channels, i
  * 485-488 is O(1) in the length of the video, and so is this: nothing but the ring survives a push).  Inside the call the
  * chunk goes through the three-stream pipeline of mofreak_extract_stream_pipelined in windows of chunk_frames frames
  * (<= gap: a default of about 96 MiB): the next window's copy under this window's kernels, the previous one's rows on
- * their way back.  kps: ONE keypoint list (host) for every frame of the chunk (streams opened with use_detector = 0).
+ * their way back.  kps: ONE keypoint list (host) for every frame of the chunk; a stream opened with use_detector = 1 finds
+ * its keypoints on the device window by window (kps and n_kp are ignored), as mofreak_compute_clips does.
  * rows_out (host; page-locked: DMA in place) receives the chunk's rows -- those of mofreak_extract_stream on the whole
  * stream, piece by piece.  A caller with two chunk buffers refills one while the other is being pushed.  On
  * MOFREAK_ERR_CAPACITY the frames are consumed all the same and *n_rows_out holds the number of rows the chunk has.

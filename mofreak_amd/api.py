@@ -35,7 +35,7 @@ EXPORTS = [
     "mofreak_set_stream", "mofreak_synchronize", "mofreak_reserve", "mofreak_check_status",
     "mofreak_set_profiling", "mofreak_get_profile", "mofreak_set_path", "mofreak_get_tile_stamps", "mofreak_bgr_to_gray", "mofreak_bow_assign", "mofreak_bow_histogram",
     "mofreak_extract_pairs", "mofreak_compact_rows", "mofreak_extract_stream", "mofreak_format_rows", "mofreak_format_rows_device",
-    "mofreak_extract_stream_pipelined", "mofreak_extract_clips", "mofreak_host_alloc", "mofreak_host_free",
+    "mofreak_extract_stream_pipelined", "mofreak_extract_clips", "mofreak_compute_clips", "mofreak_host_alloc", "mofreak_host_free",
     "mofreak_device_alloc", "mofreak_device_free", "mofreak_copy_to_host",
     "mofreak_parse_rows", "mofreak_diff_integral", "mofreak_mip19", "mofreak_roi19", "mofreak_freak_info",
     "mofreak_theta_index", "mofreak_pattern_sizes", "mofreak_scale_index", "mofreak_table_pattern",
@@ -122,6 +122,7 @@ def load() -> C.CDLL:
     L.mofreak_extract_stream.argtypes = [vp, vp, i32, i32, i32, vp, vp, i64, vp, i64, C.POINTER(i64), C.c_uint]
     L.mofreak_extract_stream_pipelined.argtypes = [vp, vp, i32, i32, i32, i32, vp, i64, vp, i64, C.POINTER(i64)]
     L.mofreak_extract_clips.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, i64, vp, i64, vp, C.POINTER(i64), C.c_uint]
+    L.mofreak_compute_clips.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp, C.POINTER(i64), C.POINTER(i64), C.c_uint]
     L.mofreak_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.mofreak_host_free.argtypes = [vp, vp]
     L.mofreak_format_rows.argtypes = [vp, i64, vp, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -553,6 +554,43 @@ class Context:
             return total.value, offs
         return (rows[:total.value] if rows_out is not None else rows[:total.value].copy()), offs
 
+    def compute_clips(self, clips, threshold: int = 30, octaves: int = 3, chunk_frames: int = 0, rows_out=None, rows_per_pair: int = 8192):
+        """Many gray stacks in one pipelined pass with the reference's own keypoint source, the BRISK detector on every pair's
+        difference image: mofreak_compute_clips (the rows of one compute_stream_host call per clip, clip after clip).
+        rows_out as in extract_clips; the number of rows is not known up front: a buffer that turns out too small (numpy: a
+        new one is made; a caller's buffer: MoFREAKError ERR_CAPACITY) -- rows_per_pair sizes the first attempt.
+        Returns (rows or row count, clip_row_offsets, keypoints detected)."""
+        n = len(clips)
+        gap = self.params.gap_for_frame_difference
+        H, W = (clips[0].shape[1], clips[0].shape[2]) if n else (1, 1)
+        ptrs = (C.c_void_p * max(n, 1))()
+        counts = np.zeros(max(n, 1), np.int32)
+        for i, c in enumerate(clips):
+            assert c.dtype == np.uint8 and c.ndim == 3 and c.flags.c_contiguous and c.shape[1:] == (H, W), "clip: (T, H, W) uint8, C-contiguous"
+            ptrs[i] = c.ctypes.data
+            counts[i] = c.shape[0]
+        n_pairs = int(sum(max(int(t) - gap, 0) for t in counts[:n]))
+        on_device = rows_out is not None and not isinstance(rows_out, np.ndarray)
+        offs = np.zeros(n + 1, np.int64)
+        total, n_kp = C.c_int64(0), C.c_int64(0)
+        rows = None
+        for attempt in range(2):
+            if on_device:
+                assert rows_out.is_cuda and rows_out.is_contiguous() and rows_out.element_size() == 1
+                rows_ptr, rows_cap = C.c_void_p(rows_out.data_ptr()), rows_out.numel() // 32
+            else:
+                rows = rows_out if rows_out is not None else np.zeros(max(total.value, n_pairs * rows_per_pair, 1), ROW_DTYPE)
+                assert rows.dtype == ROW_DTYPE and rows.flags.c_contiguous
+                rows_ptr, rows_cap = _ptr(rows), rows.shape[0]
+            rc = self._lib.mofreak_compute_clips(self._h, C.cast(ptrs, C.c_void_p), _ptr(counts), n, W, H, chunk_frames, threshold, octaves, rows_ptr, rows_cap,
+                                                 _ptr(offs), C.byref(total), C.byref(n_kp), ROWS_DEVICE if on_device else 0)
+            if rc != ERR_CAPACITY or rows_out is not None:
+                break
+        self._check(rc)
+        if on_device:
+            return total.value, offs, n_kp.value
+        return (rows[:total.value] if rows_out is not None else rows[:total.value].copy()), offs, n_kp.value
+
     def extract_stream_pipelined_host(self, frames: np.ndarray, kps: np.ndarray, chunk_frames: int = 256,
                                       rows_out: np.ndarray | None = None) -> np.ndarray:
         """A long host-resident gray stack (T,H,W) u8 through the chunked, copy/compute-overlapped frame loop; the
@@ -704,17 +742,21 @@ class FrameStream:
                                                             0 if k is None else len(k), _ptr(rows), capacity, C.byref(n), MEM_HOST))
         return rows[:n.value].copy()
 
-    def push_frames(self, frames: np.ndarray, kps: np.ndarray, chunk_frames: int = 0, rows_out: np.ndarray | None = None) -> np.ndarray:
+    def push_frames(self, frames: np.ndarray, kps: np.ndarray | None = None, chunk_frames: int = 0, rows_out: np.ndarray | None = None,
+                    rows_per_pair: int = 8192) -> np.ndarray:
         """A chunk of (n, H, W) gray frames at once (mofreak_stream_push_frames): the rows of the pairs it completes.  frames
-        and rows_out from Context.host_alloc() move by DMA in place; rows_out None: a new array sized for the chunk."""
+        and rows_out from Context.host_alloc() move by DMA in place; rows_out None: a new array sized for the chunk.
+        A stream opened with use_detector=True takes no keypoints (kps None): they are found on the device window by window;
+        the number of rows is then not known up front -- rows_per_pair sizes the array made here, and a chunk whose rows do not
+        fit raises ERR_CAPACITY (its frames are consumed all the same: size rows_out generously)."""
         assert frames.dtype == np.uint8 and frames.ndim == 3 and frames.flags.c_contiguous and frames.shape[1:] == (self.H, self.W)
         if not self._h:
             raise MoFREAKError(ERR_BAD_ARG, "stream is closed")
-        k = np.ascontiguousarray(kps, np.float32).reshape(-1, 3)
-        rows = rows_out if rows_out is not None else np.zeros(max(frames.shape[0] * len(k), 1), ROW_DTYPE)
+        k = np.zeros((0, 3), np.float32) if kps is None else np.ascontiguousarray(kps, np.float32).reshape(-1, 3)
+        rows = rows_out if rows_out is not None else np.zeros(max(frames.shape[0] * (rows_per_pair if kps is None else len(k)), 1), ROW_DTYPE)
         assert rows.dtype == ROW_DTYPE and rows.flags.c_contiguous
         n = C.c_int64(0)
-        self._ctx._check(self._ctx._lib.mofreak_stream_push_frames(self._h, _ptr(frames), frames.shape[0], chunk_frames, _ptr(k), len(k), _ptr(rows),
+        self._ctx._check(self._ctx._lib.mofreak_stream_push_frames(self._h, _ptr(frames), frames.shape[0], chunk_frames, _ptr(k) if len(k) else None, len(k), _ptr(rows),
                                                                    rows.shape[0], C.byref(n)))
         return rows[:n.value] if rows_out is not None else rows[:n.value].copy()
 

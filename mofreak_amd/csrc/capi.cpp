@@ -1183,6 +1183,15 @@ int pipe_host_pair(mofreak_ctx *ctx, void *(&slot)[2], size_t &have, size_t want
 // A clip may come in several pieces (joined[c] != 0: piece c continues the clip of piece c - 1 -- a stream's frames still on
 // the device in front of the chunk that was just pushed) and may start at a frame number of its own (label_base[c], read
 // at a clip's first piece: the frames of the stream before it); a piece may be device memory (copied device to device).
+// The reference's own keypoint source in the pipelined routes: BriskFeatureDetector(threshold, octaves) on every window's
+// difference images (MoFREAKUtilities.cpp:420-423) instead of a caller's keypoint list.
+struct ClipDetector {
+    int threshold = 30, octaves = 3;
+    int64_t n_keypoints = 0;  // out: keypoints detected over the whole call
+};
+int det_geometry(const mofreak_ctx *ctx, int W, int H, int octaves, DetGeom &g);
+int det_batch(const mofreak_ctx *ctx, const DetGeom &g, int n_pairs);
+
 struct ClipPieces {
     const uint8_t *joined = nullptr;
     const int64_t *label_base = nullptr;
@@ -1193,7 +1202,7 @@ struct ClipPieces {
 int extract_clips_impl(mofreak_ctx *ctx, const uint8_t *const *clip_frames, const int32_t *clip_n_frames, int n_clips, int W,
                        int H, int chunk_frames, const mofreak_keypoint *kps, int64_t n_kp, mofreak_row *rows_out,
                        int64_t rows_capacity, int64_t *clip_row_offsets_out, int64_t *n_rows_out, bool rows_on_device,
-                       ClipPieces *pieces = nullptr)
+                       ClipPieces *pieces = nullptr, ClipDetector *det = nullptr)
 {
     const int gap = ctx->params.gap_for_frame_difference;
     const int64_t fsz = (int64_t)W * H;
@@ -1206,12 +1215,19 @@ int extract_clips_impl(mofreak_ctx *ctx, const uint8_t *const *clip_frames, cons
     }
     const int64_t T = start[n_clips];
     if (clip_row_offsets_out) std::fill(clip_row_offsets_out, clip_row_offsets_out + n_clips + 1, (int64_t)0);
-    if (T - gap <= 0 || n_kp == 0) return MOFREAK_OK;
+    if (T - gap <= 0 || (!det && n_kp == 0)) return MOFREAK_OK;
     if (T - gap >= ((int64_t)1 << 31)) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "more than 2^31 frames in one call");
     const int64_t n_pairs_all = T - gap;
     if (chunk_frames <= gap)  // default: windows of about 96 MiB of frames
         chunk_frames = (int)std::min<int64_t>(4096, std::max<int64_t>(gap + 16, ((int64_t)96 << 20) / fsz));
     chunk_frames = (int)std::min<int64_t>(chunk_frames, T);
+    if (det) {  // a window is one detector batch: as many pairs as its workspace takes at once
+        DetGeom dg;
+        const int e = det_geometry(ctx, W, H, det->octaves, dg);
+        if (e) return e;
+        chunk_frames = std::min(chunk_frames, det_batch(ctx, dg, chunk_frames - gap) + gap);
+        n_kp = 4096;  // per pair, to size the first buffers (they grow with what the detector finds)
+    }
     const int chunk_pairs = chunk_frames - gap;
     const int n_chunks = (int)((n_pairs_all + chunk_pairs - 1) / chunk_pairs);
     const Geometry g{W, H, W, fsz};
@@ -1251,7 +1267,7 @@ int extract_clips_impl(mofreak_ctx *ctx, const uint8_t *const *clip_frames, cons
     if (!all_pinned && (rc = pipe_host_pair(ctx, P.h_frames, P.h_frames_bytes, chunk_bytes))) return rc;
     if (!rows_pinned && (rc = pipe_host_pair(ctx, P.h_rows, P.h_rows_bytes, rows_bytes))) return rc;
     if ((rc = pipe_host_pair(ctx, P.h_pair_rows, P.h_pair_rows_bytes, (size_t)chunk_pairs * sizeof(int32_t)))) return rc;
-    if ((rc = upload(ctx, ctx->stage[2], kps, (size_t)n_kp * sizeof(mofreak_keypoint)))) return rc;
+    if (!det && (rc = upload(ctx, ctx->stage[2], kps, (size_t)n_kp * sizeof(mofreak_keypoint)))) return rc;
     if ((rc = upload(ctx, ctx->pair_label, label.data(), label.size() * sizeof(int32_t)))) return rc;
     const mofreak_keypoint *d_kps = static_cast<const mofreak_keypoint *>(ctx->stage[2].ptr);
     const int32_t *d_label = static_cast<const int32_t *>(ctx->pair_label.ptr);
@@ -1262,6 +1278,7 @@ int extract_clips_impl(mofreak_ctx *ctx, const uint8_t *const *clip_frames, cons
     uint8_t *desc = static_cast<uint8_t *>(ctx->scratch_desc.ptr);
     uint8_t *valid = static_cast<uint8_t *>(ctx->scratch_valid.ptr);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the uploads above (they read `label` and the caller's kps)
+    if (det) det->n_keypoints = 0;
 
     std::vector<int32_t> rows_of_pair(clip_row_offsets_out ? (size_t)n_pairs_all : 0);
     int64_t total_rows = 0;           // rows produced so far (keeps counting past rows_capacity: the caller learns the size)
@@ -1298,12 +1315,12 @@ int extract_clips_impl(mofreak_ctx *ctx, const uint8_t *const *clip_frames, cons
         return MOFREAK_OK;
     };
 
-    int clip_lo = 0;  // first clip that reaches into the current window
-    for (int k = 0; k < n_chunks; ++k) {
+    int clip_lo = 0;  // first clip that reaches into the window whose copies are issued next
+    // the copies of window k's frames into slot k & 1, on the copy stream (the slot's previous user, window k - 2, is through)
+    auto issue_copies = [&](int k) -> int {
         const int b = k & 1;
         const int64_t f0 = (int64_t)k * chunk_pairs;
-        const int nf = (int)std::min<int64_t>(chunk_frames, T - f0), np = nf - gap;
-        if ((rc = advance(b, true))) return rc;  // slot b: window k-2 is through (its buffers are free again)
+        const int nf = (int)std::min<int64_t>(chunk_frames, T - f0);
         bool staged_wait = false;
         HIP_TRY(ctx, hipStreamWaitEvent(P.s_in, P.ev_comp[b], 0));  // the device frames of window k-2 are no longer read
         while (clip_lo < n_clips && start[clip_lo + 1] <= f0) ++clip_lo;
@@ -1324,18 +1341,86 @@ int extract_clips_impl(mofreak_ctx *ctx, const uint8_t *const *clip_frames, cons
             HIP_TRY(ctx, hipMemcpyAsync(dst, src, (size_t)(hi - lo) * fsz, hipMemcpyDefault, P.s_in));  // (host or device piece)
         }
         HIP_TRY(ctx, hipEventRecord(P.ev_in[b], P.s_in));
+        return MOFREAK_OK;
+    };
+    // With the detector a window's compute hands counts to the host (it blocks): the NEXT window's copies are issued before it,
+    // so that they still run under this window's kernels.
+    if (det && (rc = issue_copies(0))) return rc;
+    for (int k = 0; k < n_chunks; ++k) {
+        const int b = k & 1;
+        const int64_t f0 = (int64_t)k * chunk_pairs;
+        const int nf = (int)std::min<int64_t>(chunk_frames, T - f0), np = nf - gap;
+        if (!det) {
+            if ((rc = advance(b, true))) return rc;  // slot b: window k-2 is through (its buffers are free again)
+            if ((rc = issue_copies(k))) return rc;
+        } else if (k + 1 < n_chunks) {
+            if ((rc = advance(b ^ 1, true))) return rc;  // slot of window k+1: window k-1 is through
+            if ((rc = issue_copies(k + 1))) return rc;
+        }
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, P.ev_in[b], 0));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, P.ev_out[b], 0));  // the device rows of window k-2 have left
         const uint8_t *d_fr = static_cast<const uint8_t *>(P.d_frames[b].ptr);
-        rc = extract_device(ctx, d_fr + (int64_t)gap * fsz, d_fr, g, np, d_kps, nullptr, nullptr, n_kp, desc, valid, nullptr, nullptr);
-        if (rc) return rc;
+        const mofreak_keypoint *w_kps = d_kps;   // the window's keypoints: the caller's list, or what the detector finds
+        const int64_t *w_off = nullptr;
+        int64_t w_nkp = n_kp, n_items = (int64_t)np * n_kp;
+        if (det) {
+            if ((rc = advance(b, true))) return rc;  // (the first two windows: nothing to finish)
+            int64_t found = 0;
+            for (int attempt = 0;; ++attempt) {
+                const int64_t cap = std::max<int64_t>(ctx->det_kp_capacity, (int64_t)4096 * np);
+                if ((rc = ensure(ctx, ctx->det_out_kps, (size_t)cap * sizeof(mofreak_keypoint)))) return rc;
+                if ((rc = ensure(ctx, ctx->det_out_offsets, (size_t)(np + 1) * sizeof(int64_t)))) return rc;
+                rc = mofreak_detect_pairs(ctx, d_fr + (int64_t)gap * fsz, d_fr, W, H, W, fsz, np, det->threshold, det->octaves,
+                                          static_cast<mofreak_keypoint *>(ctx->det_out_kps.ptr), cap, static_cast<int64_t *>(ctx->det_out_offsets.ptr), nullptr, nullptr, &found,
+                                          MOFREAK_MEM_DEVICE);
+                if (rc == MOFREAK_ERR_CAPACITY && found > cap && attempt == 0) {
+                    ctx->det_kp_capacity = found + found / 8;
+                    continue;
+                }
+                if (rc) return rc;
+                break;
+            }
+            det->n_keypoints += found;
+            w_kps = static_cast<const mofreak_keypoint *>(ctx->det_out_kps.ptr);
+            w_off = static_cast<const int64_t *>(ctx->det_out_offsets.ptr);
+            w_nkp = n_items = found;
+            if (!rows_pinned && (size_t)found * sizeof(mofreak_row) > P.h_rows_bytes) {
+                // more rows than the host staging buffers take (both slots are idle here: this window has not produced yet,
+                // the other one is waiting for its frames)
+                if ((rc = advance(b ^ 1, true))) return rc;
+                if ((rc = pipe_host_pair(ctx, P.h_rows, P.h_rows_bytes, (size_t)(found + found / 4) * sizeof(mofreak_row)))) return rc;
+            }
+            if ((rc = ensure(ctx, P.d_rows[b], (size_t)std::max<int64_t>(found, 1) * sizeof(mofreak_row)))) return rc;
+            if ((rc = ensure(ctx, ctx->scratch_desc, (size_t)std::max<int64_t>(found, 1) * 16))) return rc;
+            if ((rc = ensure(ctx, ctx->scratch_valid, (size_t)std::max<int64_t>(found, 1)))) return rc;
+            if ((rc = ensure(ctx, ctx->compact_offsets, ((size_t)(found + kCompactItemsPerBlock - 1) / kCompactItemsPerBlock + 1) * sizeof(int64_t)))) return rc;
+            desc = static_cast<uint8_t *>(ctx->scratch_desc.ptr);
+            valid = static_cast<uint8_t *>(ctx->scratch_valid.ptr);
+            if (found > 0) {
+                std::vector<int64_t> h_off;
+                if ((rc = fetch_offsets(ctx, w_off, np, false, h_off))) return rc;
+                struct DiffScope {  // the detector's difference planes serve this window's integral images, and nobody else's
+                    mofreak_ctx *c;
+                    ~DiffScope()
+                    {
+                        c->use_det_diff = false;
+                        c->det_diff = mofreak_ctx::DetDiff{};
+                    }
+                } scope{ctx};
+                ctx->use_det_diff = true;
+                rc = extract_device(ctx, d_fr + (int64_t)gap * fsz, d_fr, g, np, w_kps, w_off, h_off.data(), found, desc, valid, nullptr, nullptr);
+                if (rc) return rc;
+            }
+        } else {
+            rc = extract_device(ctx, d_fr + (int64_t)gap * fsz, d_fr, g, np, d_kps, nullptr, nullptr, n_kp, desc, valid, nullptr, nullptr);
+            if (rc) return rc;
+        }
         {
-            const int64_t n_items = (int64_t)np * n_kp;
             const int n_blocks = (int)((n_items + kCompactItemsPerBlock - 1) / kCompactItemsPerBlock);
             CompactArgs c;
-            c.kps = d_kps;
-            c.kp_offsets = nullptr;
-            c.n_kp = n_kp;
+            c.kps = w_kps;
+            c.kp_offsets = w_off;
+            c.n_kp = w_nkp;
             c.n_items = n_items;
             c.n_pairs = np;
             c.first_frame_number = 0;
@@ -1395,6 +1480,28 @@ int mofreak_extract_clips(mofreak_ctx *ctx, const uint8_t *const *clip_frames, c
     NEED_DEVICE(ctx);
     return extract_clips_impl(ctx, clip_frames, clip_n_frames, n_clips, W, H, chunk_frames, kps, n_kp, rows_out, rows_capacity,
                               clip_row_offsets_out, n_rows_out, (flags & MOFREAK_ROWS_DEVICE) != 0);
+}
+
+int mofreak_compute_clips(mofreak_ctx *ctx, const uint8_t *const *clip_frames, const int32_t *clip_n_frames, int n_clips, int W, int H, int chunk_frames,
+                          int threshold, int octaves, mofreak_row *rows_out, int64_t rows_capacity, int64_t *clip_row_offsets_out, int64_t *n_rows_out,
+                          int64_t *n_keypoints_out, unsigned flags)
+{
+    if (!ctx) return MOFREAK_ERR_BAD_ARG;
+    if (n_rows_out) *n_rows_out = 0;
+    if (n_keypoints_out) *n_keypoints_out = 0;
+    if (n_clips < 0 || rows_capacity < 0 || W <= 0 || H <= 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "negative count or empty frame");
+    if (threshold < 1 || threshold > 255) return fail(ctx, MOFREAK_ERR_BAD_ARG, "threshold must be in 1..255");
+    if (n_clips == 0) return MOFREAK_OK;
+    if (!clip_frames || !clip_n_frames) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null clip table");
+    if (rows_capacity > 0 && !rows_out) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null rows_out");
+    NEED_DEVICE(ctx);
+    ClipDetector det;
+    det.threshold = threshold;
+    det.octaves = octaves;
+    const int rc = extract_clips_impl(ctx, clip_frames, clip_n_frames, n_clips, W, H, chunk_frames, nullptr, 0, rows_out, rows_capacity, clip_row_offsets_out, n_rows_out,
+                                      (flags & MOFREAK_ROWS_DEVICE) != 0, nullptr, &det);
+    if (n_keypoints_out) *n_keypoints_out = det.n_keypoints;
+    return rc;
 }
 
 int mofreak_extract_stream_pipelined(mofreak_ctx *ctx, const uint8_t *frames, int T, int W, int H, int chunk_frames,
@@ -2236,8 +2343,7 @@ int mofreak_stream_push_frames(mofreak_stream *s, const uint8_t *frames, int n_f
     if (n_frames < 0 || n_kp < 0 || rows_capacity < 0) return fail(ctx, MOFREAK_ERR_BAD_ARG, "negative count");
     if (n_frames == 0) return MOFREAK_OK;
     if (!frames) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null frames");
-    if (s->use_detector) return fail(ctx, MOFREAK_ERR_UNSUPPORTED, "mofreak_stream_push_frames takes a shared keypoint list; a detector stream is pushed frame by frame or handed to mofreak_compute_stream");
-    if (n_kp > 0 && !kps) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null keypoint pointer");
+    if (!s->use_detector && n_kp > 0 && !kps) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null keypoint pointer");
     if (rows_capacity > 0 && !rows_out) return fail(ctx, MOFREAK_ERR_BAD_ARG, "null rows_out");
     NEED_DEVICE(ctx);
     const int W = s->W, H = s->H, gap = ctx->params.gap_for_frame_difference, slots = gap + 1;
@@ -2247,7 +2353,10 @@ int mofreak_stream_push_frames(mofreak_stream *s, const uint8_t *frames, int n_f
     const int64_t first_new = s->n_seen;
     int rc = MOFREAK_OK;
     ClipPieces pc;
-    if ((int64_t)tail + n_frames > gap && n_kp > 0) {
+    ClipDetector det;  // a detector stream: the keypoints of every pair are found on the device, window by window (kps is ignored)
+    det.threshold = s->threshold;
+    det.octaves = s->octaves;
+    if ((int64_t)tail + n_frames > gap && (n_kp > 0 || s->use_detector)) {
         // one clip in tail + 1 pieces: the ring's frames (one slot each, oldest first), then the caller's chunk
         std::vector<const uint8_t *> ptr;
         std::vector<int32_t> len;
@@ -2264,7 +2373,8 @@ int mofreak_stream_push_frames(mofreak_stream *s, const uint8_t *frames, int n_f
         base.assign(ptr.size(), first_new - tail);  // the clip's first frame is frame number first_new - tail of the stream (:401, :488)
         pc.joined = joined.data();
         pc.label_base = base.data();
-        rc = extract_clips_impl(ctx, ptr.data(), len.data(), (int)ptr.size(), W, H, chunk_frames, kps, n_kp, rows_out, rows_capacity, nullptr, n_rows_out, false, &pc);
+        rc = extract_clips_impl(ctx, ptr.data(), len.data(), (int)ptr.size(), W, H, chunk_frames, kps, n_kp, rows_out, rows_capacity, nullptr, n_rows_out, false, &pc,
+                                s->use_detector ? &det : nullptr);
         if (rc != MOFREAK_OK && rc != MOFREAK_ERR_CAPACITY) return rc;  // (rows that do not fit: the frames are consumed all the same, like mofreak_stream_push)
     }
     // the stream's last gap frames into their ring slots: from the pipeline's last window where they already are on the

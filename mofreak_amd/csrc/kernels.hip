@@ -540,13 +540,26 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int *total)
     return base + incl - v;
 }
 
-// Is item `item` of a shared-list call a row?  With pair labels (many clips in one call) a pair that straddles two clips
-// has a negative label and none of its keypoints is one.
+// Is item `item` a row?  With pair labels (many clips in one call) a pair that straddles two clips has a negative label and
+// none of its keypoints is one.
 __device__ __forceinline__ bool compact_keeps(const CompactArgs &a, int64_t item, int *pair_out)
 {
     if (item >= a.n_items || a.valid[item] == 0) return false;
     if (a.pair_label == nullptr && a.pair_rows == nullptr) return true;
-    const int pair = (int)(item / a.n_kp);  // shared keypoint list: n_kp items per pair
+    int pair;
+    if (a.kp_offsets == nullptr) {
+        pair = (int)(item / a.n_kp);  // shared keypoint list: n_kp items per pair
+    } else {  // per-pair lists (a detector's keypoints): the pair whose segment holds the item
+        int lo = 0, hi = a.n_pairs;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.kp_offsets[mid] <= item)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        pair = lo;
+    }
     *pair_out = pair;
     return a.pair_label == nullptr || a.pair_label[pair] >= 0;
 }

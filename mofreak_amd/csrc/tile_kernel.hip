@@ -729,7 +729,8 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(TileArgs a)
             else
                 run(LL, std::integral_constant<int, kMipMaskA>{});
         };
-        switch (tile_L) {
+        switch (64 * (wave >> 1) < n_tile_kp ? tile_L : 0) {  // (a sparse tile: the second pair of waves has no keypoint)
+        case 0: break;
         case 7: run_half(std::integral_constant<int, 7>{}); break;
         case 8: run_half(std::integral_constant<int, 8>{}); break;
         case 9: run_half(std::integral_constant<int, 9>{}); break;

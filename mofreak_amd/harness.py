@@ -343,8 +343,30 @@ def _extract_batch(mofreak, stacks, use_batched: bool, to_device, workers: int, 
     counts = [0] * len(stacks)
     pieces = []  # (rows of the group, offsets, member indices)
     for (H, W), members in sizes.items():
-        kps = prov(gap, W, H)
         group = [stacks[j] for j in members]
+        if prov == "brisk":
+            # the reference's own keypoint source: the detector runs window by window inside the same pipelined pass
+            # (mofreak_compute_clips); the number of rows is only known afterwards
+            thr, octs = mofreak.BRISK_THRESHOLD, mofreak.BRISK_OCTAVES
+            if to_device is not None:
+                n_pairs = int(sum(max(s.shape[0] - gap, 0) for s in group))
+                per_pair = getattr(mofreak, "_rows_per_pair", 8192)
+                for _ in range(2):
+                    buf = torch.empty(max(n_pairs * per_pair, 1) * 32, dtype=torch.uint8, device=to_device)
+                    try:
+                        n_rows, offs, _ = mofreak._ctx.compute_clips(group, thr, octs, rows_out=buf)
+                        break
+                    except api.MoFREAKError as e:
+                        if e.code != api.ERR_CAPACITY or _ == 1:
+                            raise
+                        per_pair = mofreak._rows_per_pair = per_pair * 4
+            else:
+                buf, offs, _ = mofreak._ctx.compute_clips(group, thr, octs)
+            for k, j in enumerate(members):
+                counts[j] = int(offs[k + 1] - offs[k])
+            pieces.append((buf, offs, members))
+            continue
+        kps = prov(gap, W, H)
         cap = int(sum(max(s.shape[0] - gap, 0) for s in group)) * len(kps)
         if to_device is not None:
             buf = torch.empty(max(cap, 1) * 32, dtype=torch.uint8, device=to_device)
@@ -424,7 +446,7 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
     n_rounds = max((len(p) for p in plans), default=0)
     distributed = world_size > 1 or group_exists()
     prov = getattr(mofreak, "keypoint_provider", None)
-    use_batched = batched and not isinstance(prov, str) and getattr(prov, "shared", False)
+    use_batched = batched and (prov == "brisk" or (not isinstance(prov, str) and getattr(prov, "shared", False)))
     cuda = torch.cuda.is_available()
     by_ranks = write == "ranks" and out_dir is not None
     if write not in ("root", "ranks"):
@@ -447,7 +469,7 @@ def run_dataset(videos: Sequence, names: Sequence[str], out_dir: str | None, mof
     # Rows that are kept are written where they stay: one page-locked buffer for the whole run (its size is known up front
     # for a shared keypoint list: pairs x keypoints), filled round after round -- no copy per video.
     keep_buf, keep_at = None, 0
-    if rank == 0 and keep_rows and use_batched:
+    if rank == 0 and keep_rows and use_batched and prov != "brisk":
         gap = mofreak._ctx.params.gap_for_frame_difference
         keep_buf = _pinned_rows(mofreak, int(sum(max(sh[0] - gap, 0) * len(prov(gap, sh[2], sh[1])) for sh in shapes)))
     for r in range(n_rounds):

@@ -189,7 +189,7 @@ void MoFREAKUtilities::computeMoFREAKFromFile(std::string video_filename, std::s
 void MoFREAKUtilities::computeMoFREAKFromFiles(const std::vector<std::string> &video_filenames, const std::vector<std::string> &mofreak_filenames)
 {
     if (video_filenames.size() != mofreak_filenames.size()) throw std::runtime_error("computeMoFREAKFromFiles: one output name per video");
-    if (use_brisk_ || !provider_shared_) {  // per-frame keypoints: the plain loop
+    if (!use_brisk_ && !provider_shared_) {  // per-frame keypoints from a caller's provider: the plain loop
         for (size_t i = 0; i < video_filenames.size(); ++i) computeMoFREAKFromFile(video_filenames[i], mofreak_filenames[i], true);
         return;
     }
@@ -210,20 +210,33 @@ void MoFREAKUtilities::computeMoFREAKFromFiles(const std::vector<std::string> &v
         if (batch.empty()) return;
         std::vector<const uint8_t *> ptr(batch.size());
         std::vector<int32_t> len(batch.size());
-        const std::vector<mofreak_keypoint> kps = provider_(gap, bW, bH);
+        const std::vector<mofreak_keypoint> kps = use_brisk_ ? std::vector<mofreak_keypoint>() : provider_(gap, bW, bH);
         int64_t capacity = 0;
         for (size_t k = 0; k < batch.size(); ++k) {
             ptr[k] = batch[k].frames.data();
             len[k] = batch[k].T;
-            capacity += (int64_t)std::max(len[k] - gap, 0) * (int64_t)kps.size();
+            // (the detector's rows are counted afterwards: room for 8192 a pair to begin with, the call says what it needs)
+            capacity += (int64_t)std::max(len[k] - gap, 0) * (use_brisk_ ? (int64_t)8192 : (int64_t)kps.size());
         }
         std::vector<mofreak_row> rows((size_t)std::max<int64_t>(capacity, 1));
         std::vector<int64_t> offs(batch.size() + 1, 0);
         int64_t n_rows = 0;
-        check(ctx,
-              mofreak_extract_clips(ctx, ptr.data(), len.data(), (int)batch.size(), bW, bH, /*chunk_frames*/ 0, kps.data(), (int64_t)kps.size(),
-                                    rows.data(), capacity, offs.data(), &n_rows, 0),
-              "mofreak_extract_clips");
+        if (use_brisk_) {  // the reference's keypoint source (:420-423), window by window inside the same pipelined pass
+            int rc = mofreak_compute_clips(ctx, ptr.data(), len.data(), (int)batch.size(), bW, bH, 0, brisk_threshold_, brisk_octaves_, rows.data(), capacity, offs.data(),
+                                           &n_rows, nullptr, 0);
+            if (rc == MOFREAK_ERR_CAPACITY && n_rows > capacity) {
+                capacity = n_rows;
+                rows.resize((size_t)capacity);
+                rc = mofreak_compute_clips(ctx, ptr.data(), len.data(), (int)batch.size(), bW, bH, 0, brisk_threshold_, brisk_octaves_, rows.data(), capacity, offs.data(),
+                                           &n_rows, nullptr, 0);
+            }
+            check(ctx, rc, "mofreak_compute_clips");
+        } else {
+            check(ctx,
+                  mofreak_extract_clips(ctx, ptr.data(), len.data(), (int)batch.size(), bW, bH, /*chunk_frames*/ 0, kps.data(), (int64_t)kps.size(),
+                                        rows.data(), capacity, offs.data(), &n_rows, 0),
+                  "mofreak_extract_clips");
+        }
         for (size_t k = 0; k < batch.size(); ++k) {
             const size_t i = batch[k].index;
             appendRows(rows.data() + offs[k], offs[k + 1] - offs[k], video_filenames[i]);  // behind whatever is there (:374-498 appends)
@@ -256,7 +269,7 @@ void MoFREAKUtilities::computeMoFREAKFromFilesSharded(const std::vector<std::str
 {
     if (video_filenames.size() != mofreak_filenames.size()) throw std::runtime_error("computeMoFREAKFromFilesSharded: one output name per video");
     if (!comm) throw std::runtime_error("computeMoFREAKFromFilesSharded: no communicator");
-    if (use_brisk_ || !provider_shared_) throw std::runtime_error("computeMoFREAKFromFilesSharded: a shared keypoint list (dense grid) is required");
+    if (!use_brisk_ && !provider_shared_) throw std::runtime_error("computeMoFREAKFromFilesSharded: a shared keypoint list (dense grid) or the BRISK detector is required");
     auto dist_check = [](int rc, const char *what) {
         if (rc != MOFREAK_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + mofreak_dist_last_error());
     };
@@ -322,6 +335,7 @@ void MoFREAKUtilities::computeMoFREAKFromFilesSharded(const std::vector<std::str
         };
         std::vector<Clip> clips(mine.size());
         int64_t capacity = 0;
+        bool redo = false;
         for (size_t k = 0; k < mine.size(); ++k) {
             Clip &c = clips[k];
             std::ifstream f;
@@ -338,7 +352,7 @@ void MoFREAKUtilities::computeMoFREAKFromFilesSharded(const std::vector<std::str
                 cout << "Could not open file: " << video_filenames[mine[k]] << endl;  // :383-386
                 continue;
             }
-            capacity += (int64_t)std::max(c.T - gap, 0) * (int64_t)provider_(gap, c.W, c.H).size();
+            capacity += (int64_t)std::max(c.T - gap, 0) * (use_brisk_ ? brisk_rows_per_pair_ : (int64_t)provider_(gap, c.W, c.H).size());
         }
         DeviceRows mine_rows{ctx}, all_rows{ctx};
         check(ctx, mofreak_device_alloc(ctx, (size_t)std::max<int64_t>(capacity, 1) * sizeof(mofreak_row), &mine_rows.p), "mofreak_device_alloc");
@@ -357,16 +371,31 @@ void MoFREAKUtilities::computeMoFREAKFromFilesSharded(const std::vector<std::str
                 ptr.push_back(clips[k].frames);
                 len.push_back(clips[k].T);
             }
-            const std::vector<mofreak_keypoint> kps = provider_(gap, clips[k0].W, clips[k0].H);
             std::vector<int64_t> offs(ptr.size() + 1, 0);
             int64_t got = 0;
-            check(ctx,
-                  mofreak_extract_clips(ctx, ptr.data(), len.data(), (int)ptr.size(), clips[k0].W, clips[k0].H, /*chunk_frames*/ 0, kps.data(), (int64_t)kps.size(),
-                                        static_cast<mofreak_row *>(mine_rows.p) + n_mine, capacity - n_mine, offs.data(), &got, MOFREAK_ROWS_DEVICE),
-                  "mofreak_extract_clips");
+            if (use_brisk_) {
+                int rc = mofreak_compute_clips(ctx, ptr.data(), len.data(), (int)ptr.size(), clips[k0].W, clips[k0].H, 0, brisk_threshold_, brisk_octaves_,
+                                               static_cast<mofreak_row *>(mine_rows.p) + n_mine, capacity - n_mine, offs.data(), &got, nullptr, MOFREAK_ROWS_DEVICE);
+                if (rc == MOFREAK_ERR_CAPACITY) {  // more rows than the estimate: the round is done again with room for them
+                    brisk_rows_per_pair_ *= 4;
+                    redo = true;
+                    break;
+                }
+                check(ctx, rc, "mofreak_compute_clips");
+            } else {
+                const std::vector<mofreak_keypoint> kps = provider_(gap, clips[k0].W, clips[k0].H);
+                check(ctx,
+                      mofreak_extract_clips(ctx, ptr.data(), len.data(), (int)ptr.size(), clips[k0].W, clips[k0].H, /*chunk_frames*/ 0, kps.data(), (int64_t)kps.size(),
+                                            static_cast<mofreak_row *>(mine_rows.p) + n_mine, capacity - n_mine, offs.data(), &got, MOFREAK_ROWS_DEVICE),
+                      "mofreak_extract_clips");
+            }
             for (size_t k = k0; k < k1; ++k) count_of[k] = offs[k - k0 + 1] - offs[k - k0];
             n_mine += got;
             k0 = k1;
+        }
+        if (redo) {  // (every rank walks the same rounds: the rank that repeats one simply arrives later at its exchange)
+            --round;
+            continue;
         }
         clips.clear();
         // the exchange: per-video counts (every video belongs to one rank: the sum is its count), per-rank counts, rows

@@ -105,7 +105,8 @@ public:
     // first (file sizes); the ranks walk their shares in rounds of at most setBatchBytes() of frames: a rank's clips of a
     // round through mofreak_extract_clips with the rows left in HBM, the per-video row counts summed over the ranks, the
     // rows gathered to rank 0 over RCCL (ncclAllGather of the counts, grouped ncclSend / ncclRecv peer -> root), and rank 0
-    // writes the round's files -- the bytes computeMoFREAKFromFiles writes.  Dense-grid keypoints only.
+    // writes the round's files -- the bytes computeMoFREAKFromFiles writes.  Dense-grid keypoints, or the BRISK detector
+    // (useBriskDetector(): mofreak_compute_clips, the detector window by window inside the pipelined pass).
     // setFilesWrittenByTheirRanks(true) (the default; one node = one file system): the files are the output, so every rank
     // writes those of ITS OWN videos -- text made on the device from the rows in HBM (mofreak_format_rows_device, one call per
     // round), file by file through <name>.tmp + fsync + rename -- and only the counts are exchanged: no row crosses a link,
@@ -129,6 +130,7 @@ private:
     bool provider_shared_;
     size_t batch_bytes_ = (size_t)2 << 30;
     bool files_by_ranks_ = true;
+    int64_t brisk_rows_per_pair_ = 8192;  // first estimate of a detector stream's rows per frame pair (grown when a call needs more)
     bool use_brisk_;
     int brisk_threshold_, brisk_octaves_;
 };

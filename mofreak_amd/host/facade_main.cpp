@@ -103,6 +103,9 @@ static int run_rank(int rank, int world, const std::string &id_file, const std::
         mofreak.setDenseGrid(16, 7.0f, 23);
         if (const char *b = std::getenv("MOFREAK_BATCH_BYTES")) mofreak.setBatchBytes((size_t)std::atoll(b));
         if (const char *g = std::getenv("MOFREAK_GATHER_TO_ROOT")) mofreak.setFilesWrittenByTheirRanks(std::atoi(g) == 0);  // 1: rows to rank 0 over RCCL, rank 0 writes
+        if (const char *k = std::getenv("MOFREAK_USE_BRISK")) {
+            if (std::atoi(k)) mofreak.useBriskDetector();  // the reference's own keypoint source instead of the dense grid
+        }
         std::vector<std::string> videos, outputs;
         walk_dataset(mofreak, video_path, mofreak_path, rank == 0, videos, outputs);
         mofreak.computeMoFREAKFromFilesSharded(videos, outputs, comm);
@@ -133,6 +136,9 @@ int main(int argc, char **argv)
             MoFREAKUtilities mofreak(MoFREAKUtilities::UCF101);
             mofreak.setDenseGrid(16, 7.0f, 23);
             if (const char *bb = std::getenv("MOFREAK_BATCH_BYTES")) mofreak.setBatchBytes((size_t)std::atoll(bb));
+            if (const char *k = std::getenv("MOFREAK_USE_BRISK")) {
+                if (std::atoi(k)) mofreak.useBriskDetector();
+            }
             // The walk is the reference's; the videos it finds are handed over together (pipelined calls per batch and
             // frame size instead of one synchronous call per video), which writes the same files.
             std::vector<std::string> videos, outputs;

@@ -433,3 +433,54 @@ print("maps stay clean")
     env = dict(os.environ, MOFREAK_HIP_LIBRARY=build.DEBUG_LIB_PATH)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "maps stay clean" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_detector_in_the_pipelined_routes(ctx, oracle, tmp_path):
+    """The reference's own keypoint source where the fast routes are: mofreak_compute_clips (many clips, one pipelined pass, the
+    detector window by window), chunk pushes into a detector stream, and run_dataset's batched mode with the "brisk" provider --
+    all the rows of one mofreak_compute_stream call per clip (themselves checked against the oracle elsewhere in this file)."""
+    import torch
+    from mofreak_amd import harness
+    clips = [synth.moving_objects_stack(T, 256, 192, seed=60 + i) for i, T in enumerate((9, 23, 4, 14, 6, 31))]
+    want = [ctx.compute_stream_host(c) for c in clips]
+    assert sum(len(w) for w in want) > 400 and len(want[2]) == 0
+    # one pass, small windows (a clip spans several, windows span several clips)
+    for chunk in (0, 9, 13):
+        rows, offs, n_kp = ctx.compute_clips(clips, chunk_frames=chunk)
+        assert n_kp >= len(rows) > 0
+        for i, w in enumerate(want):
+            assert rows[offs[i]:offs[i + 1]].tobytes() == w.tobytes(), (chunk, i)
+    # rows left on the device, too small a buffer reported with the size a retry needs
+    buf = torch.empty(sum(len(w) for w in want) * 32, dtype=torch.uint8, device="cuda")
+    n, offs, _ = ctx.compute_clips(clips, rows_out=buf, chunk_frames=11)
+    assert n == sum(len(w) for w in want) and buf.cpu().numpy().view(M.ROW_DTYPE).tobytes() == np.concatenate(want).tobytes()
+    with pytest.raises(M.MoFREAKError) as e:
+        ctx.compute_clips(clips, rows_out=np.zeros(10, M.ROW_DTYPE))
+    assert e.value.code == M.api.ERR_CAPACITY
+    # the oracle on one of them, end to end
+    f = oracle.Freak()
+    lists = [_oracle_keypoints(O.absdiff(clips[3][t], clips[3][t - 5]))[0] for t in range(5, len(clips[3]))]
+    offs3 = np.concatenate([[0], np.cumsum([len(k) for k in lists])]).astype(np.int64)
+    assert want[3].tobytes() == f.extract_stream(clips[3], np.concatenate(lists), offs3).tobytes()
+    # chunk pushes of any length into a detector stream, mixed with single pushes
+    long = np.concatenate([clips[1], clips[5]])
+    whole = ctx.compute_stream_host(long)
+    with ctx.open_stream(256, 192, use_detector=True) as st:
+        parts = [st.push_frames(long[:3]), st.push(long[3]), st.push_frames(long[4:19], chunk_frames=8), st.push_frames(long[19:20]), st.push_frames(long[20:])]
+        assert st.frames == len(long)
+    assert np.concatenate(parts).tobytes() == whole.tobytes()
+    # the dataset walk: batched, rows kept; and every rank writing its files from device-made text
+    names = [f"clip{i}.avi" for i in range(len(clips))]
+    mo = harness.MoFREAKUtilities(harness.HMDB51, device=0, keypoint_provider="brisk")
+    try:
+        res = harness.run_dataset(clips, names, str(tmp_path / "root"), mo, batch_bytes=3 << 20)
+        kept = {i: r.copy() for i, r in res["rows_per_video"].items()}
+        res2 = harness.run_dataset(clips, names, str(tmp_path / "ranks"), mo, batch_bytes=3 << 20, keep_rows=False, write="ranks")
+    finally:
+        mo.close()
+    assert res["batched"] and res["rounds"] > 1 and res2["write"] == "ranks"
+    for i, w in enumerate(want):
+        assert kept[i].tobytes() == w.tobytes(), i
+        text = M.format_rows(w)
+        assert open(tmp_path / "root" / (names[i] + ".mofreak"), "rb").read() == text
+        assert open(tmp_path / "ranks" / (names[i] + ".mofreak"), "rb").read() == text

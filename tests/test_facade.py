@@ -245,3 +245,38 @@ def test_trecvid_shaped_stream_in_chunks(native_lib, oracle):
     assert rows.tobytes() == want.tobytes() and len(rows) == (T - 5) * len(grid) > 50000
     assert list(np.unique(rows["frame_number"])) == list(range(4, T - 1))
     mf.close()
+
+
+def test_cpp_dataset_routes_with_the_brisk_detector(facade, tmp_path):
+    """useBriskDetector() in the batched walk (`facade_main files`) and in the N-GPU route (`facade_ranks 1`, both ways to the
+    files): the detector runs window by window inside mofreak_compute_clips; the files are those of one
+    computeMoFREAKFromFile call per video (`facade_main extract <video> <out> brisk`)."""
+    vdir = tmp_path / "videos"
+    (vdir / "walk").mkdir(parents=True)
+    clips = {"walk/a.npy": synth.moving_objects_stack(12, 256, 192, seed=71), "walk/b.npy": synth.moving_objects_stack(27, 256, 192, seed=72),
+             "walk/c.npy": synth.moving_objects_stack(5, 256, 192, seed=73), "walk/d.npy": synth.moving_objects_stack(9, 208, 144, seed=74)}
+    for name, fr in clips.items():
+        np.save(vdir / name, fr)
+    single = tmp_path / "single"
+    (single / "walk").mkdir(parents=True)
+    for name in clips:
+        subprocess.check_call([facade, "extract", str(vdir / name), str(single / (name + ".mofreak")), "brisk"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, MOFREAK_USE_BRISK="1", MOFREAK_BATCH_BYTES=str(900_000), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = []
+    batched = tmp_path / "batched"
+    batched.mkdir()
+    subprocess.check_call([facade, "files", str(vdir), str(batched)], env=env, stdout=subprocess.DEVNULL)
+    outs.append(batched)
+    launcher = os.path.join(os.path.dirname(facade), "facade_ranks")
+    for gather in ("0", "1"):
+        out = tmp_path / f"ranks{gather}"
+        msg = subprocess.run([launcher, "1", str(vdir), str(out)], env=dict(env, MOFREAK_GATHER_TO_ROOT=gather), text=True, capture_output=True, timeout=300)
+        assert msg.returncode == 0, msg.stdout[-2000:] + msg.stderr[-2000:]
+        outs.append(out)
+    sizes = 0
+    for name in clips:
+        want = (single / (name + ".mofreak")).read_bytes()
+        sizes += len(want)
+        for out in outs:
+            assert (out / (name + ".mofreak")).read_bytes() == want, (str(out), name)
+    assert sizes > 10000 and (single / "walk/c.npy.mofreak").read_bytes() == b""
