@@ -512,9 +512,13 @@ def bench_dataset(args):
     W, H = cfg["W"], cfg["H"]
     n_clips = args.clips
     lengths = synth.clip_lengths(n_clips)  # the same seeded lengths on every rank
+    brisk = args.keypoints == "brisk"  # the reference's own keypoint source: the detector inside the pipelined pass (mofreak_compute_clips)
     mo = harness.MoFREAKUtilities(harness.HMDB51, device=local_rank,
-                                  keypoint_provider=harness.dense_grid_provider(cfg["step"], cfg["size"], cfg["lo"]))
-    pool = synth.clip_pool(8, int(lengths.max()), W, H)
+                                  keypoint_provider="brisk" if brisk else harness.dense_grid_provider(cfg["step"], cfg["size"], cfg["lo"]))
+    if brisk:  # frames with something to detect: objects moving over a textured background
+        pool = [synth.moving_objects_stack(int(lengths.max()), W, H, seed=900 + k) for k in range(8)]
+    else:
+        pool = synth.clip_pool(8, int(lengths.max()), W, H)
     if not args.pageable:  # the decoder's output buffers: page-locked, so that a clip's frames go down by DMA at link speed
         pinned = [mo._ctx.host_alloc(p.shape) for p in pool]
         for dst, src in zip(pinned, pool):
@@ -551,7 +555,8 @@ def bench_dataset(args):
             sizes = [os.path.getsize(f) for f in files]
             checked = 0
             for i in sorted({0, n_clips // 3, n_clips - 1}):
-                rows = mo._ctx.extract_stream_host(np.ascontiguousarray(clips[i]), harness.dense_grid_provider(cfg["step"], cfg["size"], cfg["lo"])(5, W, H))
+                rows = (mo._ctx.compute_stream_host(np.ascontiguousarray(clips[i])) if brisk else
+                        mo._ctx.extract_stream_host(np.ascontiguousarray(clips[i]), harness.dense_grid_provider(cfg["step"], cfg["size"], cfg["lo"])(5, W, H)))
                 import mofreak_amd as M
                 assert open(files[i], "rb").read() == M.format_rows(rows), f"{files[i]} differs from the host formatter's text"
                 checked += 1
@@ -563,14 +568,18 @@ def bench_dataset(args):
     if rank == 0:
         n_kp = len(synth.config_grid("C4"))
         n_desc = int(((lengths - 5).clip(min=0) * n_kp).sum())
+        if brisk:
+            n_desc = int(res["total_rows"])
+            n_kp = n_desc / max(1, int((lengths - 5).clip(min=0).sum()))
         assert res["total_rows"] == n_desc
         emit(({
             "metric": "MoFREAK clips/sec on an HMDB51-shaped batch, one video per GPU, rows gathered to rank 0 (BASELINE config 4)",
             "value": n_clips * steps / elapsed, "unit": "clips/s", "descriptors_per_s": n_desc * steps / elapsed,
             "n_gpus": world, "steps": steps, "warmup": 1, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic (8 distinct clips cut to the seeded lengths)",
+            "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic (8 distinct clips cut to the seeded lengths" + (", objects moving over a textured background)" if brisk else ")"),
             "config": {"workload": f"C4: {n_clips} clips {W}x{H}, seeded log-normal lengths {int(lengths.min())}..{int(lengths.max())} "
-                                   f"frames (median {int(np.median(lengths))}), dense {cfg['step']}-px grid, {n_kp} keypoints/pair",
+                                   f"frames (median {int(np.median(lengths))}), " + (f"BRISK detector (threshold 30, 3 octaves) on every pair, {n_kp:.0f} rows/pair on average"
+                                                                                     if brisk else f"dense {cfg['step']}-px grid, {n_kp} keypoints/pair"),
                        "descriptors_per_step": n_desc,
                        "parallelism": f"LPT shard of whole clips over {world} rank(s); " + (
                            "every rank's clips in ONE pipelined mofreak_extract_clips call, rows gathered device to device" if res["batched"]
@@ -589,6 +598,59 @@ def bench_dataset(args):
 
 
 # ------------------------------------------------------------------------------------------------ C5: a long stream
+def bench_stream_brisk(args):
+    """C5's shape with the reference's own keypoint source: a 720x576 stream pushed chunk by chunk into a detector stream
+    (mofreak_stream_push_frames: detector, descriptors and rows window by window on the device, the next window's frames copied
+    down meanwhile), bounded memory as in bench_stream."""
+    torch, dist, rank, local_rank, world, on_device = dist_setup(args)
+    import mofreak_amd as M
+    from mofreak_amd import synth
+
+    cfg = synth.CONFIGS["C5"]
+    W, H = cfg["W"], cfg["H"]
+    T = min(args.frames, 20000)
+    distinct = min(T, 128)
+    base = synth.moving_objects_stack(distinct, W, H, seed=333 + rank)
+    ctx = M.Context(local_rank)
+    chunk = min(args.push_frames, 256)
+    bufs = [ctx.host_alloc((chunk, H, W)) for _ in range(2)]
+    rows = [ctx.host_alloc((chunk * 8192,), M.api.ROW_DTYPE) for _ in range(2)]
+
+    def one_pass(n_frames):
+        total = 0
+        with ctx.open_stream(W, H, use_detector=True) as st:
+            for k, t0 in enumerate(range(0, n_frames, chunk)):
+                n = min(chunk, n_frames - t0)
+                b = k & 1
+                for t in range(n):  # (the stream repeats its distinct frames; a forward-backward sweep keeps the motion continuous)
+                    q = (t0 + t) % (2 * distinct - 2)
+                    bufs[b][t] = base[q if q < distinct else 2 * distinct - 2 - q]
+                total += len(st.push_frames(bufs[b][:n], None, chunk_frames=args.chunk if args.chunk < chunk else 0, rows_out=rows[b]))
+        return total
+
+    one_pass(min(T, 2 * chunk))
+    steps = args.steps or 1
+    fence(torch, dist, world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        total = one_pass(T)
+    fence(torch, dist, world)
+    elapsed = max_over_ranks(torch, dist, world, on_device, time.perf_counter() - t0)
+    for b in bufs + rows:
+        ctx.host_free(b)
+    if rank == 0:
+        emit({"metric": "MoFREAK sustained descriptors/sec on a TRECVID-shaped stream with the BRISK detector as the keypoint source, host frames in and rows out included",
+              "value": world * total * steps / elapsed, "unit": "descriptors/s", "n_gpus": world, "steps": steps, "warmup": 1, "ms_per_step": elapsed / steps * 1e3,
+              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": f"synthetic ({distinct} distinct frames of moving objects, swept forward and backward)",
+              "config": {"workload": f"C5 with detector keypoints: one {W}x{H} stream of {T} frames per GPU pushed in chunks of {chunk} frames into a detector stream "
+                                     "(mofreak_stream_push_frames), BRISK threshold 30, 3 octaves", "rows_per_pair": total / max(1, T - 5)},
+              "frame_pairs_per_s": world * (T - 5) * steps / elapsed, "ranks_seen": ranks_seen(dist, world), **dist_info(dist, args)})
+    ctx.close()
+    if grouped(dist):
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def bench_stream(args):
     """BASELINE config 5: an hour-long 720x576 stream (90 000 frames at 25 fps) through mofreak_stream_push_frames in bounded
     memory: two page-locked chunk buffers of --push-frames frames, refilled by host threads (the decoder's stand-in) while the
@@ -767,6 +829,7 @@ def main():
     ap.add_argument("--per-clip-calls", action="store_true", help="C4: one synchronous mofreak_extract_stream call per clip (round 2's path) instead of "
                     "one mofreak_extract_clips call per rank")
     ap.add_argument("--pageable", action="store_true", help="C4: clips in ordinary (pageable) host memory instead of page-locked buffers")
+    ap.add_argument("--keypoints", default="grid", choices=["grid", "brisk"], help="C4 / C5: the configuration's dense grid, or the reference's own source, the BRISK detector on every pair's difference image")
     ap.add_argument("--write", action="store_true", help="C4: write every clip's .mofreak text file inside the timed region (device formatter, each rank its own files)")
     ap.add_argument("--write-threads", type=int, default=0, help="C4 --write: threads per rank that write the files (default: the rank's share of the cores, at most 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -792,7 +855,7 @@ def main():
     elif args.config == "C4":
         bench_dataset(args)
     elif args.config == "C5":
-        bench_stream(args)
+        (bench_stream_brisk if args.keypoints == "brisk" else bench_stream)(args)
     else:
         raise SystemExit(f"unknown --config {args.config}")
 
