@@ -22,6 +22,12 @@ timeout -k 10 250 python bench.py --config C4 --steps 3 > gpurun_out/r5f/final_b
 timeout -k 10 250 python bench.py --config C4 --clips 6766 --steps 1 > gpurun_out/r5f/final_bench_c4_6766.json 2> /dev/null; echo rc=$?
 timeout -k 10 250 python bench.py --config C4 --gpus 2 --backend gloo --share-device > gpurun_out/r5f/final_bench_c4_n2.json 2> /dev/null; echo rc=$?
 timeout -k 10 250 python bench.py --config C4 --gpus 1 --backend nccl --force-dist --steps 3 > gpurun_out/r5f/final_bench_c4_nccl_n1.json 2> /dev/null; echo rc=$?
+timeout -k 10 250 python bench.py --config C4 --steps 3 --write > gpurun_out/r5f/final_bench_c4_write.json 2> /dev/null; echo rc=$?
+timeout -k 10 250 python bench.py --config C4 --clips 6766 --steps 1 --write > gpurun_out/r5f/final_bench_c4_6766_write.json 2> /dev/null; echo rc=$?
+timeout -k 10 250 python bench.py --config C4 --keypoints brisk --steps 1 > gpurun_out/r5f/final_bench_c4_brisk.json 2> /dev/null; echo rc=$?
+timeout -k 10 250 python bench.py --config C4 --keypoints brisk --steps 1 --write > gpurun_out/r5f/final_bench_c4_brisk_write.json 2> /dev/null; echo rc=$?
+timeout -k 10 250 python bench.py --config C5 --keypoints brisk --frames 2053 > gpurun_out/r5f/final_bench_c5_brisk.json 2> /dev/null; echo rc=$?
+timeout -k 10 200 python mofreak_amd/tools/bench_format.py > gpurun_out/r5f/final_format_bench.jsonl 2> /dev/null; echo rc=$?
 timeout -k 10 250 python bench.py --config C5 > gpurun_out/r5f/final_bench_c5.json 2> /dev/null; echo rc=$?
 timeout -k 10 300 python bench.py --config C5 --frames 90000 > gpurun_out/r5f/final_bench_c5_90000.json 2> /dev/null; echo rc=$?
 for set in FETCH_SIZE WRITE_SIZE; do timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/r5f/c2pmc_$set -- python3 bench.py --config C2 --steps 2 --warmup 1 --no-cpu-baseline --no-detector --no-sustain > /dev/null 2>&1; done
@@ -42,6 +48,6 @@ open('gpurun_out/r5f/final_c2_traffic.txt', 'w').write(f"C2 (1000 pairs 640x480,
 print(open('gpurun_out/r5f/final_c2_traffic.txt').read())
 PY
 rm -rf gpurun_out/r5f/c2pmc_*
-timeout -k 10 260 python tests/fuzz_parity_gpu.py 200 121 > gpurun_out/r5f/final_fuzz121.log 2>&1; echo fuzz rc=$?; tail -n 1 gpurun_out/r5f/final_fuzz121.log
-MOFREAK_HIP_LIBRARY=mofreak_amd/libmofreak_hip_debug.so timeout -k 10 260 python tests/fuzz_parity_gpu.py 200 122 > gpurun_out/r5f/final_fuzz122.log 2>&1; echo fuzz debug rc=$?; tail -n 1 gpurun_out/r5f/final_fuzz122.log
+timeout -k 10 260 python tests/fuzz_parity_gpu.py 150 521 > gpurun_out/r5f/final_fuzz521.log 2>&1; echo fuzz rc=$?; tail -n 1 gpurun_out/r5f/final_fuzz521.log
+MOFREAK_HIP_LIBRARY=mofreak_amd/libmofreak_hip_debug.so timeout -k 10 260 python tests/fuzz_parity_gpu.py 150 522 > gpurun_out/r5f/final_fuzz522.log 2>&1; echo fuzz debug rc=$?; tail -n 1 gpurun_out/r5f/final_fuzz522.log
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r5f/final_smoke.log 2>&1; echo smoke rc=$?; tail -n 1 gpurun_out/r5f/final_smoke.log
