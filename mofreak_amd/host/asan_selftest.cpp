@@ -29,6 +29,9 @@ int launch_det_pyramid(const DetArgs &, void *) { STUB; }
 int launch_det_scores(const DetArgs &, void *) { STUB; }
 int launch_det_corners(const DetArgs &, void *) { STUB; }
 int launch_det_keypoints(const DetArgs &, int64_t *, void *) { STUB; }
+size_t format_workspace_bytes(int64_t, int) { return 256; }
+int launch_format_measure(const mofreak_row *, int64_t, void *, const int64_t *, int, int32_t *, uint64_t **, uint64_t **, void *) { STUB; }
+int launch_format_write(const mofreak_row *, int64_t, void *, char *, uint64_t, void *) { STUB; }
 }  // namespace mofreak
 
 #define CHECK(c)                                                       \

@@ -247,6 +247,7 @@ def test_trecvid_shaped_stream_in_chunks(native_lib, oracle):
     mf.close()
 
 
+@pytest.mark.gpu
 def test_cpp_dataset_routes_with_the_brisk_detector(facade, tmp_path):
     """useBriskDetector() in the batched walk (`facade_main files`) and in the N-GPU route (`facade_ranks 1`, both ways to the
     files): the detector runs window by window inside mofreak_compute_clips; the files are those of one
