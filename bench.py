@@ -419,8 +419,8 @@ def bench_resident(args):
         valu = None
         counters_note = None
         lib = library_id(M)
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and args.config == "C3":
+        tpath = os.path.join(ROOT, "profiles", "traffic.json" if args.config == "C3" else f"traffic_{args.config}.json")
+        if os.path.exists(tpath) and (args.config == "C3" or n_pairs == 1000):  # (the counters are per launch of the default number of pairs)
             tj = json.load(open(tpath))
             if tj.get("library_sha256_16") != lib["sha256_16"]:
                 # counters of another build say nothing about this one: the line carries none rather than stale ones
@@ -455,7 +455,7 @@ def bench_resident(args):
                                    f"{n_kp} keypoints/pair of size {cfg['size']}, 16-byte descriptors",
                        "descriptors_per_step_per_gpu": n_desc, "bit_mode": "SSE", "parallelism": f"one stack per GPU x{world}"},
             "timed_region_s": elapsed, "sustained": sustained,
-            "roofline": {"bound": "hbm", "bound_observed": "valu+lds (vector issue and LDS cycles: valu_issue below; the HBM fraction is the metric's figure, "
+            "roofline": {"bound": "hbm", "bound_observed": "valu (vector instruction issue, the LDS array at about half: valu_issue below; the HBM fraction is the metric's figure, "
                                                            "not what limits this kernel)",
                          "kernel": "tile_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -46,6 +46,10 @@ b_alg = (2 * 640 * 480 + 28 * 875) * 1000
 traffic = (2 * avg.get('FETCH_SIZE', 0) + avg.get('WRITE_SIZE', 0)) * 1024
 open('gpurun_out/r5f/final_c2_traffic.txt', 'w').write(f"C2 (1000 pairs 640x480, 875 keypoints): tile_kernel FETCH_SIZE {avg.get('FETCH_SIZE', 0):.0f} KB, WRITE_SIZE {avg.get('WRITE_SIZE', 0):.0f} KB per launch -> (2 F + W) * 1024 = {traffic / 1e6:.1f} MB = {traffic / b_alg:.3f} x the algorithmic {b_alg / 1e6:.1f} MB\n")
 print(open('gpurun_out/r5f/final_c2_traffic.txt').read())
+import hashlib, json
+json.dump({"kernel": "tile_kernel", "config": "C2", "library_sha256_16": hashlib.sha256(open('mofreak_amd/libmofreak_hip.so', 'rb').read()).hexdigest()[:16], "pairs_per_launch": 1000,
+           "FETCH_SIZE_KB": avg.get('FETCH_SIZE', 0), "WRITE_SIZE_KB": avg.get('WRITE_SIZE', 0), "tile_kernel_hbm_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": b_alg,
+           "traffic_over_algorithmic": traffic / b_alg, "correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024, separate --pmc passes"}, open('gpurun_out/r5f/traffic_C2.json', 'w'), indent=1)
 PY
 rm -rf gpurun_out/r5f/c2pmc_*
 timeout -k 10 260 python tests/fuzz_parity_gpu.py 150 521 > gpurun_out/r5f/final_fuzz521.log 2>&1; echo fuzz rc=$?; tail -n 1 gpurun_out/r5f/final_fuzz521.log
