@@ -5,7 +5,9 @@ frame size, octaves and frame seed that replay it: `python tests/fuzz_parity_gpu
 fractional coordinates, shared list or one list per pair), random byte frames or the synthetic ones, and compares
 descriptors and validity flags byte for byte; every few rounds also the detector's keypoints on a moving-object pair,
 a set of clips of random lengths through mofreak_extract_clips (against one call per clip), and the whole frame loop
-in one call (mofreak_compute_stream) against the detector and the descriptors in two.
+in one call (mofreak_compute_stream) against the detector and the descriptors in two; the clip sets' rows as text made on
+the device against the host formatter; the frame loop's stack cut into clips through mofreak_compute_clips and pushed in
+chunks into a detector stream.
 A new context every 20 s, a third of them with random FREAK parameters (bit mode, orientation / scale normalisation)."""
 import os
 import sys
@@ -140,6 +142,13 @@ def main():
                           offs_c.tolist() != np.concatenate([[0], np.cumsum([len(w) for w in want_c])]).tolist():
                       print(f"CLIPS MISMATCH round {rounds} seed {seed}: {Wc}x{Hc} lengths {lengths}")
                       sys.exit(1)
+                  if len(rows_c):  # the rows' text made on the device == the host formatter's, with a segment per clip
+                      import torch
+                      d_rows = torch.from_numpy(rows_c.view(np.uint8).reshape(-1).copy()).cuda()
+                      text, offs_t = ctx.format_rows_device(d_rows, len(rows_c), row_starts=offs_c[:-1])
+                      if text[:offs_t[-1]].tobytes() != M.format_rows(rows_c) or any(offs_t[i] != len(M.format_rows(rows_c[:offs_c[i]])) for i in range(len(offs_c) - 1)):
+                          print(f"TEXT MISMATCH round {rounds} seed {seed}: {Wc}x{Hc} lengths {lengths}")
+                          sys.exit(1)
                   clip_rounds += 1
               if rounds % 11 == 0 and not par:  # the frame loop in one call == detector, then descriptors
                   Wl, Hl, Tl = int(rng.choice([160, 320, 400])), int(rng.choice([120, 240])), int(rng.choice([21, 26, 38, 70]))
@@ -149,6 +158,20 @@ def main():
                   one = ctx.extract_stream_host(frl, kl, kp_offsets=ol)
                   if two.tobytes() != one.tobytes():
                       print(f"FRAME LOOP MISMATCH round {rounds} seed {seed}: {Wl}x{Hl} T {Tl}: {len(two)} vs {len(one)} rows")
+                      sys.exit(1)
+                  # the detector inside the pipelined routes: the stack cut into clips through mofreak_compute_clips == one frame loop
+                  # per clip; the whole stack pushed in chunks into a detector stream == the frame loop
+                  cuts = sorted(set(int(x) for x in rng.integers(0, Tl + 1, 3)) | {0, Tl})
+                  pieces = [np.ascontiguousarray(frl[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+                  rows_p, offs_p, _ = ctx.compute_clips(pieces, chunk_frames=int(rng.choice([0, 7, 12])))
+                  want_p = [ctx.compute_stream_host(c) for c in pieces]
+                  if rows_p.tobytes() != np.concatenate(want_p).tobytes() or offs_p.tolist() != np.concatenate([[0], np.cumsum([len(w) for w in want_p])]).tolist():
+                      print(f"DETECTOR CLIPS MISMATCH round {rounds} seed {seed}: {Wl}x{Hl} T {Tl} cuts {cuts}")
+                      sys.exit(1)
+                  with ctx.open_stream(Wl, Hl, use_detector=True) as st:
+                      parts = [st.push_frames(frl[a:b], None, chunk_frames=int(rng.choice([0, 9]))) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+                  if np.concatenate(parts).tobytes() != two.tobytes():
+                      print(f"DETECTOR STREAM MISMATCH round {rounds} seed {seed}: {Wl}x{Hl} T {Tl} cuts {cuts}")
                       sys.exit(1)
                   loop_rounds += 1
     print(f"fuzz ok: {rounds} rounds, {descriptors} descriptors, {detector_rounds} detector rounds, {clip_rounds} clip-set rounds, "
