@@ -123,6 +123,42 @@ def test_run_dataset_files_equal_the_one_rank_run(tmp_path, world):
     assert any((one / (n + ".mofreak")).stat().st_size == 0 for n in names)  # clips shorter than the frame gap
 
 
+def _ranks_write_worker(rank, world, port, outdir, keep_rows):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        clips, names = _clips()
+        res = harness.run_dataset(clips, names, outdir, _FakeMoFREAK(), rank=rank, world_size=world, write="ranks", keep_rows=keep_rows,
+                                  write_threads=2, batch_bytes=1500)  # (several rounds: the text buffers' turn-taking)
+        assert res["write"] == "ranks" and res["rounds"] > 1
+        mine = harness.shard_videos([len(c) for c in clips], world)[rank]
+        assert res["videos_here"] == len(mine)
+        assert res["text_bytes_here"] == sum(len(api.format_rows(_FakeMoFREAK().extract_rows(clips[i]))) for i in mine)
+        if rank == 0:  # the counts of everybody's videos reach the root either way; the rows only when they are kept
+            assert res["total_rows"] == sum(max(len(c) - 5, 0) * 3 for c in clips)
+            assert [int(x) for x in res["rows_per_video_counts"]] == [max(len(c) - 5, 0) * 3 for c in clips]
+            assert ("rows_per_video" in res) == keep_rows
+            if keep_rows:
+                for i, c in enumerate(clips):
+                    assert res["rows_per_video"][i].tobytes() == _FakeMoFREAK().extract_rows(c).tobytes()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,keep_rows", [(2, False), (3, False), (2, True)])
+def test_files_written_by_their_ranks_equal_the_one_rank_run(tmp_path, world, keep_rows):
+    """write="ranks": every rank formats and writes the files of its own videos (here the host formatter: no GPU); without
+    keep_rows the only thing that crosses ranks is the row counts."""
+    clips, names = _clips()
+    one, many = tmp_path / "one", tmp_path / "many"
+    harness.run_dataset(clips, names, str(one), _FakeMoFREAK())
+    mp.spawn(_ranks_write_worker, args=(world, _free_port(), str(many), keep_rows), nprocs=world, join=True)
+    assert sorted(os.listdir(one)) == sorted(os.listdir(many)) == sorted(n + ".mofreak" for n in names)
+    for n in names:
+        assert (one / (n + ".mofreak")).read_bytes() == (many / (n + ".mofreak")).read_bytes()
+
+
 def test_compute_mofreak_files_skips_existing(tmp_path):
     class Rec(_FakeMoFREAK):
         def __init__(self):
