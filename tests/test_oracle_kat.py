@@ -229,6 +229,21 @@ def test_kat6_resize_clamps(oracle):
     assert out[5, 0] == 200 and out[5, 18] == 100
 
 
+@pytest.mark.parametrize("L", list(range(2, 73)) + [100])
+def test_resize_stays_within_one_level_of_torch_s_bilinear(oracle, L):
+    """An implementation nobody here wrote: torch's bilinear interpolation (pixel centres at half-integers, edges clamped, no
+    antialiasing -- the convention cv::resize INTER_LINEAR is restated with), in float64.  The oracle's 11-bit fixed point with its
+    two roundings must stay within one grey level of it for every ROI side the path can meet, enlarging and reducing."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(L)
+    ramp = (np.add.outer(np.arange(L), np.arange(L)) * 255 // max(2 * L - 2, 1)).astype(np.uint8)
+    for src in (rng.integers(0, 256, (L, L), dtype=np.uint8), ramp, (rng.integers(0, 2, (L, L)) * 255).astype(np.uint8)):
+        ref = F.interpolate(torch.from_numpy(src.astype(np.float64))[None, None], size=(19, 19), mode="bilinear", align_corners=False,
+                            antialias=False)[0, 0].numpy()
+        assert np.abs(oracle.resize_linear(src).astype(np.float64) - ref).max() < 1.0
+
+
 # ------------------------------------------------------------------ absdiff / integral
 def test_absdiff_and_integral_match_numpy(oracle):
     rng = np.random.default_rng(1)
@@ -408,3 +423,18 @@ def test_bgr2gray_known_answers(oracle):
     px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 20, 30]]], np.uint8)
     assert oracle.bgr2gray(px)[0].tolist() == [255, 0, 29, 150, 76, (10 * 1868 + 20 * 9617 + 30 * 4899 + 8192) >> 14]
     assert 1868 + 9617 + 4899 == 1 << 14
+
+
+
+def test_bgr2gray_stays_within_one_level_of_bt601_and_pillow(oracle):
+    """cv::cvtColor(BGR2GRAY) is restated from recalled fixed-point constants; two things nobody here wrote agree with it: the
+    BT.601 luma in floating point (to the rounding) and Pillow's convert("L") (its own fixed point: equal on all but a few pixels
+    in a thousand, never more than one level apart)."""
+    from PIL import Image
+    rng = np.random.default_rng(44)
+    bgr = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
+    g = oracle.bgr2gray(bgr).astype(np.float64)
+    luma = 0.114 * bgr[..., 0] + 0.587 * bgr[..., 1] + 0.299 * bgr[..., 2]
+    assert np.abs(g - luma).max() <= 0.51
+    pil = np.asarray(Image.fromarray(np.ascontiguousarray(bgr[..., ::-1]), "RGB").convert("L")).astype(np.float64)
+    assert np.abs(g - pil).max() <= 1.0 and (g != pil).mean() < 0.01
