@@ -58,6 +58,16 @@ def test_hip_reproduces_golden_stream(gpu_ctx):
     assert M.format_rows(rows) == g["text"].tobytes()
 
 
+@pytest.mark.gpu
+def test_device_formatter_reproduces_the_golden_text(gpu_ctx):
+    """The committed stream's rows, put into HBM, come back from mofreak_format_rows_device as the committed text."""
+    import torch
+    g = np.load(os.path.join(GOLD, "golden_stream.npz"))
+    rows = np.ascontiguousarray(g["rows"]).view(np.uint8).reshape(-1)
+    text, total = gpu_ctx.format_rows_device(torch.from_numpy(rows.copy()).cuda(), len(rows) // 32)
+    assert text[:total].tobytes() == g["text"].tobytes()
+
+
 def _kp(a):
     import oracle_lib
     return a.copy().view(oracle_lib.KEYPOINT_DTYPE).reshape(-1)
