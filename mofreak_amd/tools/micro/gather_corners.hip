@@ -44,6 +44,24 @@ __global__ __launch_bounds__(256) void kernB(const uint32_t *integ, int pitch, c
         }
     }
 }
+// (C) as (A) on an integral stored in 4 x 4-entry blocks of 64 bytes (a 2-D blocked layout): bx = x >> 2, by = y >> 2
+__device__ __forceinline__ uint32_t blk(const uint32_t *integ, int pitch_b, int x, int y)
+{
+    return integ[(((size_t)(y >> 2) * pitch_b + (x >> 2)) << 4) + ((y & 3) << 2) + (x & 3)];
+}
+__global__ __launch_bounds__(256) void kernC(const uint32_t *integ, int pitch_b, const int2 *kps, int n, const Box *boxes, uint32_t *out)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = (gridDim.x * 256) >> 6;
+    const Box b = boxes[lane < 43 ? lane : 0];
+    for (int k = wave; k < n; k += nw) {
+        const int2 kp = kps[k];
+        if (lane < 43) {
+            const int x = kp.x + b.dx, y = kp.y + b.dy;
+            out[(size_t)k * 64 + lane] = blk(integ, pitch_b, x + b.w, y + b.h) - blk(integ, pitch_b, x, y + b.h) - blk(integ, pitch_b, x + b.w, y) + blk(integ, pitch_b, x, y);
+        }
+    }
+}
 int main(int argc, char **argv)
 {
     const int W = 1920, H = 1080, pitch = W + 1, pairs = 16;
@@ -75,22 +93,34 @@ int main(int argc, char **argv)
     hipMemcpy(d_kps, kps.data(), n * sizeof(int2), hipMemcpyHostToDevice);
     hipMemcpy(d_boxes, boxes.data(), 43 * sizeof(Box), hipMemcpyHostToDevice);
     hipMemset(d_outA, 0, (size_t)n * 256); hipMemset(d_outB, 0, (size_t)n * 256);
+    // the same values in the blocked layout (all pairs as one tall image of pairs * (H + 1) rows)
+    const int rows_all = pairs * (H + 1), pitch_b = (pitch + 3) / 4, rows_b = (rows_all + 3) / 4;
+    std::vector<uint32_t> integ_b((size_t)rows_b * pitch_b * 16, 0u);
+    for (int y = 0; y < rows_all; ++y)
+        for (int x = 0; x < pitch; ++x) integ_b[(((size_t)(y >> 2) * pitch_b + (x >> 2)) << 4) + ((y & 3) << 2) + (x & 3)] = integ[(size_t)y * pitch + x];
+    uint32_t *d_integ_b, *d_outC;
+    hipMalloc(&d_integ_b, integ_b.size() * 4); hipMalloc(&d_outC, (size_t)n * 256);
+    hipMemcpy(d_integ_b, integ_b.data(), integ_b.size() * 4, hipMemcpyHostToDevice);
+    hipMemset(d_outC, 0, (size_t)n * 256);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int which = 0; which < 2; ++which) {
+    for (int which = 0; which < 3; ++which) {
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0);
             for (int it = 0; it < 10; ++it) {
                 if (which == 0) hipLaunchKernelGGL(kernA, dim3(256 * 5), dim3(256), 0, 0, d_integ, pitch, d_kps, n, d_boxes, d_outA);
-                else hipLaunchKernelGGL(kernB, dim3(256 * 5), dim3(256), 0, 0, d_integ, pitch, d_kps, n, d_boxes, d_outB);
+                else if (which == 1) hipLaunchKernelGGL(kernB, dim3(256 * 5), dim3(256), 0, 0, d_integ, pitch, d_kps, n, d_boxes, d_outB);
+                else hipLaunchKernelGGL(kernC, dim3(256 * 5), dim3(256), 0, 0, d_integ_b, pitch_b, d_kps, n, d_boxes, d_outC);
             }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
-            printf("R=%d kernel %c: %.3f ms per launch of %d keypoints (%.2f ns per keypoint, %.1f G corner reads/s)\n", R, which ? 'B' : 'A', ms / 10, n, ms / 10 * 1e6 / n, 172.0 * n / (ms / 10) / 1e6);
+            printf("R=%d kernel %c: %.3f ms per launch of %d keypoints (%.2f ns per keypoint, %.1f G corner reads/s)\n", R, 'A' + which, ms / 10, n, ms / 10 * 1e6 / n, 172.0 * n / (ms / 10) / 1e6);
         }
     }
     std::vector<uint32_t> a((size_t)n * 64), b((size_t)n * 64);
     hipMemcpy(a.data(), d_outA, a.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), d_outB, b.size() * 4, hipMemcpyDeviceToHost);
-    size_t bad = 0; for (size_t i = 0; i < a.size(); ++i) bad += a[i] != b[i];
+    std::vector<uint32_t> c((size_t)n * 64);
+    hipMemcpy(c.data(), d_outC, c.size() * 4, hipMemcpyDeviceToHost);
+    size_t bad = 0; for (size_t i = 0; i < a.size(); ++i) bad += (a[i] != b[i]) + (a[i] != c[i]);
     printf("mismatches %zu\n", bad);
     return 0;
 }
