@@ -537,8 +537,11 @@ def bench_dataset(args):
         out_dir = os.path.join(base or ".", f"mofreak_bench_c4_{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if world > 1 else os.getpid()}")
         args.write_threads = args.write_threads or max(2, min(16, len(os.sched_getaffinity(0)) // max(1, world)))
         kw = {"write": "ranks", "keep_rows": False, "write_threads": args.write_threads}
-    harness.run_dataset(clips[: 64 * world], names[: 64 * world], out_dir, mo, rank, world, on_device=on_device,
-                        workers=args.workers, batched=batched, **kw)  # warm-up
+    # warm-up: a few clips -- with the detector all of them once, because what the detector finds sizes the buffers (rows, keypoints,
+    # page-locked memory), and growing them is not part of a step
+    n_warm = n_clips if brisk else 64 * world
+    harness.run_dataset(clips[:n_warm], names[:n_warm], out_dir, mo, rank, world, on_device=on_device,
+                        workers=args.workers, batched=batched, **kw)
     steps = args.steps or 1
     fence(torch, dist, world)
     t0 = time.perf_counter()

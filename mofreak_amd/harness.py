@@ -360,8 +360,22 @@ def _extract_batch(mofreak, stacks, use_batched: bool, to_device, workers: int, 
                         if e.code != api.ERR_CAPACITY or _ == 1:
                             raise
                         per_pair = mofreak._rows_per_pair = per_pair * 4
+            elif len(sizes) > 1:  # (several frame sizes in one batch: a buffer of its own per size)
+                buf, offs, _ = mofreak._ctx.compute_clips(group, thr, octs, rows_per_pair=max(64, (W * H) // 64))
             else:
-                buf, offs, _ = mofreak._ctx.compute_clips(group, thr, octs)
+                # rows wanted on this host: into page-locked memory kept across calls (they travel back window by window under
+                # the pipeline's kernels, no staging copy) -- sized by a guess of the rows a pair yields, grown when a call says
+                # it was too small (a numpy array for the worst case would be gigabytes of pages to touch)
+                n_pairs = int(sum(max(s.shape[0] - gap, 0) for s in group))
+                per_pair = getattr(mofreak, "_rows_per_pair_host", max(64, (W * H) // 256))
+                for _ in range(4):
+                    try:
+                        buf, offs, _n_kp = mofreak._ctx.compute_clips(group, thr, octs, rows_out=_pinned_rows(mofreak, max(n_pairs * per_pair, 1)))
+                        break
+                    except api.MoFREAKError as e:
+                        if e.code != api.ERR_CAPACITY or _ == 3:
+                            raise
+                        per_pair = mofreak._rows_per_pair_host = per_pair * 4
             for k, j in enumerate(members):
                 counts[j] = int(offs[k + 1] - offs[k])
             pieces.append((buf, offs, members))

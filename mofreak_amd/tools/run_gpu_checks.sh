@@ -24,8 +24,8 @@ timeout -k 10 250 python bench.py --config C4 --gpus 2 --backend gloo --share-de
 timeout -k 10 250 python bench.py --config C4 --gpus 1 --backend nccl --force-dist --steps 3 > gpurun_out/r5f/final_bench_c4_nccl_n1.json 2> /dev/null; echo rc=$?
 timeout -k 10 250 python bench.py --config C4 --steps 3 --write > gpurun_out/r5f/final_bench_c4_write.json 2> /dev/null; echo rc=$?
 timeout -k 10 250 python bench.py --config C4 --clips 6766 --steps 1 --write > gpurun_out/r5f/final_bench_c4_6766_write.json 2> /dev/null; echo rc=$?
-timeout -k 10 250 python bench.py --config C4 --keypoints brisk --steps 1 > gpurun_out/r5f/final_bench_c4_brisk.json 2> /dev/null; echo rc=$?
-timeout -k 10 250 python bench.py --config C4 --keypoints brisk --steps 1 --write > gpurun_out/r5f/final_bench_c4_brisk_write.json 2> /dev/null; echo rc=$?
+timeout -k 10 250 python bench.py --config C4 --keypoints brisk --steps 2 > gpurun_out/r5f/final_bench_c4_brisk.json 2> /dev/null; echo rc=$?
+timeout -k 10 250 python bench.py --config C4 --keypoints brisk --steps 2 --write > gpurun_out/r5f/final_bench_c4_brisk_write.json 2> /dev/null; echo rc=$?
 timeout -k 10 250 python bench.py --config C5 --keypoints brisk --frames 2053 > gpurun_out/r5f/final_bench_c5_brisk.json 2> /dev/null; echo rc=$?
 timeout -k 10 200 python mofreak_amd/tools/bench_format.py > gpurun_out/r5f/final_format_bench.jsonl 2> /dev/null; echo rc=$?
 timeout -k 10 250 python bench.py --config C5 > gpurun_out/r5f/final_bench_c5.json 2> /dev/null; echo rc=$?
