@@ -619,15 +619,24 @@ def bench_stream_brisk(args):
     bufs = [ctx.host_alloc((chunk, H, W)) for _ in range(2)]
     rows = [ctx.host_alloc((chunk * 8192,), M.api.ROW_DTYPE) for _ in range(2)]
 
+    from concurrent.futures import ThreadPoolExecutor
+    filler = ThreadPoolExecutor(max_workers=1)  # the decoder's stand-in: the next chunk is put together while this one is pushed
+
+    def fill(b, t0, n):
+        for t in range(n):  # (the stream repeats its distinct frames; a forward-backward sweep keeps the motion continuous)
+            q = (t0 + t) % (2 * distinct - 2)
+            bufs[b][t] = base[q if q < distinct else 2 * distinct - 2 - q]
+        return n
+
     def one_pass(n_frames):
         total = 0
+        starts = list(range(0, n_frames, chunk))
         with ctx.open_stream(W, H, use_detector=True) as st:
-            for k, t0 in enumerate(range(0, n_frames, chunk)):
-                n = min(chunk, n_frames - t0)
-                b = k & 1
-                for t in range(n):  # (the stream repeats its distinct frames; a forward-backward sweep keeps the motion continuous)
-                    q = (t0 + t) % (2 * distinct - 2)
-                    bufs[b][t] = base[q if q < distinct else 2 * distinct - 2 - q]
+            nxt = filler.submit(fill, 0, 0, min(chunk, n_frames))
+            for k, t0 in enumerate(starts):
+                n, b = nxt.result(), k & 1
+                if k + 1 < len(starts):
+                    nxt = filler.submit(fill, b ^ 1, starts[k + 1], min(chunk, n_frames - starts[k + 1]))
                 total += len(st.push_frames(bufs[b][:n], None, chunk_frames=args.chunk if args.chunk < chunk else 0, rows_out=rows[b]))
         return total
 
@@ -639,6 +648,7 @@ def bench_stream_brisk(args):
         total = one_pass(T)
     fence(torch, dist, world)
     elapsed = max_over_ranks(torch, dist, world, on_device, time.perf_counter() - t0)
+    filler.shutdown()
     for b in bufs + rows:
         ctx.host_free(b)
     if rank == 0:
