@@ -56,7 +56,8 @@ struct mofreak_ctx {
         int W = 0, H = 0, pairs = 0;
     } det_diff;
     bool use_det_diff = false;
-    int det_cand_cap = 131072;
+    int det_cand_cap = 131072;  // most candidates (corners) per pair the detector will reserve room for (mofreak_detect_set_capacity)
+    int det_cand_shift = 0;     // what a call starts from is W * H / 8 << det_cand_shift, below that limit: grown (x 4) by a call that met more
     size_t det_counter_bytes = 0;  // row counts + tie counters behind the running total in det_rows
     int64_t det_kp_capacity = 0;
     ThetaBound *d_theta = nullptr;
@@ -1907,10 +1908,21 @@ int det_geometry(const mofreak_ctx *ctx, int W, int H, int octaves, DetGeom &g)
     return MOFREAK_OK;
 }
 
+// Candidates (corners of all layers) per pair the workspace is laid out for: an eighth of the frame's pixels -- difference
+// images have 1-2 % -- at least 4096, grown by calls that met more, never above the context's limit.  The grids of the
+// per-candidate kernels and the pairs a batch takes follow from it: a 320 x 240 pair does not pay for a full-HD pair's lists.
+int det_cand_eff(const mofreak_ctx *ctx, const DetGeom &g)
+{
+    const int64_t px = (int64_t)g.L[0].w * g.L[0].h;
+    const int64_t want = ((std::max<int64_t>(4096, px / 8) + 1023) / 1024 * 1024) << std::min(ctx->det_cand_shift, 16);
+    return (int)std::min<int64_t>(ctx->det_cand_cap, want);
+}
+
 int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
 {
     int rc;
-    const size_t planes = (size_t)batch * g.plane_bytes, cands = (size_t)batch * ctx->det_cand_cap;
+    const int cand_cap = det_cand_eff(ctx, g);
+    const size_t planes = (size_t)batch * g.plane_bytes, cands = (size_t)batch * cand_cap;
     if ((rc = ensure(ctx, ctx->det_img, planes))) return rc;
     if ((rc = ensure(ctx, ctx->det_score, planes))) return rc;
     // The two bookkeeping maps of the tie logic are all zero between calls: the emission takes back every byte a call set.
@@ -1927,7 +1939,7 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
         ctx->det_maps_dirty = false;
     }
     if ((rc = ensure(ctx, ctx->det_hit_mask, (size_t)batch * g.mask_words * sizeof(unsigned long long)))) return rc;
-    a.walk_chunks = (ctx->det_cand_cap + 511) / 512;
+    a.walk_chunks = (cand_cap + 511) / 512;
     if ((rc = ensure(ctx, ctx->det_walk_list, cands * sizeof(int32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_walk_count, (size_t)batch * a.walk_chunks * sizeof(int32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_cand_cells, cands * 64))) return rc;
@@ -1946,7 +1958,7 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     if ((rc = ensure(ctx, ctx->det_layer_start, (size_t)batch * (kDetMaxLayers + 1) * sizeof(int32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_emit_count, (size_t)batch * sizeof(int32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->det_emit_offsets, (size_t)(batch + 1) * sizeof(int64_t)))) return rc;
-    a.emit_chunk_cap = (ctx->det_cand_cap + 1023) / 1024;
+    a.emit_chunk_cap = (cand_cap + 1023) / 1024;
     if ((rc = ensure(ctx, ctx->det_emit_chunks, (size_t)batch * a.emit_chunk_cap * sizeof(int32_t)))) return rc;
     a.g = g;
     // the device copy of the geometry: sent when it changes (a stream of equal-sized frames: once)
@@ -1969,7 +1981,7 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
     a.tie_list = static_cast<DetTie *>(ctx->det_tie_list.ptr);
     a.tie_count = static_cast<int32_t *>(ctx->det_tie_count.ptr);
     ctx->det_counter_bytes = n_row_counts * sizeof(int32_t);
-    a.cand_cap = ctx->det_cand_cap;
+    a.cand_cap = cand_cap;
     a.cand_xy = static_cast<uint32_t *>(ctx->det_cand_xy.ptr);
     a.cand_flag = static_cast<uint8_t *>(ctx->det_cand_flag.ptr);
     a.cand_emit = static_cast<uint8_t *>(ctx->det_cand_emit.ptr);
@@ -1992,7 +2004,7 @@ int det_workspace(mofreak_ctx *ctx, const DetGeom &g, int batch, DetArgs &a)
 int det_batch(const mofreak_ctx *ctx, const DetGeom &g, int n_pairs)
 {
     const size_t per_pair = 4 * (size_t)g.plane_bytes + (size_t)g.mask_words * 8 +
-                            (size_t)ctx->det_cand_cap * (sizeof(uint32_t) + 3 + 12 + sizeof(DetResult) + sizeof(int32_t) + 64 + 8);
+                            (size_t)det_cand_eff(ctx, g) * (sizeof(uint32_t) + 3 + 12 + sizeof(DetResult) + sizeof(int32_t) + 64 + 8);
     const size_t b = std::max<size_t>(1, ((size_t)8 << 30) / per_pair);
     return (int)std::min<size_t>({b, (size_t)std::max(n_pairs, 1), (size_t)16384});
 }
@@ -2053,6 +2065,9 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
             d_layer = static_cast<int32_t *>(ctx->det_out_layer.ptr);
         }
     }
+    int64_t total = 0;
+    int32_t st = 0;
+    for (;;) {  // (again from the start, with room for four times the candidates, when a pair had more than the workspace's share)
     const int batch = det_batch(ctx, g, n_pairs);
     DetArgs a{};
     if ((rc = det_workspace(ctx, g, batch, a))) return rc;
@@ -2085,10 +2100,17 @@ int mofreak_detect_pairs(mofreak_ctx *ctx, const uint8_t *cur, const uint8_t *pr
     int64_t head[2] = {0, 0};  // the running total and, behind it, the status word
     HIP_TRY(ctx, hipMemcpyAsync(head, running, sizeof(head), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const int64_t total = head[0];
-    const int32_t st = (int32_t)(uint32_t)(uint64_t)head[1];
-    if (n_out) *n_out = total;
+    total = head[0];
+    st = (int32_t)(uint32_t)(uint64_t)head[1];
     ctx->det_maps_dirty = (st & (16 | 32 | 64)) != 0;  // (else) the emission of every batch has taken its bytes back
+    if ((st & 4) && !(st & (16 | 32 | 64)) && det_cand_eff(ctx, g) < ctx->det_cand_cap) {
+        ctx->det_cand_shift += 2;    // kept for the context's later calls
+        ctx->det_maps_dirty = true;  // (candidates past the workspace's share were not followed: nothing is taken for granted)
+        continue;
+    }
+    break;
+    }
+    if (n_out) *n_out = total;
     if (st & 64) return fail(ctx, MOFREAK_ERR_HIP, "detector: the bookkeeping maps were not clean when the call started (internal error; bounds-checking build)");
     if (st & 16) return fail(ctx, MOFREAK_ERR_HIP, "detector: a refinement walk left its staged window (internal error)");
     if (st & 32) return fail(ctx, MOFREAK_ERR_HIP, "detector: a chain of tied scores did not resolve within its pass budget (internal error)");
