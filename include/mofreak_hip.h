@@ -325,10 +325,11 @@ int mofreak_stream_push_frames(mofreak_stream *s, const uint8_t *frames, int n_f
 int64_t mofreak_stream_frames(const mofreak_stream *s); /* frames pushed so far */
 void mofreak_stream_close(mofreak_stream *s);
 
-/* The most candidates (corners of a pair's pyramid) per pair the detector will reserve room for (default 131072); more
- * corners than that in one pair make mofreak_detect_pairs return MOFREAK_ERR_CAPACITY.  Below that limit the room follows
- * the frames: a call starts from an eighth of the frame's pixels and, when a pair has more, runs again with four times that
- * (kept for the context's later calls) -- small frames do not pay for a full-HD pair's lists. */
+/* Candidates (corners of a pair's pyramid) per pair the detector reserves room for; more corners than that in one pair make
+ * mofreak_detect_pairs return MOFREAK_ERR_CAPACITY.  By default (and again after candidates_per_pair = 0) the room follows the
+ * frames: a call starts from an eighth of the frame's pixels and, when a pair has more, runs again with four times that (kept
+ * for the context's later calls), up to 131072 -- small frames do not pay for a full-HD pair's lists.  A number names the room
+ * outright (256 .. 2^24). */
 int mofreak_detect_set_capacity(mofreak_ctx *ctx, int candidates_per_pair);
 
 /* Components, for tests and for callers that want the pyramid: the layers of BriskScaleSpace::constructPyramid over

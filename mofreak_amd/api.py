@@ -351,8 +351,10 @@ class Context:
         return FrameStream(self, W, H, use_detector, threshold, octaves)
 
     def set_detect_capacity(self, candidates_per_pair: int):
+        """Candidates per pair the detector reserves room for; 0: the default again -- room by frame size, grown on demand, at
+        most 131072 per pair (mofreak_detect_set_capacity)."""
         self._check(self._lib.mofreak_detect_set_capacity(self._h, candidates_per_pair))
-        self._det_cand_cap = int(candidates_per_pair)
+        self._det_cand_cap = int(candidates_per_pair) or 131072
 
     def brisk_pyramid_host(self, img: np.ndarray, octaves=3, scores=True):
         """-> list of (layer image, score map or None, scale, offset) per pyramid layer."""

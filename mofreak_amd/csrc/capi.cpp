@@ -57,7 +57,8 @@ struct mofreak_ctx {
     } det_diff;
     bool use_det_diff = false;
     int det_cand_cap = 131072;  // most candidates (corners) per pair the detector will reserve room for (mofreak_detect_set_capacity)
-    int det_cand_shift = 0;     // what a call starts from is W * H / 8 << det_cand_shift, below that limit: grown (x 4) by a call that met more
+    bool det_cand_auto = true;  // the room follows the frames (below); false once the caller has named a number: then that is what is reserved
+    int det_cand_shift = 0;     // automatic: a call starts from W * H / 8 << det_cand_shift, below the limit; grown (x 4) by a call that met more
     size_t det_counter_bytes = 0;  // row counts + tie counters behind the running total in det_rows
     int64_t det_kp_capacity = 0;
     ThetaBound *d_theta = nullptr;
@@ -1913,6 +1914,7 @@ int det_geometry(const mofreak_ctx *ctx, int W, int H, int octaves, DetGeom &g)
 // per-candidate kernels and the pairs a batch takes follow from it: a 320 x 240 pair does not pay for a full-HD pair's lists.
 int det_cand_eff(const mofreak_ctx *ctx, const DetGeom &g)
 {
+    if (!ctx->det_cand_auto) return ctx->det_cand_cap;
     const int64_t px = (int64_t)g.L[0].w * g.L[0].h;
     const int64_t want = ((std::max<int64_t>(4096, px / 8) + 1023) / 1024 * 1024) << std::min(ctx->det_cand_shift, 16);
     return (int)std::min<int64_t>(ctx->det_cand_cap, want);
@@ -2016,8 +2018,14 @@ extern "C" {
 int mofreak_detect_set_capacity(mofreak_ctx *ctx, int candidates_per_pair)
 {
     if (!ctx) return MOFREAK_ERR_BAD_ARG;
-    if (candidates_per_pair < 256 || candidates_per_pair > (1 << 24)) return fail(ctx, MOFREAK_ERR_BAD_ARG, "candidates_per_pair must be in 256..2^24");
+    if (candidates_per_pair == 0) {  // back to the default: room by frame size, at most 131072 per pair
+        ctx->det_cand_auto = true;
+        ctx->det_cand_cap = 131072;
+        return MOFREAK_OK;
+    }
+    if (candidates_per_pair < 256 || candidates_per_pair > (1 << 24)) return fail(ctx, MOFREAK_ERR_BAD_ARG, "candidates_per_pair must be 0 (automatic) or in 256..2^24");
     ctx->det_cand_cap = candidates_per_pair;
+    ctx->det_cand_auto = false;
     return MOFREAK_OK;
 }
 

@@ -157,7 +157,7 @@ def test_frame_loop_grows_its_keypoint_buffers(ctx):
         kps_d, offs_d, _, _ = ctx.detect_pairs_host(fr[5:], fr[:-5], capacity=T * 40000)
         plain = ctx.extract_stream_host(fr, kps_d, kp_offsets=offs_d)
     finally:
-        ctx.set_detect_capacity(131072)
+        ctx.set_detect_capacity(0)  # (the default: room by frame size)
     assert len(got) > 17 * 8192 and got.tobytes() == plain.tobytes()
 
 
@@ -176,7 +176,7 @@ def test_frame_loop_in_several_detector_batches(ctx):
             n_rows, n_kp = ctx.compute_stream(fr, T, W, H, np.zeros(10, M.api.ROW_DTYPE), capacity=10)
         assert e.value.code == M.api.ERR_CAPACITY and str(len(plain)) in str(e.value)
     finally:
-        ctx.set_detect_capacity(131072)
+        ctx.set_detect_capacity(0)  # (the default: room by frame size)
     assert len(got) > 200 and got.tobytes() == plain.tobytes()
     assert len(set(got["frame_number"].tolist())) > 20  # rows from every batch
 
@@ -192,7 +192,7 @@ def test_rows_wider_than_one_chunk(ctx):
     try:
         kps, offs, resp, layer = ctx.detect_pairs_host(img, None, 30, 2)
     finally:
-        ctx.set_detect_capacity(131072)
+        ctx.set_detect_capacity(0)  # (the default: room by frame size)
     _assert_same_keypoints((kps, resp, layer), _oracle_keypoints(img, 30, 2), "4400-wide")
     near = np.abs(kps[:, 0] - 2048) < 6
     assert near.any(), "no keypoint next to the chunk boundary: the input does not test it"
@@ -211,9 +211,35 @@ def test_full_hd_pair_and_capacity_errors(ctx):
     with pytest.raises(M.MoFREAKError) as e:
         ctx.detect_pairs_host(fr[5], fr[0])
     assert e.value.code == M.api.ERR_CAPACITY
-    ctx.set_detect_capacity(131072)
+    ctx.set_detect_capacity(0)  # (the default: room by frame size)
     again = ctx.detect_pairs_host(fr[5], fr[0])
     assert again[0].tobytes() == kps.tobytes()
+
+
+def test_candidate_room_follows_the_frames_and_grows():
+    """The default: room for an eighth of the frame's pixels as candidates per pair (at least 4096), grown four-fold by a call that
+    meets more.  Blocky few-level noise on a small frame has several times that: the call runs again by itself and gives the
+    oracle's keypoints -- the first time, the second time (the room is kept), and for a quiet image afterwards; and a number named
+    by the caller is the room outright: too small a one is an error, not a retry."""
+    noisy = _quantised_noise(5, 150, 200, levels=3, block=2)
+    quiet = O.absdiff(*synth.moving_objects_stack(6, 200, 150, seed=4)[[5, 0]])
+    want_noisy, want_quiet = _oracle_keypoints(noisy), _oracle_keypoints(quiet)
+    b = O.Brisk(noisy, 3)
+    b.get_keypoints(30)
+    assert sum(len(b.layer_points(l)) for l in range(b.n_layers)) > 2 * 4096  # (the input does ask for more room than the start)
+    with M.Context(0) as fresh:
+        for turn in range(2):
+            kps, offs, resp, layer = fresh.detect_pairs_host(noisy, None)
+            _assert_same_keypoints((kps, resp, layer), want_noisy, f"noisy, turn {turn}")
+        kps, offs, resp, layer = fresh.detect_pairs_host(quiet, None)
+        _assert_same_keypoints((kps, resp, layer), want_quiet, "quiet")
+        fresh.set_detect_capacity(512)
+        with pytest.raises(M.MoFREAKError) as e:
+            fresh.detect_pairs_host(noisy, None)
+        assert e.value.code == M.api.ERR_CAPACITY
+        fresh.set_detect_capacity(0)
+        kps, offs, resp, layer = fresh.detect_pairs_host(noisy, None)
+        _assert_same_keypoints((kps, resp, layer), want_noisy, "noisy, automatic again")
 
 
 def test_detect_then_describe_gives_the_reference_rows(ctx, oracle):
@@ -278,7 +304,7 @@ def test_many_pairs_in_several_batches(ctx):
     try:
         many = ctx.detect_pairs_host(cur, prev)
     finally:
-        ctx.set_detect_capacity(131072)
+        ctx.set_detect_capacity(0)  # (the default: room by frame size)
     for a, b in zip(one, many):
         assert a.tobytes() == b.tobytes()
     assert len(one[1]) == 6 and np.all(np.diff(one[1]) > 0)
